@@ -1,0 +1,272 @@
+"""
+ctypes front-end of the CPU oracle (oracle/svmc_oracle.c) plus a NumPy restatement of the same path.
+
+TEST INFRASTRUCTURE ONLY.  The product package (stochvolmodels_amd) never imports this module; only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker / CPU baseline.
+
+Parity pinning: tests/test_oracle_golden.py checks every function here against the golden vectors
+made by tests/golden/make_golden.py from the unmodified Python reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsvmc_oracle.so")
+
+CALL, PUT, INV_CALL, INV_PUT = 0, 1, 2, 3
+LOG_RETURN, Q_VAR, SIGMA = 1, 2, 3
+HESTON_EULER_FLOOR, HESTON_QE = 0, 1
+TYPE_CODES = {"C": CALL, "P": PUT, "IC": INV_CALL, "IP": INV_PUT}
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """compile oracle/libsvmc_oracle.so with the committed Makefile (gcc only)."""
+    src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("svmc_oracle.c", "svmc_oracle.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_time:
+        subprocess.run(["make", "-C", _HERE, "-B", "libsvmc_oracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        sz, i32, u32, u64, f64 = C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+        L.svo_set_time_grid.argtypes = [f64, i32, C.POINTER(i32), _dp]
+        L.svo_logsv_terminal_w.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, f64, f64, i32,
+                                           _dp, _dp, sz]
+        L.svo_heston_terminal_w.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, _dp, _dp, sz]
+        L.svo_heston_qe_terminal_w.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64,
+                                               _dp, _dp, _dp, sz]
+        L.svo_payoff.argtypes = [sz, _dp, _dp, f64, f64, f64, sz, _dp, C.POINTER(C.c_int8), i32, _dp, _dp]
+        L.svo_payoff.restype = i32
+        L.svo_philox4x32_10.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        L.svo_fill_normals.argtypes = [u64, u32, u64, u32, sz, i32, _dp, _dp, sz]
+        L.svo_fill_uniforms.argtypes = [u64, u32, u64, u32, sz, i32, _dp, sz]
+        L.svo_logsv_terminal_rng.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, f64, f64, i32,
+                                             u64, u32, u64, u32]
+        L.svo_heston_terminal_rng.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, i32,
+                                              u64, u32, u64, u32]
+        for name in ("svo_set_time_grid", "svo_logsv_terminal_w", "svo_heston_terminal_w",
+                     "svo_heston_qe_terminal_w", "svo_philox4x32_10", "svo_fill_normals",
+                     "svo_fill_uniforms", "svo_logsv_terminal_rng", "svo_heston_terminal_rng"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def _state(*arrs) -> Tuple[np.ndarray, ...]:
+    return tuple(np.array(a, dtype=np.float64, order="C", copy=True) for a in arrs)
+
+
+def _w(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    assert a.ndim == 2
+    return a
+
+
+def type_codes(optiontypes: Sequence[str]) -> np.ndarray:
+    """'C','P','IC','IP' -> int8 codes; unknown -> ValueError like utils/mc_payoffs.py:84."""
+    out = np.empty(len(optiontypes), dtype=np.int8)
+    for i, t in enumerate(optiontypes):
+        t = str(t)
+        if t not in TYPE_CODES:
+            raise ValueError("unknown option payoff code")
+        out[i] = TYPE_CODES[t]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# C oracle wrappers
+# ---------------------------------------------------------------------------------------------------
+def set_time_grid(ttm: float, nb_steps_per_year: int = 360) -> Tuple[int, float]:
+    n, dt = C.c_int(), C.c_double()
+    lib().svo_set_time_grid(float(ttm), int(nb_steps_per_year), C.byref(n), C.byref(dt))
+    return n.value, dt.value
+
+
+def logsv_terminal_w(x0, sigma0, qvar0, dt, theta, kappa1, kappa2, beta, volvol, W0, W1,
+                     eta=1.0, is_spot_measure=True):
+    x, s, q = _state(x0, sigma0, qvar0)
+    W0, W1 = _w(W0), _w(W1)
+    nb_steps, n = W0.shape
+    assert W1.shape == W0.shape and x.shape == s.shape == q.shape == (n,)
+    lib().svo_logsv_terminal_w(n, nb_steps, dt, _p(x), _p(s), _p(q), theta, kappa1, kappa2, beta, volvol,
+                               eta, int(bool(is_spot_measure)), _p(W0), _p(W1), n)
+    return x, s, q
+
+
+def heston_terminal_w(x0, var0, qvar0, dt, theta, kappa, rho, volvol, W0, W1):
+    x, v, q = _state(x0, var0, qvar0)
+    W0, W1 = _w(W0), _w(W1)
+    nb_steps, n = W0.shape
+    lib().svo_heston_terminal_w(n, nb_steps, dt, _p(x), _p(v), _p(q), theta, kappa, rho, volvol,
+                                _p(W0), _p(W1), n)
+    return x, v, q
+
+
+def heston_qe_terminal_w(x0, var0, qvar0, dt, theta, kappa, rho, volvol, Z0, Z1, U):
+    x, v, q = _state(x0, var0, qvar0)
+    Z0, Z1, U = _w(Z0), _w(Z1), _w(U)
+    nb_steps, n = Z0.shape
+    lib().svo_heston_qe_terminal_w(n, nb_steps, dt, _p(x), _p(v), _p(q), theta, kappa, rho, volvol,
+                                   _p(Z0), _p(Z1), _p(U), n)
+    return x, v, q
+
+
+def payoff(x, qvar, ttm, forward, strikes, optiontypes, discfactor=1.0, variable_type=LOG_RETURN):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    qvar = np.ascontiguousarray(qvar, dtype=np.float64)
+    strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+    codes = type_codes(optiontypes) if not (isinstance(optiontypes, np.ndarray) and optiontypes.dtype == np.int8) \
+        else optiontypes
+    prices, stderrs = np.empty_like(strikes), np.empty_like(strikes)
+    rc = lib().svo_payoff(x.size, _p(x), _p(qvar), ttm, forward, discfactor, strikes.size, _p(strikes),
+                          codes.ctypes.data_as(C.POINTER(C.c_int8)), int(variable_type), _p(prices), _p(stderrs))
+    if rc == -1:
+        raise ValueError("unknown option payoff code")
+    if rc == -2:
+        raise NotImplementedError
+    return prices, stderrs
+
+
+def philox4x32_10(ctr: Sequence[int], key: Sequence[int]) -> Tuple[int, int, int, int]:
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().svo_philox4x32_10(c, k, o)
+    return tuple(int(v) for v in o)
+
+
+def fill_normals(seed, n_path, nb_steps, call_id=0, path_offset=0, step_offset=0):
+    W0 = np.empty((nb_steps, n_path)), np.empty((nb_steps, n_path))
+    W0, W1 = W0
+    lib().svo_fill_normals(seed, call_id, path_offset, step_offset, n_path, nb_steps, _p(W0), _p(W1), n_path)
+    return W0, W1
+
+
+def fill_uniforms(seed, n_path, nb_steps, call_id=0, path_offset=0, step_offset=0):
+    U = np.empty((nb_steps, n_path))
+    lib().svo_fill_uniforms(seed, call_id, path_offset, step_offset, n_path, nb_steps, _p(U), n_path)
+    return U
+
+
+def logsv_terminal_rng(x0, sigma0, qvar0, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, seed,
+                       eta=1.0, is_spot_measure=True, call_id=0, path_offset=0, step_offset=0):
+    x, s, q = _state(x0, sigma0, qvar0)
+    lib().svo_logsv_terminal_rng(x.size, nb_steps, dt, _p(x), _p(s), _p(q), theta, kappa1, kappa2, beta, volvol,
+                                 eta, int(bool(is_spot_measure)), seed, call_id, path_offset, step_offset)
+    return x, s, q
+
+
+def heston_terminal_rng(x0, var0, qvar0, nb_steps, dt, theta, kappa, rho, volvol, seed,
+                        scheme=HESTON_EULER_FLOOR, call_id=0, path_offset=0, step_offset=0):
+    x, v, q = _state(x0, var0, qvar0)
+    lib().svo_heston_terminal_rng(x.size, nb_steps, dt, _p(x), _p(v), _p(q), theta, kappa, rho, volvol,
+                                  int(scheme), seed, call_id, path_offset, step_offset)
+    return x, v, q
+
+
+# ---------------------------------------------------------------------------------------------------
+# chain drivers (restating pricers/logsv_pricer.py:806-867, :1100-1162, pricers/heston_pricer.py:285-331)
+# ---------------------------------------------------------------------------------------------------
+def logsv_chain_fixed_randoms(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, W0s, W1s, dts,
+                              v0, theta, kappa1, kappa2, beta, volvol, vol_backbone_etas,
+                              is_spot_measure=True, variable_type=LOG_RETURN, return_states=False):
+    n = np.asarray(W0s[0]).shape[1]
+    x, s, q = np.zeros(n), v0 * np.ones(n), np.zeros(n)
+    prices, stderrs, states = [], [], []
+    for ttm, F, DF, K, ty, eta, W0, W1, dt in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                                  vol_backbone_etas, W0s, W1s, dts):
+        x, s, q = logsv_terminal_w(x, s, q, float(dt), theta, kappa1, kappa2, beta, volvol, W0, W1,
+                                   eta=float(eta), is_spot_measure=is_spot_measure)
+        p, e = payoff(x, q, float(ttm), float(F), K, ty, float(DF), variable_type)
+        prices.append(p), stderrs.append(e), states.append((x.copy(), s.copy(), q.copy()))
+    return (prices, stderrs, states) if return_states else (prices, stderrs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# NumPy restatement (array code, one vector pass per line like the reference) -- second witness for
+# the C oracle and the like-for-like single-core baseline of the reference's NumPy/Numba array code.
+# ---------------------------------------------------------------------------------------------------
+def np_logsv_terminal_w(x0, sigma0, qvar0, dt, theta, kappa1, kappa2, beta, volvol, W0, W1,
+                        eta=1.0, is_spot_measure=True):
+    """pricers/logsv_pricer.py:1028-1045 restated."""
+    x, sigma, qvar = (np.array(a, dtype=np.float64) for a in (x0, sigma0, qvar0))
+    sdt = np.sqrt(dt)
+    alpha, adj = (-1.0, 0.0) if is_spot_measure else (1.0, beta * eta)
+    vartheta2 = beta * beta + volvol * volvol
+    eta2 = eta * eta
+    L = np.log(sigma)
+    for w0, w1 in zip(np.asarray(W0), np.asarray(W1)):
+        w0 = sdt * w0
+        w1 = sdt * w1
+        s2dt = eta2 * sigma * sigma * dt
+        x = x + alpha * 0.5 * s2dt + eta * sigma * w0
+        L = L + ((kappa1 * theta / sigma - kappa1) + kappa2 * (theta - sigma) + adj * sigma - 0.5 * vartheta2) * dt \
+            + beta * w0 + volvol * w1
+        sigma = np.exp(L)
+        qvar = qvar + 0.5 * (s2dt + eta2 * sigma * sigma * dt)
+    return x, sigma, qvar
+
+
+def np_heston_terminal_w(x0, var0, qvar0, dt, theta, kappa, rho, volvol, W0, W1):
+    """pricers/heston_pricer.py:368-379 restated."""
+    x, var, qvar = (np.array(a, dtype=np.float64) for a in (x0, var0, qvar0))
+    sdt = np.sqrt(dt)
+    rho_1 = np.sqrt(1.0 - rho * rho)
+    for w0, w1 in zip(np.asarray(W0), np.asarray(W1)):
+        w0 = sdt * w0
+        w1 = sdt * w1
+        sigma = np.sqrt(var)
+        s2dt = var * dt
+        x = x - 0.5 * s2dt + sigma * w0
+        qvar = qvar + s2dt
+        var = var + kappa * (theta - var) * dt + sigma * volvol * (rho * w0 + rho_1 * w1)
+        var = np.maximum(var, 1e-4)
+    return x, var, qvar
+
+
+def np_payoff(x, qvar, ttm, forward, strikes, optiontypes, discfactor=1.0, variable_type=LOG_RETURN):
+    """utils/mc_payoffs.py:61-88 restated."""
+    x = np.asarray(x, dtype=np.float64)
+    spots = forward * np.exp(x)
+    spots = spots - (np.nanmean(spots) - forward)
+    if variable_type == LOG_RETURN:
+        u = spots
+    elif variable_type == Q_VAR:
+        u = np.asarray(qvar) / ttm
+    else:
+        raise NotImplementedError
+    prices, stds = np.zeros(len(strikes)), np.zeros(len(strikes))
+    with np.errstate(all="ignore"):
+        for i, (K, ty) in enumerate(zip(strikes, optiontypes)):
+            ty = str(ty)
+            if ty == "C":
+                pay = np.where(u > K, u - K, 0.0)
+            elif ty == "IC":
+                pay = np.where(u > K, u - K, 0.0) / spots
+            elif ty == "P":
+                pay = np.where(u < K, K - u, 0.0)
+            elif ty == "IP":
+                pay = np.where(u < K, K - u, 0.0) / spots
+            else:
+                raise ValueError("unknown option payoff code")
+            prices[i] = discfactor * np.nanmean(pay)
+            stds[i] = discfactor * np.nanstd(pay)
+    return prices, stds / np.sqrt(x.shape[0])

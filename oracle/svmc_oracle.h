@@ -1,0 +1,97 @@
+/*
+ * svmc_oracle.h -- CPU restatement (plain C, IEEE fp64, no fast-math, no FMA contraction) of the
+ * Monte Carlo hot path of ArturSepp/StochVolModels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under stochvolmodels_amd/ may include, link, import or execute
+ * this code; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / the timed CPU baseline, never as the product.
+ *
+ * Parity pinning: every function below is checked against golden vectors produced by importing the
+ * unmodified Python reference (NumPy mode) in the build container -- tests/golden/make_golden.py,
+ * tests/test_oracle_golden.py.
+ *
+ * Citations are relative to the reference checkout (src/stochvolmodels/...).
+ */
+#ifndef SVMC_ORACLE_H
+#define SVMC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* option payoff codes, utils/config.py:8-15 (C, P, IC, IP) */
+enum { SVO_CALL = 0, SVO_PUT = 1, SVO_INV_CALL = 2, SVO_INV_PUT = 3 };
+/* VariableType, utils/config.py:18-24 */
+enum { SVO_LOG_RETURN = 1, SVO_Q_VAR = 2, SVO_SIGMA = 3 };
+/* Heston discretisation */
+enum { SVO_HESTON_EULER_FLOOR = 0, SVO_HESTON_QE = 1 };
+
+/* utils/funcs.py:24-48  set_time_grid */
+void svo_set_time_grid(double ttm, int nb_steps_per_year, int *nb_steps, double *dt);
+
+/* pricers/logsv_pricer.py:950-1047  simulate_logsv_x_vol_terminal, W0/W1 supplied (unscaled N(0,1),
+ * step-major [nb_steps][ldw], path p at column p).  State updated in place. */
+void svo_logsv_terminal_w(size_t n_path, int nb_steps, double dt,
+                          double *x, double *sigma, double *qvar,
+                          double theta, double kappa1, double kappa2, double beta, double volvol,
+                          double eta, int is_spot_measure,
+                          const double *W0, const double *W1, size_t ldw);
+
+/* pricers/heston_pricer.py:334-381  simulate_heston_x_vol_terminal with the normals supplied
+ * (unscaled, same layout).  `var` is the variance; returns variance like the reference. */
+void svo_heston_terminal_w(size_t n_path, int nb_steps, double dt,
+                           double *x, double *var, double *qvar,
+                           double theta, double kappa, double rho, double volvol,
+                           const double *W0, const double *W1, size_t ldw);
+
+/* Andersen (2008) QE-M scheme for Heston (NOT in the reference).  Z0 drives the
+ * log-price, Z1 the quadratic branch of the variance, U the exponential branch. psi_c = 1.5,
+ * gamma1 = gamma2 = 0.5.  qvar accumulates the trapezoid of v. */
+void svo_heston_qe_terminal_w(size_t n_path, int nb_steps, double dt,
+                              double *x, double *var, double *qvar,
+                              double theta, double kappa, double rho, double volvol,
+                              const double *Z0, const double *Z1, const double *U, size_t ldw);
+
+/* utils/mc_payoffs.py:10-88  compute_mc_vars_payoff.  Returns 0, or -1 unknown payoff code,
+ * -2 unsupported variable type (SIGMA). */
+int svo_payoff(size_t n_path, const double *x, const double *qvar,
+               double ttm, double forward, double discfactor,
+               size_t n_strikes, const double *strikes, const int8_t *types, int variable_type,
+               double *prices, double *stderrs);
+
+/* ---- counter-based RNG shared (by specification, not by code) with the HIP kernels ------------ */
+
+/* Philox4x32-10 (Salmon et al., SC'11). */
+void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* The svmc draw: counter = (path_lo, path_hi, step, stream | call_id << 8), key = seed.
+ * stream 0 -> Box-Muller pair (w0, w1); stream 1 -> one uniform in (0,1). */
+void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
+                      double *w0, double *w1);
+double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step);
+
+/* Materialise the streams the kernels consume: W0/W1[t*ldw + p] for global path ids
+ * path_offset + p, global step ids step_offset + t. */
+void svo_fill_normals(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
+                      size_t n_path, int nb_steps, double *W0, double *W1, size_t ldw);
+void svo_fill_uniforms(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
+                       size_t n_path, int nb_steps, double *U, size_t ldw);
+
+/* Same generators driven by the on-the-fly draw (no materialised arrays). */
+void svo_logsv_terminal_rng(size_t n_path, int nb_steps, double dt,
+                            double *x, double *sigma, double *qvar,
+                            double theta, double kappa1, double kappa2, double beta, double volvol,
+                            double eta, int is_spot_measure,
+                            uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset);
+void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
+                             double *x, double *var, double *qvar,
+                             double theta, double kappa, double rho, double volvol, int scheme,
+                             uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

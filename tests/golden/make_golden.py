@@ -1,0 +1,333 @@
+"""
+Generate the golden vectors under tests/golden/ from the UNMODIFIED Python reference.
+
+Runs only in the build container (needs /root/reference); its outputs (*.npz, data only) are committed
+and travel to the GPU box, this script's imports of the reference do not.
+
+    python tests/golden/make_golden.py
+
+How the reference is executed: `numba` is not installable here, so the reference is imported with the
+identity-`njit` stand-in under tests/golden/_shims (NumPy mode == every function's `.py_func`, which
+the reference's own tests assert equal to the compiled route at 1e-14: reference
+tests/test_logsv_characterization.py:403-404,439-441, tests/test_numerical_utilities.py:110-111).
+
+Random inputs: either the reference's own `get_randoms_for_chain_valuation` (RandomState), NumPy
+generators named below, or the svmc Philox/Box-Muller stream materialised by the C oracle
+(oracle.fill_normals) and handed to the reference through its fixed-randoms interface.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, "/root/reference/src")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import stochvolmodels.pricers.heston_pricer as hp  # noqa: E402
+import stochvolmodels.pricers.logsv_pricer as lp  # noqa: E402
+from stochvolmodels.pricers.logsv.logsv_params import LogSvParams  # noqa: E402
+from stochvolmodels.pricers.logsv.vol_moments_ode import compute_analytic_qvar, compute_expected_vol_t  # noqa: E402
+from stochvolmodels.utils.config import VariableType  # noqa: E402
+from stochvolmodels.utils.funcs import set_time_grid  # noqa: E402
+from stochvolmodels.utils.mc_payoffs import compute_mc_vars_payoff  # noqa: E402
+
+from oracle import oracle  # noqa: E402  (only for the Philox normals fed INTO the reference)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def logsv_kwargs(p):
+    return dict(theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol)
+
+
+def params_vec(p):
+    return np.array([p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol])
+
+
+BTC = lp.LOGSV_BTC_PARAMS
+TEST = LogSvParams(sigma0=0.2, theta=0.22, kappa1=3.0, kappa2=12.0, beta=-0.3, volvol=0.4)
+
+
+# -- a1 ------------------------------------------------------------------------------------------
+def g_time_grid():
+    rng = np.random.default_rng(1)
+    cases = [(1.0, 1023), (0.25, 360), (0.02, 360), (1.0, 360), (0.125, 1016), (0.25, 508), (1.0, 99),
+             (1.0 / 52, 1016), (1.0 / 24 - 1.0 / 52, 1016), (0.275, 360), (0.001, 360), (0.05, 100)]
+    cases += [(float(rng.uniform(0.001, 3.0)), int(rng.integers(1, 2000))) for _ in range(200)]
+    out = []
+    for ttm, spy in cases:
+        n, dt, grid = set_time_grid(ttm=ttm, nb_steps_per_year=spy)
+        assert grid.shape[0] == n + 1
+        out.append((ttm, spy, n, dt))
+    save("time_grid", cases=np.array(out, dtype=np.float64))
+
+
+# -- a2: zero-noise anchors ----------------------------------------------------------------------
+def g_logsv_zero_noise():
+    z = np.zeros((91, 1))
+    res = []
+    for spot in (True, False):
+        x, s, q = lp.simulate_logsv_x_vol_terminal(ttm=0.25, x0=np.zeros(1), sigma0=np.array([BTC.sigma0]),
+                                                   qvar0=np.zeros(1), nb_path=1, W0=z, W1=z, dt=0.25 / 91,
+                                                   is_spot_measure=spot, **logsv_kwargs(BTC))
+        res.append([x[0], s[0], q[0]])
+    save("logsv_zero_noise", params=params_vec(BTC), nb_steps=91, dt=0.25 / 91, terminal=np.array(res))
+
+
+# -- a3/a4/a5: tiny RandomState chain ------------------------------------------------------------
+def run_chain_with_states(p, ttms, forwards, dfs, strikes, types, W0s, W1s, dts, etas, spot, vt):
+    prices, stds = lp.logsv_mc_chain_pricer_fixed_randoms(
+        ttms=ttms, forwards=forwards, discfactors=dfs, strikes_ttms=strikes, optiontypes_ttms=types,
+        W0s=W0s, W1s=W1s, dts=dts, v0=p.sigma0, vol_backbone_etas=etas, is_spot_measure=spot,
+        variable_type=vt, **logsv_kwargs(p))
+    n = W0s[0].shape[1]
+    x, s, q = np.zeros(n), p.sigma0 * np.ones(n), np.zeros(n)
+    states, t0 = [], 0.0
+    for ttm, eta, W0, W1, dt in zip(ttms, etas, W0s, W1s, dts):
+        x, s, q = lp.simulate_logsv_x_vol_terminal(ttm=ttm - t0, x0=x, sigma0=s, qvar0=q, nb_path=n, W0=W0, W1=W1,
+                                                   dt=dt, vol_backbone_eta=eta, is_spot_measure=spot,
+                                                   **logsv_kwargs(p))
+        t0 = ttm
+        states.append(np.stack([x, s, q]))
+    return [np.asarray(a) for a in prices], [np.asarray(a) for a in stds], states
+
+
+def g_logsv_tiny_chain():
+    ttms = np.array([0.05, 0.1])
+    W0s, W1s, dts = lp.get_randoms_for_chain_valuation(ttms=ttms, nb_path=8, nb_steps_per_year=100, seed=7)
+    forwards, dfs = np.array([1.0, 1.01]), np.array([0.99, 0.98])
+    strikes = (np.array([0.9, 1.0, 1.1]), np.array([0.9, 1.0, 1.1]))
+    types = (np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"]))
+    pr, sd, st = run_chain_with_states(BTC, ttms, forwards, dfs, strikes, types, W0s, W1s, dts,
+                                       np.ones(2), True, VariableType.LOG_RETURN)
+    save("logsv_tiny_chain", params=params_vec(BTC), ttms=ttms, forwards=forwards, discfactors=dfs,
+         strikes=np.stack(strikes), types=np.stack(types), W0_0=W0s[0], W0_1=W0s[1], W1_0=W1s[0], W1_1=W1s[1],
+         dts=np.array(dts), prices=np.stack(pr), stderrs=np.stack(sd), states=np.stack(st), seed=7, spy=100)
+
+
+# -- a3/a4 on the svmc Philox stream -------------------------------------------------------------
+def g_logsv_chain_philox():
+    n, spy, seed = 2048, 120, 20240601
+    ttms = np.array([0.1, 0.25, 0.5])
+    forwards = np.array([1.0, 1.02, 67000.0 / 65000.0])
+    dfs = np.array([0.995, 0.99, 0.98])
+    etas = np.array([1.0, 0.9, 1.1])
+    kk = np.linspace(0.6, 1.6, 7)
+    strikes = tuple(f * kk for f in forwards)
+    types = (np.array(["P", "P", "P", "C", "C", "C", "C"]), np.array(["IP", "IP", "IP", "IC", "IC", "IC", "IC"]),
+             np.array(["P", "IP", "C", "IC", "C", "P", "IC"]))
+    qv_strikes = tuple(np.linspace(0.2, 1.6, 7) for _ in ttms)
+    qv_types = (np.array(["P", "P", "P", "C", "C", "C", "C"]),) * 3
+    W0s, W1s, dts, step0 = [], [], [], 0
+    t0 = 0.0
+    for ttm in ttms:
+        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=spy)
+        W0, W1 = oracle.fill_normals(seed, n, nb, step_offset=step0)
+        W0s.append(W0), W1s.append(W1), dts.append(dt)
+        step0 += nb
+        t0 = ttm
+    out = dict(params=params_vec(BTC), ttms=ttms, forwards=forwards, discfactors=dfs, etas=etas, seed=seed, spy=spy,
+               n_path=n, dts=np.array(dts), nb_steps=np.array([w.shape[0] for w in W0s]),
+               strikes=np.stack(strikes), types=np.stack(types), qv_strikes=np.stack(qv_strikes),
+               qv_types=np.stack(qv_types), W0_head=W0s[0][:4, :64].copy(), W1_head=W1s[0][:4, :64].copy(),
+               W0_sum=np.array([w.sum() for w in W0s]), W1_sum=np.array([w.sum() for w in W1s]))
+    for tag, spot in (("spot", True), ("inv", False)):
+        pr, sd, st = run_chain_with_states(BTC, ttms, forwards, dfs, strikes, types, W0s, W1s, dts, etas, spot,
+                                           VariableType.LOG_RETURN)
+        out[f"prices_{tag}"], out[f"stderrs_{tag}"], out[f"states_{tag}"] = np.stack(pr), np.stack(sd), np.stack(st)
+    pr, sd, _ = run_chain_with_states(BTC, ttms, forwards, dfs, qv_strikes, qv_types, W0s, W1s, dts, etas, True,
+                                      VariableType.Q_VAR)
+    out["prices_qvar"], out["stderrs_qvar"] = np.stack(pr), np.stack(sd)
+    save("logsv_chain_philox", **out)
+
+
+# -- the reference's own fixed-random test case (tests/test_logsv_characterization.py:346-458) ------
+def g_logsv_reference_test_case():
+    nb_path, nb_steps, ttm = 40_000, 91, 0.25
+    dt = ttm / nb_steps
+    rng = np.random.default_rng(123)
+    W0 = rng.standard_normal((nb_steps, nb_path))
+    W1 = rng.standard_normal((nb_steps, nb_path))
+    strikes, types = np.array([0.9, 1.0, 1.1]), np.array(["P", "C", "C"])
+    pr, sd = lp.logsv_mc_chain_pricer_fixed_randoms(
+        ttms=np.array([ttm]), forwards=np.array([1.0]), discfactors=np.array([0.98]), strikes_ttms=(strikes,),
+        optiontypes_ttms=(types,), W0s=[W0], W1s=[W1], dts=[dt], v0=TEST.sigma0, vol_backbone_etas=np.ones(1),
+        **logsv_kwargs(TEST))
+    x, s, q = lp.simulate_logsv_x_vol_terminal(ttm=ttm, x0=np.zeros(nb_path), sigma0=np.full(nb_path, TEST.sigma0),
+                                               qvar0=np.zeros(nb_path), nb_path=nb_path, W0=W0, W1=W1, dt=dt,
+                                               **logsv_kwargs(TEST))
+    analytic = np.asarray(lp.LogSVPricer().price_chain(
+        lp.OptionChain.slice_to_chain(ttm=ttm, forward=1.0, strikes=strikes, optiontypes=types, discfactor=0.98,
+                                      id="3m"), TEST)[0])
+    save("logsv_reference_test_case", params=params_vec(TEST), nb_path=nb_path, nb_steps=nb_steps, ttm=ttm, dt=dt,
+         rng="numpy.random.default_rng(123).standard_normal((91,40000)) twice: W0 then W1",
+         strikes=strikes, types=types, discfactor=0.98, prices=np.asarray(pr[0]), stderrs=np.asarray(sd[0]),
+         analytic=analytic, x_head=x[:256], sigma_head=s[:256], qvar_head=q[:256],
+         means=np.array([np.mean(np.exp(x)), np.mean(s), np.mean(q / ttm)]),
+         expected_sigma=compute_expected_vol_t(TEST, np.array([ttm]), n_terms=8)[0],
+         expected_qvar=compute_analytic_qvar(TEST, ttm=ttm, n_terms=8))
+
+
+# -- a6 ------------------------------------------------------------------------------------------
+def g_heston():
+    # (i) survey anchor: global NumPy RNG, w0 drawn first then w1 (heston_pricer.py:369-370)
+    hpar = dict(theta=0.05, kappa=2.0, rho=-0.5, volvol=0.4)
+    np.random.seed(42)
+    W0 = np.random.normal(0, 1, size=(6, 4))
+    W1 = np.random.normal(0, 1, size=(6, 4))
+    np.random.seed(42)
+    x, v, q = hp.simulate_heston_x_vol_terminal(ttm=0.05, x0=np.zeros(4), var0=0.04 * np.ones(4), qvar0=np.zeros(4),
+                                                nb_path=4, nb_steps_per_year=100, **hpar)
+    # (ii) chain driver on the Philox stream: np.random.normal is replaced by a feeder that hands the
+    # reference the oracle-materialised normals in its own draw order (W0 then W1 per slice).
+    n, seed = 2048, 20240603
+    ttms = np.array([0.05, 0.1, 0.25])
+    forwards, dfs = np.array([1.0, 1.01, 1.03]), np.array([0.999, 0.995, 0.99])
+    kk = np.linspace(0.8, 1.2, 5)
+    strikes = tuple(f * kk for f in forwards)
+    types = (np.array(["P", "P", "C", "C", "C"]), np.array(["IP", "IP", "IC", "IC", "IC"]),
+             np.array(["P", "IP", "C", "IC", "C"]))
+    results = {}
+    for tag, par in (("base", dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)),
+                     ("btc", dict(v0=0.8, theta=1.0, kappa=2.0, rho=0.0, volvol=2.0))):
+        feed, nbs, dts_, step0, t0 = [], [], [], 0, 0.0
+        for ttm in ttms:
+            nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=360)
+            A, B = oracle.fill_normals(seed, n, nb, step_offset=step0)
+            feed += [A, B]
+            nbs.append(nb), dts_.append(dt)
+            step0 += nb
+            t0 = ttm
+        it = iter(feed)
+        orig = np.random.normal
+
+        def feeder(loc, scale, size):
+            a = next(it)
+            assert a.shape == tuple(size)
+            return a
+
+        np.random.normal = feeder
+        try:
+            pr, sd = hp.heston_mc_chain_pricer(ttms=ttms, forwards=forwards, discfactors=dfs, strikes_ttms=strikes,
+                                               optiontypes_ttms=types, nb_path=n, **par)
+            it = iter(feed)
+            xs, vs, qs = np.zeros(n), par["v0"] * np.ones(n), np.zeros(n)
+            states, t0 = [], 0.0
+            for ttm in ttms:
+                xs, vs, qs = hp.simulate_heston_x_vol_terminal(ttm=ttm - t0, x0=xs, var0=vs, qvar0=qs, nb_path=n,
+                                                               theta=par["theta"], kappa=par["kappa"], rho=par["rho"],
+                                                               volvol=par["volvol"])
+                t0 = ttm
+                states.append(np.stack([xs, vs, qs]))
+        finally:
+            np.random.normal = orig
+        results[f"params_{tag}"] = np.array([par["v0"], par["theta"], par["kappa"], par["rho"], par["volvol"]])
+        results[f"prices_{tag}"] = np.stack([np.asarray(a) for a in pr])
+        results[f"stderrs_{tag}"] = np.stack([np.asarray(a) for a in sd])
+        results[f"states_{tag}"] = np.stack(states)
+    save("heston", seed42_W0=W0, seed42_W1=W1, seed42_params=np.array([0.04, 0.05, 2.0, -0.5, 0.4]),
+         seed42_dt=set_time_grid(0.05, 100)[1], seed42_terminal=np.stack([x, v, q]),
+         ttms=ttms, forwards=forwards, discfactors=dfs, strikes=np.stack(strikes), types=np.stack(types),
+         seed=seed, n_path=n, nb_steps=np.array(nbs), dts=np.array(dts_), **results)
+
+
+# -- a7 ------------------------------------------------------------------------------------------
+def g_payoff():
+    out = {}
+    # reference tests/test_numerical_utilities.py:73-111 inputs
+    spots = np.array([0.8, 1.0, 1.2])
+    cases = {
+        "kat": dict(x0=np.log(spots), qvar0=np.zeros(3), ttm=1.0, forward=1.0, strikes_ttm=np.ones(4),
+                    optiontypes_ttm=np.array(["C", "P", "IC", "IP"]), discfactor=0.95,
+                    variable_type=VariableType.LOG_RETURN),
+        # :144-167
+        "qvar": dict(x0=np.zeros(3), qvar0=np.array([0.02, 0.08, 0.18]), ttm=0.5, forward=1.0,
+                     strikes_ttm=np.array([0.15, 0.15]), optiontypes_ttm=np.array(["C", "P"]), discfactor=1.0,
+                     variable_type=VariableType.Q_VAR),
+    }
+    rng = np.random.default_rng(5)
+    xr = 0.4 * rng.standard_normal(10007) - 0.08
+    qr = 0.3 * np.exp(0.5 * rng.standard_normal(10007))
+    kk = np.linspace(0.5, 1.5, 21)
+    cases["random_lr"] = dict(x0=xr, qvar0=qr, ttm=0.75, forward=1.25, strikes_ttm=1.25 * kk,
+                              optiontypes_ttm=np.array((["P", "IP"] * 5 + ["C", "IC"] * 6)[:21]), discfactor=0.97,
+                              variable_type=VariableType.LOG_RETURN)
+    cases["random_qv"] = dict(x0=xr, qvar0=qr, ttm=0.75, forward=1.25, strikes_ttm=np.linspace(0.1, 1.0, 10),
+                              optiontypes_ttm=np.array(["P", "C", "IP", "IC", "P", "C", "IP", "IC", "P", "C"]),
+                              discfactor=0.97, variable_type=VariableType.Q_VAR)
+    xn = xr[:997].copy()
+    qn = qr[:997].copy()
+    xn[[3, 500, 996]] = np.nan          # NaN log-returns: payoff 0 for C/P, excluded for IC/IP
+    xn[10] = np.inf                     # +inf spot
+    xn[11] = -np.inf                    # zero spot
+    qn[[7, 8]] = np.nan
+    cases["nan_lr"] = dict(x0=xn, qvar0=qn, ttm=0.5, forward=1.0, strikes_ttm=np.array([0.8, 1.0, 1.2, 1.0]),
+                           optiontypes_ttm=np.array(["P", "IC", "C", "IP"]), discfactor=0.9,
+                           variable_type=VariableType.LOG_RETURN)
+    xm = xr[:997].copy()
+    xm[[3, 500, 996]] = np.nan
+    cases["nan_qv"] = dict(x0=xm, qvar0=qn, ttm=0.5, forward=1.0, strikes_ttm=np.array([0.3, 0.6, 0.6, 0.3]),
+                           optiontypes_ttm=np.array(["P", "IC", "C", "IP"]), discfactor=0.9,
+                           variable_type=VariableType.Q_VAR)
+    with np.errstate(all="ignore"):
+        import warnings
+        warnings.simplefilter("ignore")
+        for name, kw in cases.items():
+            pr, sd = compute_mc_vars_payoff(sigma0=np.ones_like(kw["x0"]), **kw)
+            out[f"{name}_x"], out[f"{name}_qvar"] = kw["x0"], kw["qvar0"]
+            out[f"{name}_strikes"], out[f"{name}_types"] = kw["strikes_ttm"], kw["optiontypes_ttm"]
+            out[f"{name}_scalars"] = np.array([kw["ttm"], kw["forward"], kw["discfactor"], kw["variable_type"].value])
+            out[f"{name}_prices"], out[f"{name}_stderrs"] = pr, sd
+    save("payoff", names=np.array(list(cases)), **out)
+
+
+# -- analytic oracles for the statistical tests (configs C2, C3, C5) ------------------------------
+def g_analytic():
+    out = {}
+    ttms = np.array([0.25, 0.5, 0.75, 1.0])
+    kk = np.linspace(0.5, 1.5, 21)
+    fw, df = np.ones(4), np.ones(4)
+    strikes = tuple(kk for _ in ttms)
+    types = tuple(np.where(kk >= 1.0, "C", "P") for _ in ttms)
+    out.update(ttms=ttms, strikes=kk, types=types[0])
+    for tag, par in (("base", dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)),
+                     ("btc", dict(v0=0.8, theta=1.0, kappa=2.0, rho=0.0, volvol=2.0))):
+        pr = hp.heston_chain_pricer(ttms=ttms, forwards=fw, strikes_ttms=strikes, optiontypes_ttms=types,
+                                    discfactors=df, **par)
+        out[f"heston_{tag}_params"] = np.array([par["v0"], par["theta"], par["kappa"], par["rho"], par["volvol"]])
+        out[f"heston_{tag}_prices"] = np.stack([np.asarray(a) for a in pr])
+    sets = {
+        "btc": BTC,
+        "readme": LogSvParams(sigma0=0.8327, theta=1.0139, kappa1=4.8609, kappa2=4.794, beta=0.1988, volvol=2.3694),
+        "quick": LogSvParams(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0),
+        "test": TEST,
+        "fig3": LogSvParams(sigma0=1.5, theta=1.0, kappa1=4.0, kappa2=4.0, beta=0.0, volvol=1.5),
+    }
+    for tag, p in sets.items():
+        pr = lp.logsv_chain_pricer(params=p, ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes,
+                                   optiontypes_ttms=types)
+        out[f"logsv_{tag}_params"] = params_vec(p)
+        out[f"logsv_{tag}_prices"] = np.stack([np.asarray(a) for a in pr])
+        print("analytic logsv", tag, "done")
+    out["logsv_test_expected_sigma"] = compute_expected_vol_t(TEST, ttms, n_terms=8)
+    out["logsv_test_expected_qvar"] = np.array([compute_analytic_qvar(TEST, ttm=t, n_terms=8) for t in ttms])
+    save("analytic", **out)
+
+
+if __name__ == "__main__":
+    oracle.build()
+    g_time_grid()
+    g_logsv_zero_noise()
+    g_logsv_tiny_chain()
+    g_logsv_chain_philox()
+    g_logsv_reference_test_case()
+    g_heston()
+    g_payoff()
+    g_analytic()

@@ -1,0 +1,219 @@
+"""
+Pin the CPU oracle (oracle/svmc_oracle.c and the NumPy restatement) against the golden vectors that
+tests/golden/make_golden.py produced from the unmodified Python reference.
+
+Tolerances: the oracle keeps the reference's evaluation order, so the only differences are libm vs
+NumPy exp/log rounding (<=1 ULP per call) propagated through the steps: 1e-13 relative on states,
+1e-13 on prices (the reference's own compiled-vs-python tolerance is 1e-14..3e-14).
+"""
+import numpy as np
+import pytest
+
+RT = 1e-13
+
+
+def P(v):
+    return dict(zip(("sigma0", "theta", "kappa1", "kappa2", "beta", "volvol"), (float(a) for a in v)))
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    assert oracle.philox4x32_10([0] * 4, [0] * 2) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert oracle.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert oracle.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_normal_stream_moments(oracle):
+    W0, W1 = oracle.fill_normals(99, 1 << 15, 32)
+    a = np.concatenate([W0.ravel(), W1.ravel()])
+    n = a.size
+    assert abs(a.mean()) < 4 / np.sqrt(n)
+    assert abs(a.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs((a ** 3).mean()) < 4 * np.sqrt(15 / n)
+    assert abs((a ** 4).mean() - 3) < 4 * np.sqrt(96 / n)
+    assert abs(np.corrcoef(W0.ravel(), W1.ravel())[0, 1]) < 4 / np.sqrt(n / 2)
+    assert abs(np.corrcoef(W0[:-1].ravel(), W0[1:].ravel())[0, 1]) < 4 / np.sqrt(n / 2)
+    U = oracle.fill_uniforms(99, 1 << 15, 8)
+    assert 0.0 < U.min() and U.max() < 1.0
+    assert abs(U.mean() - 0.5) < 4 / np.sqrt(12 * U.size)
+    # sharding invariance: a sub-range of paths/steps addressed by offsets reproduces the same numbers
+    A0, A1 = oracle.fill_normals(99, 100, 5, path_offset=1000, step_offset=7)
+    np.testing.assert_array_equal(A0, W0[7:12, 1000:1100])
+    np.testing.assert_array_equal(A1, W1[7:12, 1000:1100])
+    B0, _ = oracle.fill_normals(99, 100, 5, call_id=1)
+    assert not np.array_equal(B0, W0[:5, :100])
+
+
+def test_time_grid(oracle, golden):
+    for ttm, spy, n, dt in golden("time_grid")["cases"]:
+        assert oracle.set_time_grid(ttm, int(spy)) == (int(n), dt)
+
+
+def test_logsv_zero_noise(oracle, golden):
+    g = golden("logsv_zero_noise")
+    p = P(g["params"])
+    z = np.zeros((int(g["nb_steps"]), 1))
+    for row, spot in zip(g["terminal"], (True, False)):
+        for fn in (oracle.logsv_terminal_w, oracle.np_logsv_terminal_w):
+            x, s, q = fn([0.0], [p["sigma0"]], [0.0], float(g["dt"]), p["theta"], p["kappa1"], p["kappa2"],
+                         p["beta"], p["volvol"], z, z, is_spot_measure=spot)
+            np.testing.assert_allclose([x[0], s[0], q[0]], row, rtol=RT)
+    # survey anchors
+    np.testing.assert_allclose(g["terminal"][0], [-0.08351278522002883, 0.8053845173369816, 0.16695286502902215],
+                               rtol=1e-15)
+
+
+def test_logsv_tiny_chain(oracle, golden):
+    g = golden("logsv_tiny_chain")
+    p = P(g["params"])
+    W0s, W1s = [g["W0_0"], g["W0_1"]], [g["W1_0"], g["W1_1"]]
+    prices, stderrs, states = oracle.logsv_chain_fixed_randoms(
+        g["ttms"], g["forwards"], g["discfactors"], g["strikes"], g["types"], W0s, W1s, g["dts"],
+        p["sigma0"], p["theta"], p["kappa1"], p["kappa2"], p["beta"], p["volvol"], np.ones(2), return_states=True)
+    np.testing.assert_allclose(np.stack(prices), g["prices"], rtol=RT, atol=1e-15)
+    np.testing.assert_allclose(np.stack(stderrs), g["stderrs"], rtol=RT, atol=1e-15)
+    for (x, s, q), ref in zip(states, g["states"]):
+        np.testing.assert_allclose(np.stack([x, s, q]), ref, rtol=RT, atol=1e-15)
+    # survey anchors
+    np.testing.assert_allclose(g["prices"][0], [0.03667813350545091, 0.07082026091812794, 0.03508919291665263],
+                               rtol=1e-14)
+    # steps/dt rule per slice
+    t0 = 0.0
+    for ttm, dt, W0 in zip(g["ttms"], g["dts"], W0s):
+        assert oracle.set_time_grid(ttm - t0, int(g["spy"])) == (W0.shape[0], dt)
+        t0 = ttm
+
+
+def _philox_chain_randoms(oracle, g):
+    W0s, W1s, step0 = [], [], 0
+    for nb in g["nb_steps"]:
+        W0, W1 = oracle.fill_normals(int(g["seed"]), int(g["n_path"]), int(nb), step_offset=step0)
+        W0s.append(W0), W1s.append(W1)
+        step0 += int(nb)
+    return W0s, W1s
+
+
+@pytest.mark.parametrize("tag,spot,vt", [("spot", True, 1), ("inv", False, 1), ("qvar", True, 2)])
+def test_logsv_chain_philox(oracle, golden, tag, spot, vt):
+    g = golden("logsv_chain_philox")
+    p = P(g["params"])
+    W0s, W1s = _philox_chain_randoms(oracle, g)
+    # the stream the reference was fed is the stream we regenerate here
+    np.testing.assert_allclose(W0s[0][:4, :64], g["W0_head"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(W1s[0][:4, :64], g["W1_head"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose([w.sum() for w in W0s], g["W0_sum"], atol=1e-10)
+    strikes, types = (g["qv_strikes"], g["qv_types"]) if tag == "qvar" else (g["strikes"], g["types"])
+    prices, stderrs, states = oracle.logsv_chain_fixed_randoms(
+        g["ttms"], g["forwards"], g["discfactors"], strikes, types, W0s, W1s, g["dts"],
+        p["sigma0"], p["theta"], p["kappa1"], p["kappa2"], p["beta"], p["volvol"], g["etas"],
+        is_spot_measure=spot, variable_type=vt, return_states=True)
+    np.testing.assert_allclose(np.stack(prices), g[f"prices_{tag}"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(np.stack(stderrs), g[f"stderrs_{tag}"], rtol=1e-12, atol=1e-15)
+    if tag != "qvar":
+        for (x, s, q), ref in zip(states, g[f"states_{tag}"]):
+            np.testing.assert_allclose(np.stack([x, s, q]), ref, rtol=1e-12, atol=1e-14)
+    # on-the-fly generator == materialised stream (bitwise: same C code path)
+    n = int(g["n_path"])
+    x, s, q = np.zeros(n), p["sigma0"] * np.ones(n), np.zeros(n)
+    step0 = 0
+    for nb, dt, eta, st in zip(g["nb_steps"], g["dts"], g["etas"], states):
+        x, s, q = oracle.logsv_terminal_rng(x, s, q, int(nb), float(dt), p["theta"], p["kappa1"], p["kappa2"],
+                                            p["beta"], p["volvol"], int(g["seed"]), eta=float(eta),
+                                            is_spot_measure=spot, step_offset=step0)
+        step0 += int(nb)
+        np.testing.assert_array_equal(np.stack([x, s, q]), np.stack(st))
+
+
+def test_logsv_reference_test_case(oracle, golden):
+    """the reference's own fixed-random case, tests/test_logsv_characterization.py:346-458"""
+    g = golden("logsv_reference_test_case")
+    p = P(g["params"])
+    n, nb = int(g["nb_path"]), int(g["nb_steps"])
+    rng = np.random.default_rng(123)
+    W0 = rng.standard_normal((nb, n))
+    W1 = rng.standard_normal((nb, n))
+    x, s, q = oracle.logsv_terminal_w(np.zeros(n), np.full(n, p["sigma0"]), np.zeros(n), float(g["dt"]),
+                                      p["theta"], p["kappa1"], p["kappa2"], p["beta"], p["volvol"], W0, W1)
+    np.testing.assert_allclose(x[:256], g["x_head"], rtol=RT, atol=1e-15)
+    np.testing.assert_allclose(s[:256], g["sigma_head"], rtol=RT)
+    np.testing.assert_allclose(q[:256], g["qvar_head"], rtol=RT)
+    np.testing.assert_allclose([np.mean(np.exp(x)), np.mean(s), np.mean(q / float(g["ttm"]))], g["means"], rtol=1e-13)
+    pr, sd = oracle.payoff(x, q, float(g["ttm"]), 1.0, g["strikes"], g["types"], float(g["discfactor"]))
+    np.testing.assert_allclose(pr, g["prices"], rtol=1e-12)
+    np.testing.assert_allclose(sd, g["stderrs"], rtol=1e-12)
+    # the reference test's acceptance criteria hold for the oracle too
+    assert np.all(np.abs(g["analytic"] - pr) <= 4.0 * sd)
+    assert abs(np.mean(s) - float(g["expected_sigma"])) <= 4.0 * np.std(s, ddof=1) / np.sqrt(n)
+    assert abs(np.mean(q / float(g["ttm"])) - float(g["expected_qvar"])) <= 4 * np.std(q / float(g["ttm"]), ddof=1) / np.sqrt(n)
+
+
+def test_heston(oracle, golden):
+    g = golden("heston")
+    v0, theta, kappa, rho, volvol = g["seed42_params"]
+    for fn in (oracle.heston_terminal_w, oracle.np_heston_terminal_w):
+        x, v, q = fn(np.zeros(4), v0 * np.ones(4), np.zeros(4), float(g["seed42_dt"]), theta, kappa, rho, volvol,
+                     g["seed42_W0"], g["seed42_W1"])
+        np.testing.assert_allclose(np.stack([x, v, q]), g["seed42_terminal"], rtol=RT, atol=1e-16)
+    np.testing.assert_allclose(g["seed42_terminal"][0], [0.01098398454577643, -0.02767244743557851,
+                                                         -0.00896675799514848, -0.0337356808354091], rtol=1e-13)
+    n = int(g["n_path"])
+    for tag in ("base", "btc"):
+        v0, theta, kappa, rho, volvol = g[f"params_{tag}"]
+        x, v, q = np.zeros(n), v0 * np.ones(n), np.zeros(n)
+        xr, vr, qr = x.copy(), v.copy(), q.copy()
+        step0 = 0
+        for i, (nb, dt) in enumerate(zip(g["nb_steps"], g["dts"])):
+            W0, W1 = oracle.fill_normals(int(g["seed"]), n, int(nb), step_offset=step0)
+            x, v, q = oracle.heston_terminal_w(x, v, q, float(dt), theta, kappa, rho, volvol, W0, W1)
+            xr, vr, qr = oracle.heston_terminal_rng(xr, vr, qr, int(nb), float(dt), theta, kappa, rho, volvol,
+                                                    int(g["seed"]), step_offset=step0)
+            step0 += int(nb)
+            np.testing.assert_allclose(np.stack([x, v, q]), g[f"states_{tag}"][i], rtol=1e-12, atol=1e-14)
+            np.testing.assert_array_equal(np.stack([xr, vr, qr]), np.stack([x, v, q]))
+            assert v.min() >= 1e-4
+            pr, sd = oracle.payoff(x, q, float(g["ttms"][i]), float(g["forwards"][i]), g["strikes"][i],
+                                   g["types"][i], float(g["discfactors"][i]))
+            np.testing.assert_allclose(pr, g[f"prices_{tag}"][i], rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(sd, g[f"stderrs_{tag}"][i], rtol=1e-12, atol=1e-15)
+
+
+def test_payoff(oracle, golden):
+    g = golden("payoff")
+    for name in g["names"]:
+        ttm, fwd, df, vt = g[f"{name}_scalars"]
+        for fn in (oracle.payoff, oracle.np_payoff):
+            pr, sd = fn(g[f"{name}_x"], g[f"{name}_qvar"], ttm, fwd, g[f"{name}_strikes"], g[f"{name}_types"],
+                        df, int(vt))
+            np.testing.assert_allclose(pr, g[f"{name}_prices"], rtol=1e-12, atol=1e-15, err_msg=str(name))
+            np.testing.assert_allclose(sd, g[f"{name}_stderrs"], rtol=1e-12, atol=1e-15, err_msg=str(name))
+    # the reference's known-answer test, tests/test_numerical_utilities.py:73-111
+    spots = np.array([0.8, 1.0, 1.2])
+    pay = np.vstack([np.maximum(spots - 1, 0), np.maximum(1 - spots, 0), np.maximum(spots - 1, 0) / spots,
+                     np.maximum(1 - spots, 0) / spots])
+    np.testing.assert_allclose(g["kat_prices"], 0.95 * pay.mean(axis=1), atol=1e-14)
+    np.testing.assert_allclose(g["kat_stderrs"], 0.95 * pay.std(axis=1) / np.sqrt(3), atol=1e-14)
+
+
+def test_payoff_errors(oracle):
+    z = np.zeros(4)
+    with pytest.raises(ValueError, match="payoff"):
+        oracle.payoff(z, z, 1.0, 1.0, np.array([1.0]), np.array(["BAD"]))
+    with pytest.raises(NotImplementedError):
+        oracle.payoff(z, z, 1.0, 1.0, np.array([1.0]), np.array(["C"]), variable_type=3)
+
+
+def test_heston_qe_matches_analytic(oracle, golden):
+    """QE is new relative to the reference: oracle = the reference's analytic Heston price."""
+    g = golden("analytic")
+    n, nb = 1 << 16, 32
+    for tag in ("base", "btc"):
+        v0, theta, kappa, rho, volvol = g[f"heston_{tag}_params"]
+        x, v, q = np.zeros(n), v0 * np.ones(n), np.zeros(n)
+        for i, ttm in enumerate(g["ttms"]):
+            x, v, q = oracle.heston_terminal_rng(x, v, q, nb, 0.25 / nb, theta, kappa, rho, volvol, 777,
+                                                 scheme=oracle.HESTON_QE, step_offset=i * nb)
+            pr, sd = oracle.payoff(x, q, float(ttm), 1.0, g["strikes"], g["types"])
+            assert np.all(np.abs(pr - g[f"heston_{tag}_prices"][i]) <= 4.0 * sd + 2e-4), (tag, i)
+            assert abs(np.mean(np.exp(x)) - 1.0) <= 4 * np.std(np.exp(x)) / np.sqrt(n)
+        assert v.min() >= 0.0
