@@ -1,0 +1,159 @@
+/*
+ * svmc.h -- C ABI of libsvmc.so, the MI355X (gfx950) Monte Carlo engine behind the StochVolModels
+ * hot path (LogSV / Heston terminal-state generators + forward-recentred payoff reduction).
+ *
+ * The reference (ArturSepp/StochVolModels, pure Python + Numba) has no FFI of its own; each entry point
+ * below names the reference function it replaces (paths relative to src/stochvolmodels/).  The binding
+ * a maintainer of the reference would add is a ctypes stub: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an svmc status code (0 = SVMC_OK); svmc_last_error() gives the message of
+ *     the last failure on the calling thread.  No exceptions cross the boundary.
+ *   - all `double *` state / random / output pointers are DEVICE pointers on the current HIP device
+ *     (svmc_set_device) unless the parameter name ends in `_host`.  Buffers are caller-owned.
+ *   - every compute call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default
+ *     stream).  Outputs are valid after svmc_stream_synchronize(stream).
+ *   - all arithmetic is IEEE fp64.  Option payoff codes are int8: C=0, P=1, IC=2, IP=3
+ *     (utils/config.py:8-15); variable types are 1=LOG_RETURN, 2=Q_VAR, 3=SIGMA (utils/config.py:18-24).
+ *   - random layout is the reference's: W[t * ldw + p], step-major, UNSCALED N(0,1)
+ *     (pricers/logsv_pricer.py:1028-1030).
+ *   - the library is thread-compatible: concurrent calls must use distinct streams and buffers.
+ */
+#ifndef SVMC_H
+#define SVMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVMC_VERSION 100 /* 0.1.0 */
+
+#if defined(__GNUC__) || defined(__clang__)
+#define SVMC_API __attribute__((visibility("default")))
+#else
+#define SVMC_API
+#endif
+
+/* status codes */
+#define SVMC_OK 0
+#define SVMC_ERR_INVALID_ARGUMENT 1
+#define SVMC_ERR_HIP 2
+#define SVMC_ERR_UNKNOWN_PAYOFF 3       /* reference: ValueError("unknown option payoff code"), utils/mc_payoffs.py:84 */
+#define SVMC_ERR_UNSUPPORTED_VARIABLE 4 /* reference: NotImplementedError for VariableType.SIGMA, utils/mc_payoffs.py:69-70 */
+#define SVMC_ERR_WORKSPACE 5
+
+#define SVMC_CALL 0
+#define SVMC_PUT 1
+#define SVMC_INV_CALL 2
+#define SVMC_INV_PUT 3
+
+#define SVMC_LOG_RETURN 1
+#define SVMC_Q_VAR 2
+#define SVMC_SIGMA 3
+
+#define SVMC_HESTON_EULER_FLOOR 0 /* the reference's scheme, pricers/heston_pricer.py:373-379 */
+#define SVMC_HESTON_QE 1          /* Andersen QE-M; new capability */
+
+typedef void *svmc_stream_t; /* hipStream_t */
+typedef void *svmc_event_t;  /* hipEvent_t */
+
+/* ---- library / device plumbing (no reference counterpart: the reference is single-process NumPy) -- */
+SVMC_API int svmc_version(void);
+SVMC_API const char *svmc_last_error(void);
+SVMC_API int svmc_device_count(int *count);
+SVMC_API int svmc_set_device(int device);
+SVMC_API int svmc_get_device(int *device);
+SVMC_API int svmc_device_info(int device, char *name, size_t name_len, int *compute_units, int *clock_khz,
+                     size_t *hbm_bytes);
+SVMC_API int svmc_malloc(void **dptr, size_t bytes);
+SVMC_API int svmc_free(void *dptr);
+SVMC_API int svmc_host_alloc(void **hptr, size_t bytes); /* pinned host memory for async H2D/D2H */
+SVMC_API int svmc_host_free(void *hptr);
+SVMC_API int svmc_memset(void *dptr, int value, size_t bytes, svmc_stream_t stream);
+SVMC_API int svmc_memcpy_h2d(void *dst, const void *src_host, size_t bytes, svmc_stream_t stream);
+SVMC_API int svmc_memcpy_d2h(void *dst_host, const void *src, size_t bytes, svmc_stream_t stream);
+SVMC_API int svmc_memcpy_d2d(void *dst, const void *src, size_t bytes, svmc_stream_t stream);
+/* strided upload of a [height][width] double sub-matrix (a rank's path range of a host W array) */
+SVMC_API int svmc_memcpy2d_h2d(void *dst, size_t dst_pitch_bytes, const void *src_host, size_t src_pitch_bytes,
+                      size_t width_bytes, size_t height, svmc_stream_t stream);
+SVMC_API int svmc_stream_create(svmc_stream_t *stream);
+SVMC_API int svmc_stream_destroy(svmc_stream_t stream);
+SVMC_API int svmc_stream_synchronize(svmc_stream_t stream);
+SVMC_API int svmc_event_create(svmc_event_t *event);
+SVMC_API int svmc_event_destroy(svmc_event_t event);
+SVMC_API int svmc_event_record(svmc_event_t event, svmc_stream_t stream);
+SVMC_API int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms); /* synchronises on `stop` */
+
+/* ---- state ----------------------------------------------------------------------------------------
+ * x0 = zeros, sigma0 = v0 * ones, qvar0 = zeros of pricers/logsv_pricer.py:832-834 and
+ * pricers/heston_pricer.py:303-305, written directly in HBM. */
+SVMC_API int svmc_fill_state(double *x, double *vol, double *qvar, size_t n_path, double x0, double vol0,
+                    double qvar0, svmc_stream_t stream);
+
+/* ---- counter-based randoms (replaces np.random.normal inside the generators,
+ * pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370) ------------------------------
+ * Philox4x32-10, key = seed, counter = (path_lo, path_hi, step, stream | call_id << 8); stream 0 is a
+ * Box-Muller pair (w0, w1), stream 1 one uniform in (0,1).  `path` is the GLOBAL path id
+ * path_offset + p, `step` the chain-global step id step_offset + t, so results do not depend on how
+ * paths are sharded over GPUs.  Exact definition: DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c. */
+SVMC_API int svmc_fill_normals(double *W0, double *W1, size_t ldw, size_t n_path, int nb_steps, uint64_t seed,
+                      uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream);
+SVMC_API int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint64_t seed,
+                       uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream);
+
+/* ---- LogSV generator: simulate_logsv_x_vol_terminal, pricers/logsv_pricer.py:950-1047 ------------
+ * In-place update of (x, sigma, qvar) over nb_steps log-Euler steps of size dt (Eq. 3.59).
+ * _rng draws its increments on device (reference branch W0 is None, :1022-1026);
+ * _w consumes supplied unscaled normals (reference branch :1028-1030). */
+SVMC_API int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                            double theta, double kappa1, double kappa2, double beta, double volvol,
+                            double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                            uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream);
+SVMC_API int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                          double theta, double kappa1, double kappa2, double beta, double volvol,
+                          double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
+                          size_t ldw, svmc_stream_t stream);
+
+/* ---- Heston generator: simulate_heston_x_vol_terminal, pricers/heston_pricer.py:334-381 ----------
+ * `var` is the variance (the reference returns variance, not vol).  scheme = SVMC_HESTON_EULER_FLOOR
+ * reproduces the reference (Euler, floor max(v, 1e-4)); SVMC_HESTON_QE is Andersen's QE-M. */
+SVMC_API int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                             double theta, double kappa, double rho, double volvol, int scheme,
+                             uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
+                             svmc_stream_t stream);
+SVMC_API int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                           double theta, double kappa, double rho, double volvol, const double *W0,
+                           const double *W1, size_t ldw, svmc_stream_t stream);
+SVMC_API int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                              double theta, double kappa, double rho, double volvol, const double *Z0,
+                              const double *Z1, const double *U, size_t ldw, svmc_stream_t stream);
+
+/* ---- payoff reduction: compute_mc_vars_payoff, utils/mc_payoffs.py:10-88 -------------------------
+ * Split at the two points where the reference needs a global quantity, so that a multi-GPU caller can
+ * all-reduce the partial sums in between (sums are plain fp64 and add across ranks):
+ *   1. svmc_spot_sums     spot_sums[0..1] = { sum over non-NaN of F*exp(x), count of non-NaN }  (:61-62)
+ *   2. svmc_payoff_sums   per strike k, with d = payoff - shift_k over the non-NaN payoffs:
+ *                         sums[3k..3k+2] = { sum d, sum d^2, count }; the recentring
+ *                         c = spot_sums[0]/spot_sums[1] - F is read from device memory             (:63-86)
+ *   3. svmc_payoff_finalize (host) price = DF*(shift + sum/cnt),
+ *                         stderr = DF*sqrt(sum2/cnt - (sum/cnt)^2)/sqrt(N_total)                   (:85-88)
+ * shifts_host (nullable = zeros) are any per-strike constants near the mean payoff (the host mirror uses
+ * the intrinsic value at the forward); they only remove the cancellation in E[p^2] - E[p]^2.
+ * `workspace` is a device scratch buffer of at least svmc_payoff_workspace_bytes() bytes. */
+SVMC_API int svmc_payoff_workspace_bytes(size_t *bytes);
+SVMC_API int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_sums, void *workspace,
+                   size_t workspace_bytes, svmc_stream_t stream);
+SVMC_API int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double forward, double ttm,
+                     const double *spot_sums, const double *strikes_host, const int8_t *types_host,
+                     const double *shifts_host, size_t n_strikes, int variable_type, double *sums,
+                     void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes,
+                         double discfactor, double n_path_total, double *prices_host, double *stderrs_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVMC_H */

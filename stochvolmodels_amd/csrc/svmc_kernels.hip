@@ -1,0 +1,496 @@
+// svmc_kernels.hip -- gfx950 kernels and compute entry points of the C ABI (include/svmc.h).
+//
+// Mapping: one wavefront lane per Monte Carlo path.  A path's state (x, L = ln sigma, sigma, I) lives in
+// VGPRs for the whole slice; HBM is touched once per slice per path (24 B read + 24 B write) in the
+// on-device-RNG kernels, and 16 B per path-step (the two supplied normals, coalesced 512 B per wave
+// per load) in the streamed-randoms kernels.  No MFMA: the work is elementwise fp64 VALU +
+// transcendentals (DESIGN.md "Rooflines").
+#include "svmc_internal.h"
+#include "svmc_models.h"
+#include "svmc_rng.h"
+
+namespace svmc {
+
+constexpr int BLOCK = 256;           // 4 waves of 64 lanes
+constexpr int MAX_REDUCE_GRID = 2048;  // 256 CUs x 8 blocks: cap for grid-stride reductions
+constexpr int KC = 16;                 // strikes per payoff launch (register accumulators)
+
+static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void fill_state_kernel(double *__restrict__ x, double *__restrict__ vol,
+                                                           double *__restrict__ qvar, size_t n, double x0,
+                                                           double vol0, double qvar0)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p < n) {
+        x[p] = x0;
+        vol[p] = vol0;
+        qvar[p] = qvar0;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_normals_kernel(double *__restrict__ W0, double *__restrict__ W1,
+                                                             size_t ldw, size_t n, int nb_steps, uint64_t seed,
+                                                             uint32_t c3, uint64_t path_offset,
+                                                             uint32_t step_offset)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t gp = path_offset + p;
+    for (int t = 0; t < nb_steps; ++t) {
+        double w0, w1;
+        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), w0, w1);
+        W0[static_cast<size_t>(t) * ldw + p] = w0;
+        W1[static_cast<size_t>(t) * ldw + p] = w1;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_uniforms_kernel(double *__restrict__ U, size_t ldw, size_t n,
+                                                              int nb_steps, uint64_t seed, uint32_t c3,
+                                                              uint64_t path_offset, uint32_t step_offset)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t gp = path_offset + p;
+    for (int t = 0; t < nb_steps; ++t)
+        U[static_cast<size_t>(t) * ldw + p] = draw_uniform(seed, c3, gp, step_offset + static_cast<uint32_t>(t));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LogSV generators (pricers/logsv_pricer.py:950-1047)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
+                                                          double *__restrict__ qvar, size_t n, int nb_steps,
+                                                          LogsvConsts c, uint64_t seed, uint32_t c3,
+                                                          uint64_t path_offset, uint32_t step_offset)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double xv = x[p], s = sigma[p], q = qvar[p];
+    double L = log(s);                                                                          // :1039
+    const uint64_t gp = path_offset + p;
+    for (int t = 0; t < nb_steps; ++t) {
+        double w0, w1;
+        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), w0, w1);
+        logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);
+    }
+    x[p] = xv;
+    sigma[p] = s;
+    qvar[p] = q;
+}
+
+__global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, double *__restrict__ sigma,
+                                                        double *__restrict__ qvar, size_t n, int nb_steps,
+                                                        LogsvConsts c, const double *__restrict__ W0,
+                                                        const double *__restrict__ W1, size_t ldw)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double xv = x[p], s = sigma[p], q = qvar[p];
+    double L = log(s);
+    const double *w0p = W0 + p, *w1p = W1 + p;
+#pragma unroll 8
+    for (int t = 0; t < nb_steps; ++t) {
+        const double w0 = w0p[static_cast<size_t>(t) * ldw];
+        const double w1 = w1p[static_cast<size_t>(t) * ldw];
+        logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);                                      // :1028-1030
+    }
+    x[p] = xv;
+    sigma[p] = s;
+    qvar[p] = q;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Heston generators (pricers/heston_pricer.py:334-381; QE is new)
+// ---------------------------------------------------------------------------------------------------
+template <int SCHEME>
+__global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                           double *__restrict__ qvar, size_t n, int nb_steps,
+                                                           HestonConsts c, QeConsts qc, uint64_t seed,
+                                                           uint32_t c3, uint64_t path_offset,
+                                                           uint32_t step_offset)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double xv = x[p], v = var[p], q = qvar[p];
+    const uint64_t gp = path_offset + p;
+    for (int t = 0; t < nb_steps; ++t) {
+        const uint32_t step = step_offset + static_cast<uint32_t>(t);
+        double w0, w1;
+        draw_normals(seed, c3, gp, step, w0, w1);
+        if (SCHEME == SVMC_HESTON_QE) {
+            const double u = draw_uniform(seed, c3, gp, step);
+            heston_qe_step(qc, xv, v, q, w0, w1, u);
+        } else {
+            heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+        }
+    }
+    x[p] = xv;
+    var[p] = v;
+    qvar[p] = q;
+}
+
+__global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                         double *__restrict__ qvar, size_t n, int nb_steps,
+                                                         HestonConsts c, const double *__restrict__ W0,
+                                                         const double *__restrict__ W1, size_t ldw)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double xv = x[p], v = var[p], q = qvar[p];
+    const double *w0p = W0 + p, *w1p = W1 + p;
+#pragma unroll 8
+    for (int t = 0; t < nb_steps; ++t) {
+        const double w0 = w0p[static_cast<size_t>(t) * ldw];
+        const double w1 = w1p[static_cast<size_t>(t) * ldw];
+        heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+    }
+    x[p] = xv;
+    var[p] = v;
+    qvar[p] = q;
+}
+
+__global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                            double *__restrict__ qvar, size_t n, int nb_steps,
+                                                            QeConsts qc, const double *__restrict__ Z0,
+                                                            const double *__restrict__ Z1,
+                                                            const double *__restrict__ U, size_t ldw)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double xv = x[p], v = var[p], q = qvar[p];
+#pragma unroll 4
+    for (int t = 0; t < nb_steps; ++t) {
+        const size_t o = static_cast<size_t>(t) * ldw + p;
+        heston_qe_step(qc, xv, v, q, Z0[o], Z1[o], U[o]);
+    }
+    x[p] = xv;
+    var[p] = v;
+    qvar[p] = q;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Payoff reduction (utils/mc_payoffs.py:61-88).  Deterministic two-stage sums: per-block partials in a
+// fixed tree order, then one block per output column adds the partials -- no fp64 atomics, so a given
+// (n_path, grid) always reproduces the same bits.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// all threads must call; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *lds4)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+__global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restrict__ x, size_t n, double forward,
+                                                          double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
+    double s = 0.0, cnt = 0.0;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
+        const double sp = forward * exp(x[i]);                                                  // :61
+        if (sp == sp) {                                                                         // nanmean :62
+            s += sp;
+            cnt += 1.0;
+        }
+    }
+    s = block_sum(s, lds);
+    cnt = block_sum(cnt, lds);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x + 0] = s;
+        partials[2 * blockIdx.x + 1] = cnt;
+    }
+}
+
+struct PayoffChunk {
+    double strikes[KC];
+    double shifts[KC];  // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
+    int8_t types[KC];
+    int k;
+};
+
+__global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__restrict__ x,
+                                                            const double *__restrict__ qvar, size_t n,
+                                                            double forward, double ttm,
+                                                            const double *__restrict__ spot_sums,
+                                                            PayoffChunk ch, int variable_type,
+                                                            double *__restrict__ partials)
+{
+    __shared__ double lds[4];
+    const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
+    const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
+    double sum[KC], sq[KC], cnt[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) sum[k] = sq[k] = cnt[k] = 0.0;
+
+    for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
+        const double spot = forward * exp(x[i]) - corr;                                         // :61-63
+        const double u = (variable_type == SVMC_LOG_RETURN) ? spot : qvar[i] / ttm;             // :65-68
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (k < ch.k) {
+                const double K = ch.strikes[k];
+                const int ty = ch.types[k];
+                double pay = (ty == SVMC_CALL || ty == SVMC_INV_CALL) ? ((u > K) ? (u - K) : 0.0)   // :75-78
+                                                                      : ((u < K) ? (K - u) : 0.0);  // :79-82
+                if (ty == SVMC_INV_CALL || ty == SVMC_INV_PUT) pay = pay / spot;
+                if (pay == pay) {                                                               // nanmean/nanstd
+                    const double d = pay - ch.shifts[k];
+                    sum[k] += d;
+                    sq[k] = fma(d, d, sq[k]);
+                    cnt[k] += 1.0;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        if (k < ch.k) {
+            const double a = block_sum(sum[k], lds);
+            const double b = block_sum(sq[k], lds);
+            const double c = block_sum(cnt[k], lds);
+            if (threadIdx.x == 0) {
+                double *row = partials + static_cast<size_t>(blockIdx.x) * (3 * KC) + 3 * k;
+                row[0] = a;
+                row[1] = b;
+                row[2] = c;
+            }
+        }
+    }
+}
+
+// out[j] = sum_r partials[r * ld + j]; one block per column j
+__global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials, int n_rows,
+                                                               int ld, double *__restrict__ out)
+{
+    __shared__ double lds[4];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < n_rows; r += BLOCK) s += partials[static_cast<size_t>(r) * ld + j];
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) out[j] = s;
+}
+
+static inline unsigned reduce_grid(size_t n)
+{
+    const size_t g = (n + BLOCK - 1) / BLOCK;
+    return static_cast<unsigned>(g < 1 ? 1 : (g > MAX_REDUCE_GRID ? MAX_REDUCE_GRID : g));
+}
+
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVMC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return SVMC_OK;
+}
+
+static int check_state(const char *fn, const double *x, const double *v, const double *q, int nb_steps, double dt)
+{
+    if (x == nullptr || v == nullptr || q == nullptr) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null state pointer");
+    if (nb_steps < 0) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": nb_steps < 0");
+    if (!(dt > 0.0)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": dt must be positive");
+    return SVMC_OK;
+}
+
+static inline uint32_t make_c3(uint32_t call_id) { return (call_id << 8); }
+
+}  // namespace svmc
+
+using namespace svmc;
+
+extern "C" {
+
+int svmc_fill_state(double *x, double *vol, double *qvar, size_t n_path, double x0, double vol0, double qvar0,
+                    svmc_stream_t stream)
+{
+    SVMC_REQUIRE(x && vol && qvar, "svmc_fill_state: null state pointer");
+    if (n_path == 0) return SVMC_OK;
+    hipLaunchKernelGGL(fill_state_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, vol, qvar,
+                       n_path, x0, vol0, qvar0);
+    return check_launch("svmc_fill_state");
+}
+
+int svmc_fill_normals(double *W0, double *W1, size_t ldw, size_t n_path, int nb_steps, uint64_t seed,
+                      uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(W0 && W1, "svmc_fill_normals: null output");
+    SVMC_REQUIRE(ldw >= n_path && nb_steps >= 0, "svmc_fill_normals: ldw < n_path or nb_steps < 0");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_fill_normals: call_id must fit 24 bits");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    hipLaunchKernelGGL(fill_normals_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), W0, W1, ldw,
+                       n_path, nb_steps, seed, make_c3(call_id), path_offset, step_offset);
+    return check_launch("svmc_fill_normals");
+}
+
+int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint64_t seed, uint32_t call_id,
+                       uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(U, "svmc_fill_uniforms: null output");
+    SVMC_REQUIRE(ldw >= n_path && nb_steps >= 0, "svmc_fill_uniforms: ldw < n_path or nb_steps < 0");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_fill_uniforms: call_id must fit 24 bits");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    hipLaunchKernelGGL(fill_uniforms_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), U, ldw,
+                       n_path, nb_steps, seed, make_c3(call_id), path_offset, step_offset);
+    return check_launch("svmc_fill_uniforms");
+}
+
+int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                            double theta, double kappa1, double kappa2, double beta, double volvol,
+                            double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                            uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+{
+    if (int rc = check_state("svmc_logsv_terminal_rng", x, sigma, qvar, nb_steps, dt)) return rc;
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_terminal_rng: call_id must fit 24 bits");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure);
+    hipLaunchKernelGGL(logsv_rng_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
+                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset);
+    return check_launch("svmc_logsv_terminal_rng");
+}
+
+int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                          double theta, double kappa1, double kappa2, double beta, double volvol,
+                          double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
+                          size_t ldw, svmc_stream_t stream)
+{
+    if (int rc = check_state("svmc_logsv_terminal_w", x, sigma, qvar, nb_steps, dt)) return rc;
+    SVMC_REQUIRE(W0 && W1, "svmc_logsv_terminal_w: null W0/W1");
+    SVMC_REQUIRE(ldw >= n_path, "svmc_logsv_terminal_w: ldw < n_path");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure);
+    hipLaunchKernelGGL(logsv_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
+                       n_path, nb_steps, c, W0, W1, ldw);
+    return check_launch("svmc_logsv_terminal_w");
+}
+
+int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                             double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
+                             uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+{
+    if (int rc = check_state("svmc_heston_terminal_rng", x, var, qvar, nb_steps, dt)) return rc;
+    SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, "svmc_heston_terminal_rng: unknown scheme");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_heston_terminal_rng: call_id must fit 24 bits");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
+    const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
+    if (scheme == SVMC_HESTON_QE)
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
+                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset);
+    else
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(grid_for(n_path)), dim3(BLOCK), 0,
+                           as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id),
+                           path_offset, step_offset);
+    return check_launch("svmc_heston_terminal_rng");
+}
+
+int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                           double theta, double kappa, double rho, double volvol, const double *W0,
+                           const double *W1, size_t ldw, svmc_stream_t stream)
+{
+    if (int rc = check_state("svmc_heston_terminal_w", x, var, qvar, nb_steps, dt)) return rc;
+    SVMC_REQUIRE(W0 && W1, "svmc_heston_terminal_w: null W0/W1");
+    SVMC_REQUIRE(ldw >= n_path, "svmc_heston_terminal_w: ldw < n_path");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
+    hipLaunchKernelGGL(heston_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, var, qvar,
+                       n_path, nb_steps, c, W0, W1, ldw);
+    return check_launch("svmc_heston_terminal_w");
+}
+
+int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                              double theta, double kappa, double rho, double volvol, const double *Z0,
+                              const double *Z1, const double *U, size_t ldw, svmc_stream_t stream)
+{
+    if (int rc = check_state("svmc_heston_qe_terminal_w", x, var, qvar, nb_steps, dt)) return rc;
+    SVMC_REQUIRE(Z0 && Z1 && U, "svmc_heston_qe_terminal_w: null Z0/Z1/U");
+    SVMC_REQUIRE(ldw >= n_path, "svmc_heston_qe_terminal_w: ldw < n_path");
+    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
+    hipLaunchKernelGGL(heston_qe_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, var, qvar,
+                       n_path, nb_steps, qc, Z0, Z1, U, ldw);
+    return check_launch("svmc_heston_qe_terminal_w");
+}
+
+int svmc_payoff_workspace_bytes(size_t *bytes)
+{
+    SVMC_REQUIRE(bytes != nullptr, "svmc_payoff_workspace_bytes: null output");
+    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * sizeof(double);
+    return SVMC_OK;
+}
+
+int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_sums, void *workspace,
+                   size_t workspace_bytes, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(x && spot_sums && workspace, "svmc_spot_sums: null pointer");
+    const unsigned g = reduce_grid(n_path);
+    if (workspace_bytes < static_cast<size_t>(g) * 2 * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, "svmc_spot_sums: workspace too small (svmc_payoff_workspace_bytes)");
+    double *partials = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(spot_sums_kernel, dim3(g), dim3(BLOCK), 0, as_stream(stream), x, n_path, forward, partials);
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream), partials, static_cast<int>(g),
+                       2, spot_sums);
+    return check_launch("svmc_spot_sums");
+}
+
+int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double forward, double ttm,
+                     const double *spot_sums, const double *strikes_host, const int8_t *types_host,
+                     const double *shifts_host, size_t n_strikes, int variable_type, double *sums, void *workspace,
+                     size_t workspace_bytes, svmc_stream_t stream)
+{
+    if (variable_type != SVMC_LOG_RETURN && variable_type != SVMC_Q_VAR)
+        return fail(SVMC_ERR_UNSUPPORTED_VARIABLE, "svmc_payoff_sums: variable_type must be LOG_RETURN or Q_VAR");
+    SVMC_REQUIRE(x && spot_sums && sums && workspace, "svmc_payoff_sums: null pointer");
+    SVMC_REQUIRE(variable_type != SVMC_Q_VAR || qvar != nullptr, "svmc_payoff_sums: Q_VAR needs qvar");
+    SVMC_REQUIRE(n_strikes == 0 || (strikes_host && types_host), "svmc_payoff_sums: null strikes/types");
+    for (size_t k = 0; k < n_strikes; ++k)
+        if (types_host[k] < SVMC_CALL || types_host[k] > SVMC_INV_PUT)
+            return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
+    const unsigned g = reduce_grid(n_path);
+    if (workspace_bytes < static_cast<size_t>(g) * 3 * KC * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, "svmc_payoff_sums: workspace too small (svmc_payoff_workspace_bytes)");
+    double *partials = static_cast<double *>(workspace);
+    for (size_t k0 = 0; k0 < n_strikes; k0 += KC) {
+        PayoffChunk ch;
+        ch.k = static_cast<int>((n_strikes - k0 < static_cast<size_t>(KC)) ? (n_strikes - k0) : KC);
+        for (int k = 0; k < KC; ++k) {
+            ch.strikes[k] = (k < ch.k) ? strikes_host[k0 + k] : 0.0;
+            ch.shifts[k] = (k < ch.k && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
+            ch.types[k] = (k < ch.k) ? types_host[k0 + k] : 0;
+        }
+        hipLaunchKernelGGL(payoff_sums_kernel, dim3(g), dim3(BLOCK), 0, as_stream(stream), x, qvar, n_path, forward,
+                           ttm, spot_sums, ch, variable_type, partials);
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * ch.k), dim3(BLOCK), 0, as_stream(stream), partials,
+                           static_cast<int>(g), 3 * KC, sums + 3 * k0);
+    }
+    return check_launch("svmc_payoff_sums");
+}
+
+int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes, double discfactor,
+                         double n_path_total, double *prices_host, double *stderrs_host)
+{
+    SVMC_REQUIRE(sums_host && prices_host && stderrs_host, "svmc_payoff_finalize: null pointer");
+    for (size_t k = 0; k < n_strikes; ++k) {
+        const double s = sums_host[3 * k], s2 = sums_host[3 * k + 1], cnt = sums_host[3 * k + 2];
+        const double dmean = s / cnt;                     // nanmean of (p - shift); 0/0 -> NaN like NumPy
+        const double mean = (shifts_host ? shifts_host[k] : 0.0) + dmean;
+        double var = s2 / cnt - dmean * dmean;            // nanstd^2, ddof = 0 (shift-invariant)
+        if (var < 0.0) var = 0.0;
+        prices_host[k] = discfactor * mean;                                                     // :85
+        stderrs_host[k] = discfactor * sqrt(var) / sqrt(n_path_total);                          // :86-88
+    }
+    return SVMC_OK;
+}
+
+}  // extern "C"

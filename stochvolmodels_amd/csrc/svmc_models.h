@@ -1,0 +1,138 @@
+// svmc_models.h -- per-path time-step functions (one lane = one path, state in registers).
+//
+// The expressions keep the reference's evaluation order; hipcc contracts a*b+c into FMA (one rounding
+// instead of two), so against the reference on identical W the state agrees to rounding level, not
+// bitwise: tests state 1e-12 relative.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace svmc {
+
+// ---- LogSV, Eq. (3.59): pricers/logsv_pricer.py:1032-1045 ------------------------------------------
+struct LogsvConsts {
+    double dt, sdt, theta, kappa1, kappa2, beta, volvol, eta, eta2;
+    double alpha_half;      // alpha*0.5: -0.5 spot measure, +0.5 inverse measure  (:1032-1035)
+    double adj;             // 0 | beta*eta                                        (:1035)
+    double half_vartheta2;  // 0.5*(beta^2 + volvol^2)                             (:1037)
+    double k1theta;         // kappa1*theta                                        (:1043)
+};
+
+inline LogsvConsts make_logsv_consts(double dt, double theta, double kappa1, double kappa2, double beta,
+                                     double volvol, double eta, int is_spot_measure)
+{
+    LogsvConsts c;
+    c.dt = dt;
+    c.sdt = sqrt(dt);
+    c.theta = theta;
+    c.kappa1 = kappa1;
+    c.kappa2 = kappa2;
+    c.beta = beta;
+    c.volvol = volvol;
+    c.eta = eta;
+    c.eta2 = eta * eta;
+    c.alpha_half = is_spot_measure ? -0.5 : 0.5;
+    c.adj = is_spot_measure ? 0.0 : beta * eta;
+    c.half_vartheta2 = 0.5 * (beta * beta + volvol * volvol);
+    c.k1theta = kappa1 * theta;
+    return c;
+}
+
+// w0, w1 are the scaled increments sqrt(dt)*N(0,1)
+__device__ __forceinline__ void logsv_step(const LogsvConsts &c, double &x, double &L, double &sigma,
+                                           double &qvar, double w0, double w1)
+{
+    const double s = sigma;
+    const double s2dt = ((c.eta2 * s) * s) * c.dt;                                              // :1041
+    const double drift = ((((c.k1theta / s) - c.kappa1) + c.kappa2 * (c.theta - s)) + c.adj * s)
+                         - c.half_vartheta2;
+    x = (x + c.alpha_half * s2dt) + (c.eta * s) * w0;                                           // :1042
+    L = ((L + drift * c.dt) + c.beta * w0) + c.volvol * w1;                                     // :1043
+    const double sn = exp(L);                                                                   // :1044
+    sigma = sn;
+    qvar = qvar + 0.5 * (s2dt + ((c.eta2 * sn) * sn) * c.dt);                                   // :1045
+}
+
+// ---- Heston Euler with the reference's floor: pricers/heston_pricer.py:372-379 ---------------------
+struct HestonConsts {
+    double dt, sdt, theta, kappa, rho, rho_1, volvol;
+};
+
+inline HestonConsts make_heston_consts(double dt, double theta, double kappa, double rho, double volvol)
+{
+    HestonConsts c;
+    c.dt = dt;
+    c.sdt = sqrt(dt);
+    c.theta = theta;
+    c.kappa = kappa;
+    c.rho = rho;
+    c.rho_1 = sqrt(1.0 - rho * rho);
+    c.volvol = volvol;
+    return c;
+}
+
+__device__ __forceinline__ void heston_euler_step(const HestonConsts &c, double &x, double &var, double &qvar,
+                                                  double w0, double w1)
+{
+    const double v = var;
+    const double s = sqrt(v);                                                                   // :374
+    const double s2dt = v * c.dt;                                                               // :375
+    x = (x - 0.5 * s2dt) + s * w0;                                                              // :376
+    qvar = qvar + s2dt;                                                                         // :377
+    const double vn = (v + (c.kappa * (c.theta - v)) * c.dt) + (s * c.volvol) * (c.rho * w0 + c.rho_1 * w1);
+    var = (vn > 1e-4) ? vn : ((vn != vn) ? vn : 1e-4);                  // np.maximum(v, 1e-4)     :379
+}
+
+// ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------
+struct QeConsts {
+    double dt, theta, E, c1, c2, K1, K2, K3, K4, A, K0_plain, K13;
+};
+
+inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho, double volvol)
+{
+    QeConsts c;
+    const double g1 = 0.5, g2 = 0.5;
+    const double E = exp(-kappa * dt);
+    const double kre = kappa * rho / volvol - 0.5;
+    c.dt = dt;
+    c.theta = theta;
+    c.E = E;
+    c.c1 = volvol * volvol * E * (1.0 - E) / kappa;
+    c.c2 = theta * volvol * volvol * (1.0 - E) * (1.0 - E) / (2.0 * kappa);
+    c.K1 = g1 * dt * kre - rho / volvol;
+    c.K2 = g2 * dt * kre + rho / volvol;
+    c.K3 = g1 * dt * (1.0 - rho * rho);
+    c.K4 = g2 * dt * (1.0 - rho * rho);
+    c.A = c.K2 + 0.5 * c.K4;
+    c.K0_plain = -rho * kappa * theta / volvol * dt;
+    c.K13 = c.K1 + 0.5 * c.K3;
+    return c;
+}
+
+__device__ __forceinline__ void heston_qe_step(const QeConsts &c, double &x, double &var, double &qvar,
+                                               double z0, double z1, double u)
+{
+    const double v0 = var;
+    const double m = c.theta + (v0 - c.theta) * c.E;
+    const double s2 = v0 * c.c1 + c.c2;
+    const double psi = s2 / (m * m);
+    double v1, K0;
+    if (psi <= 1.5) {
+        const double ip = 2.0 / psi;
+        const double b2 = ip - 1.0 + sqrt(ip * (ip - 1.0));
+        const double a = m / (1.0 + b2);
+        const double b = sqrt(b2);
+        const double den = 1.0 - 2.0 * c.A * a;
+        v1 = a * (b + z1) * (b + z1);
+        K0 = (den > 0.0) ? (-c.A * b2 * a / den + 0.5 * log(den) - c.K13 * v0) : c.K0_plain;
+    } else {
+        const double p = (psi - 1.0) / (psi + 1.0);
+        const double bt = (1.0 - p) / m;
+        v1 = (u <= p) ? 0.0 : log((1.0 - p) / (1.0 - u)) / bt;
+        K0 = (c.A < bt) ? (-log(p + bt * (1.0 - p) / (bt - c.A)) - c.K13 * v0) : c.K0_plain;
+    }
+    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt(c.K3 * v0 + c.K4 * v1) * z0;
+    qvar = qvar + 0.5 * c.dt * (v0 + v1);
+    var = v1;
+}
+
+}  // namespace svmc

@@ -1,0 +1,116 @@
+"""
+Path sharding over the GPUs of one node.
+
+Paths are independent, so rank r of R owns the global path ids [r*N/R, (r+1)*N/R) and its own resident
+state; the Philox counter is the GLOBAL path id, so the union of the shards is the same path set for any
+R.  The only cross-rank couplings are the two reductions of compute_mc_vars_payoff
+(utils/mc_payoffs.py:61-63 and :85-86): per chain ONE all-reduce of [sum F*exp(x), count] per expiry
+(2*M doubles) and ONE all-reduce of [sum d, sum d^2, count] per strike (3*sum(K_i) doubles), packed fp64,
+over RCCL (torch.distributed backend "nccl") -- a few KB, latency-bound on xGMI.  SURVEY.md 8(e).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first global path id, number of local paths) of `rank`."""
+    lo = (n_total * rank) // world
+    hi = (n_total * (rank + 1)) // world
+    return lo, hi - lo
+
+
+class SingleComm:
+    """one process, one GPU: reductions are already global."""
+    rank = 0
+    world = 1
+
+    def alloc(self, engine, n_doubles: int, tag: str):
+        return engine.alloc_sums(n_doubles, tag)
+
+    def all_reduce_sum(self, engine, handle) -> None:
+        return None
+
+    def to_host(self, engine, ptr, handle, n: int):
+        return engine.download(ptr, n)
+
+
+class TorchComm:
+    """torch.distributed process group (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+
+    The reduction buffers are torch tensors on the engine's device so the collective runs on them in
+    place; libsvmc's kernels write them through `data_ptr()`."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch, self._dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._bufs = {}
+
+    def _device(self, engine):
+        kind = getattr(engine, "torch_device", None)
+        if kind is not None:
+            return self._torch.device(kind)
+        return self._torch.device("cuda", engine.device)
+
+    def alloc(self, engine, n_doubles: int, tag: str):
+        # one persistent tensor per (engine, tag), zero-initialised (never hands garbage to the collective)
+        key = (id(engine), tag)
+        t = self._bufs.get(key)
+        if t is None or t.numel() < n_doubles:
+            t = self._torch.zeros(max(n_doubles, 1), dtype=self._torch.float64, device=self._device(engine))
+            self._bufs[key] = t
+        return t.data_ptr(), t
+
+    def all_reduce_sum(self, engine, handle) -> None:
+        engine.synchronize()                       # svmc kernels that wrote the buffer are complete
+        handle = handle.view(-1)
+        self._dist.all_reduce(handle, op=self._dist.ReduceOp.SUM, group=self.group)
+        if handle.is_cuda:
+            self._torch.cuda.synchronize(handle.device)   # reduced values visible to the next svmc kernels
+
+    def to_host(self, engine, ptr, handle, n: int):
+        engine.synchronize()
+        return handle[:n].detach().cpu().numpy().copy()
+
+
+_default_comm = SingleComm()
+
+
+def get_default_comm():
+    return _default_comm
+
+
+def set_default_comm(comm) -> None:
+    global _default_comm
+    _default_comm = comm if comm is not None else SingleComm()
+
+
+def init_from_env(backend: Optional[str] = None):
+    """one process per GPU launched by torch.distributed.run: bind LOCAL_RANK's GPU, create the process
+    group over RCCL and make it the default communicator of the chain pricers."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        set_default_comm(None)
+        return get_default_comm()
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    set_default_comm(TorchComm())
+    return get_default_comm()

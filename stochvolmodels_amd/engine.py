@@ -1,0 +1,300 @@
+"""
+HipEngine: the host-side owner of one GPU's Monte Carlo state and the thin caller of libsvmc's kernels.
+
+One engine = one HIP device + one stream + the resident per-path state (x, vol, qvar) of `n_path` local
+paths, the per-expiry snapshots the payoff pass reads, and the reduction scratch.  State never leaves
+HBM between expiries (the reference carries it slice to slice in NumPy arrays,
+pricers/logsv_pricer.py:843-856).
+
+The chain drivers in mc_chain.py talk to an engine only through the methods below, so the sharding /
+collective logic can be exercised on CPU by a test double (tests/ only); the product always uses this
+class and fails loudly when libsvmc.so or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+LOG_RETURN, Q_VAR, SIGMA = 1, 2, 3
+HESTON_EULER_FLOOR, HESTON_QE = 0, 1
+_TYPE_CODES = {"C": 0, "P": 1, "IC": 2, "IP": 3}
+
+
+def option_type_codes(optiontypes: Sequence) -> np.ndarray:
+    """'C','P','IC','IP' -> int8; anything else raises like utils/mc_payoffs.py:84."""
+    out = np.empty(len(optiontypes), dtype=np.int8)
+    for i, t in enumerate(optiontypes):
+        code = _TYPE_CODES.get(str(t))
+        if code is None:
+            raise ValueError("unknown option payoff code")
+        out[i] = code
+    return out
+
+
+def payoff_shifts(strikes: np.ndarray, codes: np.ndarray, forward: float, variable_type: int) -> np.ndarray:
+    """per-strike constants subtracted inside the payoff sums (include/svmc.h): the intrinsic value at the
+    forward for LOG_RETURN (the recentred spots average to the forward exactly), zero otherwise."""
+    shifts = np.zeros(len(strikes), dtype=np.float64)
+    if variable_type == LOG_RETURN:
+        call = (codes == 0) | (codes == 2)
+        intrinsic = np.where(call, np.maximum(forward - strikes, 0.0), np.maximum(strikes - forward, 0.0))
+        shifts = np.where(codes >= 2, intrinsic / forward, intrinsic).astype(np.float64)
+    return np.ascontiguousarray(shifts)
+
+
+class DeviceBuffer:
+    """a caller-owned HBM allocation of `n` doubles (svmc_malloc / svmc_free)."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+        self.nbytes = 8 * self.n
+        p = C.c_void_p()
+        _lib.check(_lib.load().svmc_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def free(self) -> None:
+        if getattr(self, "ptr", None):
+            _lib.load().svmc_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def offset(self, n_doubles: int) -> int:
+        return self.ptr + 8 * int(n_doubles)
+
+
+class HipEngine:
+    def __init__(self, n_path: int, device: Optional[int] = None, path_offset: int = 0,
+                 n_snapshots: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        cnt = C.c_int()
+        _lib.check(self.lib.svmc_device_count(C.byref(cnt)))
+        if cnt.value < 1:
+            raise _lib.SvmcError("no HIP device visible: the svmc Monte Carlo path runs on the GPU only")
+        if device is not None:
+            _lib.check(self.lib.svmc_set_device(int(device)))
+        dev = C.c_int()
+        _lib.check(self.lib.svmc_get_device(C.byref(dev)))
+        self.device = dev.value
+        self.n_path = int(n_path)
+        self.path_offset = int(path_offset)
+        self.stream = stream  # None = default stream
+        self.x = DeviceBuffer(self.n_path)
+        self.vol = DeviceBuffer(self.n_path)
+        self.qvar = DeviceBuffer(self.n_path)
+        ws = C.c_size_t()
+        _lib.check(self.lib.svmc_payoff_workspace_bytes(C.byref(ws)))
+        self.ws_bytes = ws.value
+        self.ws = DeviceBuffer(self.ws_bytes // 8)
+        self._snap: Optional[DeviceBuffer] = None
+        self._snap_rows = 0
+        self._rand: Optional[DeviceBuffer] = None
+        self._sums = {}
+        self._prof = None   # list of (name, start_event, stop_event) while kernel timing is on
+        if n_snapshots:
+            self.reserve_snapshots(n_snapshots)
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def synchronize(self) -> None:
+        _lib.check(self.lib.svmc_stream_synchronize(self.stream))
+
+    def reserve_snapshots(self, rows: int) -> None:
+        if self._snap is None or self._snap_rows < rows:
+            if self._snap is not None:
+                self._snap.free()
+            self._snap = DeviceBuffer(rows * self.n_path)
+            self._snap_rows = rows
+
+    def snapshot_ptr(self, row: int) -> int:
+        return self._snap.offset(row * self.n_path)
+
+    def alloc_sums(self, n_doubles: int, tag: str = "sums") -> Tuple[int, object]:
+        """named device buffer for reduction results; returns (ptr, owner).  Buffers with different tags
+        never alias; a tag's buffer is re-used (grown) across calls."""
+        buf = self._sums.get(tag)
+        if buf is None or buf.n < n_doubles:
+            if buf is not None:
+                buf.free()
+            buf = DeviceBuffer(max(int(n_doubles), 1))
+            self._sums[tag] = buf
+        return buf.ptr, buf
+
+    def download(self, ptr: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.float64)
+        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, ptr, 8 * n, self.stream))
+        self.synchronize()
+        return out
+
+    def upload(self, ptr: int, host: np.ndarray) -> None:
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        _lib.check(self.lib.svmc_memcpy_h2d(ptr, host.ctypes.data, host.nbytes, self.stream))
+        self.synchronize()  # the pageable source may be released by the caller
+
+    # ---- kernel timing (HIP events on the launch stream; bench.py) ---------------------------------
+    def start_kernel_timing(self) -> None:
+        self._prof = []
+
+    def _timed(self, name: str, launch) -> None:
+        if self._prof is None:
+            launch()
+            return
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.svmc_event_create(C.byref(e0)))
+        _lib.check(self.lib.svmc_event_create(C.byref(e1)))
+        _lib.check(self.lib.svmc_event_record(e0, self.stream))
+        launch()
+        _lib.check(self.lib.svmc_event_record(e1, self.stream))
+        self._prof.append((name, e0, e1))
+
+    def stop_kernel_timing(self):
+        """-> {kernel name: [durations in ms]} of every generator launch since start_kernel_timing()."""
+        out = {}
+        for name, e0, e1 in self._prof or []:
+            ms = C.c_float()
+            _lib.check(self.lib.svmc_event_elapsed_ms(e0, e1, C.byref(ms)))
+            out.setdefault(name, []).append(ms.value)
+            self.lib.svmc_event_destroy(e0)
+            self.lib.svmc_event_destroy(e1)
+        self._prof = None
+        return out
+
+    # ---- state ----------------------------------------------------------------------------------
+    def fill_state(self, x0: float, vol0: float, qvar0: float) -> None:
+        _lib.check(self.lib.svmc_fill_state(self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path,
+                                            float(x0), float(vol0), float(qvar0), self.stream))
+
+    def set_state(self, x: np.ndarray, vol: np.ndarray, qvar: np.ndarray) -> None:
+        for buf, a in ((self.x, x), (self.vol, vol), (self.qvar, qvar)):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            assert a.shape == (self.n_path,)
+            self.upload(buf.ptr, a)
+
+    def get_state(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        return (self.download(self.x.ptr, self.n_path), self.download(self.vol.ptr, self.n_path),
+                self.download(self.qvar.ptr, self.n_path))
+
+    def snapshot(self, row: int, which: str = "x") -> None:
+        src = self.x.ptr if which == "x" else self.qvar.ptr
+        _lib.check(self.lib.svmc_memcpy_d2d(self.snapshot_ptr(row), src, 8 * self.n_path, self.stream))
+
+    # ---- randoms --------------------------------------------------------------------------------
+    def _rand_buffer(self, n_doubles: int) -> DeviceBuffer:
+        if self._rand is None or self._rand.n < n_doubles:
+            if self._rand is not None:
+                self._rand.free()
+            self._rand = DeviceBuffer(n_doubles)
+        return self._rand
+
+    def upload_randoms(self, arrays: Sequence[np.ndarray], col0: int = 0) -> Tuple[int, ...]:
+        """upload the local column range [col0, col0 + n_path) of host [nb_steps, nb_path_total] arrays."""
+        nb = arrays[0].shape[0]
+        buf = self._rand_buffer(len(arrays) * nb * self.n_path)
+        ptrs = []
+        for i, a in enumerate(arrays):
+            a = np.asarray(a)
+            if a.dtype != np.float64 or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+            assert a.ndim == 2 and a.shape[0] == nb and a.shape[1] >= col0 + self.n_path
+            dst = buf.offset(i * nb * self.n_path)
+            _lib.check(self.lib.svmc_memcpy2d_h2d(dst, 8 * self.n_path, a.ctypes.data + 8 * col0, 8 * a.shape[1],
+                                                  8 * self.n_path, nb, self.stream))
+            ptrs.append(dst)
+        self.synchronize()
+        return tuple(ptrs)
+
+    def fill_normals(self, nb_steps: int, seed: int, call_id: int = 0, step_offset: int = 0) -> Tuple[int, int]:
+        buf = self._rand_buffer(2 * nb_steps * self.n_path)
+        w0, w1 = buf.ptr, buf.offset(nb_steps * self.n_path)
+        _lib.check(self.lib.svmc_fill_normals(w0, w1, self.n_path, self.n_path, nb_steps, seed, call_id,
+                                              self.path_offset, step_offset, self.stream))
+        return w0, w1
+
+    # ---- generators -----------------------------------------------------------------------------
+    def logsv_rng(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
+                  step_offset) -> None:
+        self._timed("logsv_rng_kernel", lambda: _lib.check(self.lib.svmc_logsv_terminal_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
+            int(seed), int(call_id), self.path_offset, int(step_offset), self.stream)))
+
+    def logsv_w(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0_ptr, w1_ptr,
+                ldw=None) -> None:
+        self._timed("logsv_w_kernel", lambda: _lib.check(self.lib.svmc_logsv_terminal_w(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
+            w0_ptr, w1_ptr, self.n_path if ldw is None else int(ldw), self.stream)))
+
+    def heston_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset) -> None:
+        self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_terminal_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa), float(rho), float(volvol), int(scheme), int(seed), int(call_id), self.path_offset,
+            int(step_offset), self.stream)))
+
+    def heston_w(self, nb_steps, dt, theta, kappa, rho, volvol, w0_ptr, w1_ptr, ldw=None) -> None:
+        _lib.check(self.lib.svmc_heston_terminal_w(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa), float(rho), float(volvol), w0_ptr, w1_ptr,
+            self.n_path if ldw is None else int(ldw), self.stream))
+
+    def heston_qe_w(self, nb_steps, dt, theta, kappa, rho, volvol, z0_ptr, z1_ptr, u_ptr, ldw=None) -> None:
+        _lib.check(self.lib.svmc_heston_qe_terminal_w(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa), float(rho), float(volvol), z0_ptr, z1_ptr, u_ptr,
+            self.n_path if ldw is None else int(ldw), self.stream))
+
+    # ---- payoff reduction -----------------------------------------------------------------------
+    def spot_sums(self, x_ptr: int, forward: float, out_ptr: int) -> None:
+        _lib.check(self.lib.svmc_spot_sums(x_ptr, self.n_path, float(forward), out_ptr, self.ws.ptr,
+                                           self.ws_bytes, self.stream))
+
+    def payoff_sums(self, x_ptr: int, qvar_ptr: Optional[int], forward: float, ttm: float, spot_sums_ptr: int,
+                    strikes: np.ndarray, codes: np.ndarray, shifts: np.ndarray, variable_type: int,
+                    out_ptr: int) -> None:
+        k = len(strikes)
+        _lib.check(self.lib.svmc_payoff_sums(
+            x_ptr, qvar_ptr, self.n_path, float(forward), float(ttm), spot_sums_ptr,
+            strikes.ctypes.data_as(C.POINTER(C.c_double)), codes.ctypes.data_as(C.POINTER(C.c_int8)),
+            shifts.ctypes.data_as(C.POINTER(C.c_double)), k, int(variable_type), out_ptr, self.ws.ptr,
+            self.ws_bytes, self.stream))
+
+    def close(self) -> None:
+        for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, *self._sums.values()):
+            if b is not None:
+                b.free()
+
+
+def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float
+                    ) -> Tuple[np.ndarray, np.ndarray]:
+    """host arithmetic of utils/mc_payoffs.py:85-88 on the reduced sums (svmc_payoff_finalize)."""
+    lib = _lib.load()
+    k = len(shifts)
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    shifts = np.ascontiguousarray(shifts, dtype=np.float64)
+    prices, stderrs = np.empty(k), np.empty(k)
+    pd = C.POINTER(C.c_double)
+    _lib.check(lib.svmc_payoff_finalize(sums.ctypes.data_as(pd), shifts.ctypes.data_as(pd), k, float(discfactor),
+                                        float(n_path_total), prices.ctypes.data_as(pd), stderrs.ctypes.data_as(pd)))
+    return prices, stderrs
+
+
+# engines are cached per (device, n_path, path_offset): buffers stay resident across calls
+_ENGINES = {}
+
+
+def get_engine(n_path: int, path_offset: int = 0, device: Optional[int] = None) -> HipEngine:
+    key = (device, int(n_path), int(path_offset))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        if len(_ENGINES) >= 4:  # bound resident HBM: drop the oldest engine
+            _ENGINES.pop(next(iter(_ENGINES))).close()
+        eng = HipEngine(n_path, device=device, path_offset=path_offset)
+        _ENGINES[key] = eng
+    return eng

@@ -1,0 +1,79 @@
+"""
+Chain driver shared by the LogSV and Heston Monte Carlo pricers.
+
+Restates the expiry loop of logsv_mc_chain_pricer / logsv_mc_chain_pricer_fixed_randoms /
+heston_mc_chain_pricer (reference pricers/logsv_pricer.py:806-867, :1100-1162,
+pricers/heston_pricer.py:285-331): one path set, terminal state carried slice to slice, payoff reduction
+per slice.  Re-ordered for the GPU / multi-GPU case:
+
+  phase 1  for every expiry: advance the resident state (one stepping kernel per slice) and snapshot the
+           terminal x (and qvar for Q_VAR chains) in HBM                      -- no host round trip
+  phase 2  per-expiry [sum F*exp(x), count]              -> ONE all-reduce over ranks (2*M doubles)
+  phase 3  per-strike [sum d, sum d^2, count]            -> ONE all-reduce over ranks (3*sum K doubles)
+  phase 4  D2H of the sums, host finalisation (utils/mc_payoffs.py:85-88)
+
+The driver is engine-agnostic: `engine` is a HipEngine in the product (GPU only, no fallback); tests may
+pass a double to exercise the sharding logic on CPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+from .engine import LOG_RETURN, Q_VAR, option_type_codes, payoff_finalize, payoff_shifts
+from .utils.config import VariableType
+
+
+def variable_type_code(variable_type) -> int:
+    code = variable_type.value if isinstance(variable_type, VariableType) else int(variable_type)
+    if code not in (LOG_RETURN, Q_VAR):
+        raise NotImplementedError  # VariableType.SIGMA, reference utils/mc_payoffs.py:69-70
+    return code
+
+
+def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, forwards: np.ndarray,
+                          discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
+                          optiontypes_ttms: Sequence[np.ndarray], variable_type,
+                          advance_slice: Callable[[int], None],
+                          finalize: Callable = payoff_finalize) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    vt = variable_type_code(variable_type)
+    m = len(ttms)
+    if not (len(forwards) == len(discfactors) == len(strikes_ttms) == len(optiontypes_ttms) == m):
+        raise ValueError("chain arrays must have one entry per maturity")
+    strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
+    codes = [option_type_codes(t) for t in optiontypes_ttms]          # ValueError on unknown codes, up front
+    shifts = [payoff_shifts(k, c, float(f), vt) for k, c, f in zip(strikes, codes, forwards)]
+    need_q = vt == Q_VAR
+
+    # phase 1: stepping, state resident
+    engine.reserve_snapshots(m * (2 if need_q else 1))
+    for i in range(m):
+        advance_slice(i)
+        engine.snapshot(i, "x")
+        if need_q:
+            engine.snapshot(m + i, "qvar")
+
+    # phase 2: forward recentring needs the GLOBAL mean of the terminal spots
+    spot_ptr, spot_handle = comm.alloc(engine, 2 * m, "spot")
+    for i in range(m):
+        engine.spot_sums(engine.snapshot_ptr(i), float(forwards[i]), spot_ptr + 16 * i)
+    comm.all_reduce_sum(engine, spot_handle)
+
+    # phase 3: per-strike payoff sums
+    offs = np.concatenate([[0], np.cumsum([3 * len(k) for k in strikes])]).astype(int)
+    sums_ptr, sums_handle = comm.alloc(engine, int(offs[-1]) + 1, "payoff")
+    for i in range(m):
+        engine.payoff_sums(engine.snapshot_ptr(i), engine.snapshot_ptr(m + i) if need_q else None,
+                           float(forwards[i]), float(ttms[i]), spot_ptr + 16 * i, strikes[i], codes[i], shifts[i],
+                           vt, sums_ptr + 8 * int(offs[i]))
+    comm.all_reduce_sum(engine, sums_handle)
+
+    # phase 4
+    sums = comm.to_host(engine, sums_ptr, sums_handle, int(offs[-1]))
+    prices, stderrs = [], []
+    for i in range(m):
+        p, e = finalize(sums[offs[i]:offs[i + 1]], shifts[i], float(discfactors[i]), float(n_path_total))
+        prices.append(p.reshape(np.shape(strikes_ttms[i])))
+        stderrs.append(e.reshape(np.shape(strikes_ttms[i])))
+    return prices, stderrs

@@ -1,0 +1,75 @@
+"""
+LogSvParams: parameters of the log-normal SV model with quadratic drift, Eq. (3.12)
+    dsigma = (kappa1 + kappa2 sigma)(theta - sigma) dt + beta sigma dW0 + volvol sigma dW1
+(hot-path subset of the reference's pricers/logsv/logsv_params.py:34-161; the moment-matrix / grid
+helpers serve the analytic pricer and are out of scope).
+"""
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass
+from typing import Any, Dict, Optional
+
+import numpy as np
+import pandas as pd
+
+from ..model_pricer import ModelParams
+
+
+@dataclass
+class LogSvParams(ModelParams):
+    sigma0: float = 0.2
+    theta: float = 0.2
+    kappa1: float = 1.0
+    kappa2: Optional[float] = 2.5   # None maps to kappa1 / theta
+    beta: float = -1.0
+    volvol: float = 1.0
+    vol_backbone: pd.Series = None
+    H: float = 0.5
+    weights: np.ndarray = None
+    nodes: np.ndarray = None
+
+    def __post_init__(self):
+        if self.kappa2 is None:
+            self.kappa2 = self.kappa1 / self.theta
+        assert 1e-4 < self.H <= 0.5
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict(self)
+
+    def to_str(self) -> str:
+        return (f"sigma0={self.sigma0:0.2f}, theta={self.theta:0.2f}, kappa1={self.kappa1:0.2f}, "
+                f"kappa2={self.kappa2:0.2f}, beta={self.beta:0.2f}, volvol={self.volvol:0.2f}")
+
+    def set_vol_backbone(self, vol_backbone: pd.Series) -> None:
+        self.vol_backbone = vol_backbone
+
+    def _backbone_lookup(self, tau: float) -> float:
+        # first quoted maturity at or beyond tau (reference utils/funcs.py:165-168, is_equal_or_largest)
+        index = self.vol_backbone.index.to_numpy()
+        return self.vol_backbone.loc[index[np.searchsorted(index, tau, side="left")]]
+
+    def get_vol_backbone_eta(self, tau: float) -> float:
+        return self._backbone_lookup(tau) if self.vol_backbone is not None else 1.0
+
+    def get_vol_backbone_etas(self, ttms: np.ndarray) -> np.ndarray:
+        etas = np.ones_like(ttms)
+        if self.vol_backbone is not None:
+            for idx, tau in enumerate(ttms):
+                etas[idx] = self._backbone_lookup(tau)
+        return etas
+
+    @property
+    def kappa(self) -> float:
+        return self.kappa1 + self.kappa2 * self.theta
+
+    @property
+    def theta2(self) -> float:
+        return self.theta * self.theta
+
+    @property
+    def vartheta2(self) -> float:
+        return self.beta * self.beta + self.volvol * self.volvol
+
+    @property
+    def gamma(self) -> float:
+        return self.kappa1 / self.theta

@@ -1,0 +1,178 @@
+"""
+LogSV Monte Carlo on MI355X: drop-in for the MC part of the reference's pricers/logsv_pricer.py
+(model_mc_price_chain :368-427, simulate_terminal_values :589-611, logsv_mc_chain_pricer :806-867,
+simulate_logsv_x_vol_terminal :950-1047, get_randoms_for_chain_valuation :1051-1074,
+logsv_mc_chain_pricer_fixed_randoms :1100-1162).
+
+Same names, keyword signatures, defaults and return structure; the arithmetic runs in libsvmc's HIP
+kernels (one lane per path, fp64, state resident in HBM across expiries).  Two additions, both optional
+keywords: `seed=` (the reference exposes none; default = process seed / set_seed + fresh call id) and
+`comm=` (a stochvolmodels_amd.dist communicator to shard paths over GPUs; default = the process default).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import dist as svdist
+from ..data.option_chain import OptionChain
+from ..engine import get_engine
+from ..mc_chain import price_chain_on_engine, variable_type_code
+from ..utils.config import VariableType
+from ..utils.funcs import next_rng_call, set_time_grid, timer
+from .logsv.logsv_params import LogSvParams
+from .model_pricer import ModelPricer
+
+LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
+
+
+class LogSVPricer(ModelPricer):
+
+    @timer
+    def model_mc_price_chain(self, option_chain: OptionChain, params: LogSvParams, is_spot_measure: bool = True,
+                             variable_type: VariableType = VariableType.LOG_RETURN, nb_path: int = 100000,
+                             nb_steps: Optional[int] = None, **kwargs
+                             ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """price an option chain by Monte Carlo.  `nb_steps` is steps PER YEAR and defaults to
+        int(360*max(ttms)) + 1, exactly the reference's rule (:427)."""
+        if kwargs.get("use_rough_mc"):
+            raise NotImplementedError("the rough-volatility simulator is outside this package's scope")
+        etas = params.get_vol_backbone_etas(ttms=option_chain.ttms)
+        return logsv_mc_chain_pricer(v0=params.sigma0, theta=params.theta, kappa1=params.kappa1,
+                                     kappa2=params.kappa2, beta=params.beta, volvol=params.volvol,
+                                     vol_backbone_etas=etas, ttms=option_chain.ttms, forwards=option_chain.forwards,
+                                     discfactors=option_chain.discfactors, strikes_ttms=option_chain.strikes_ttms,
+                                     optiontypes_ttms=option_chain.optiontypes_ttms, is_spot_measure=is_spot_measure,
+                                     variable_type=variable_type, nb_path=nb_path,
+                                     nb_steps_per_year=nb_steps or int(360 * np.max(option_chain.ttms)) + 1,
+                                     seed=kwargs.get("seed"), comm=kwargs.get("comm"))
+
+    @timer
+    def simulate_terminal_values(self, params: LogSvParams, ttm: float = 1.0, nb_path: int = 100000,
+                                 is_spot_measure: bool = True, **kwargs
+                                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        return simulate_logsv_x_vol_terminal(ttm=ttm, x0=np.zeros(nb_path), sigma0=params.sigma0 * np.ones(nb_path),
+                                             qvar0=np.zeros(nb_path), theta=params.theta, kappa1=params.kappa1,
+                                             kappa2=params.kappa2, beta=params.beta, volvol=params.volvol,
+                                             nb_path=nb_path, is_spot_measure=is_spot_measure,
+                                             seed=kwargs.get("seed"))
+
+
+def _broadcast_state(x0, vol0, qvar0, nb_path):
+    """length-1 inputs are initial values (x0 -> x0*zeros, qvar0 -> zeros, vol0 -> vol0*ones); otherwise the
+    vectors must have nb_path entries (reference :1007-1020, AssertionError)."""
+    x0, vol0, qvar0 = np.asarray(x0, dtype=np.float64), np.asarray(vol0, dtype=np.float64), \
+        np.asarray(qvar0, dtype=np.float64)
+    if x0.shape[0] == 1:
+        x0 = x0 * np.zeros(nb_path)
+    else:
+        assert x0.shape[0] == nb_path
+    if qvar0.shape[0] == 1:
+        qvar0 = np.zeros(nb_path)
+    else:
+        assert qvar0.shape[0] == nb_path
+    if vol0.shape[0] == 1:
+        vol0 = vol0 * np.ones(nb_path)
+    else:
+        assert vol0.shape[0] == nb_path
+    return x0, vol0, qvar0
+
+
+def simulate_logsv_x_vol_terminal(ttm: float, x0: np.ndarray, sigma0: np.ndarray, qvar0: np.ndarray, theta: float,
+                                  kappa1: float, kappa2: float, beta: float, volvol: float,
+                                  vol_backbone_eta: float = 1.0, is_spot_measure: bool = True, nb_path: int = 100000,
+                                  nb_steps_per_year: int = 360, W0: Optional[np.ndarray] = None,
+                                  W1: Optional[np.ndarray] = None, dt: Optional[float] = None,
+                                  seed: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """terminal (x, sigma, qvar) after one slice of Eq. (3.59) (reference :950-1047).  W0/W1 are UNSCALED
+    N(0,1) of shape [nb_steps, nb_path] with their `dt`; when omitted the increments are drawn on device."""
+    x0, sigma0, qvar0 = _broadcast_state(x0, sigma0, qvar0, nb_path)
+    eng = get_engine(nb_path)
+    eng.set_state(x0, sigma0, qvar0)
+    if W0 is None and W1 is None:
+        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
+        rng_seed, call_id = next_rng_call(seed)
+        eng.logsv_rng(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure,
+                      rng_seed, call_id, 0)
+    else:
+        W0, W1 = np.asarray(W0), np.asarray(W1)
+        if W0.shape != W1.shape or W0.ndim != 2 or W0.shape[1] != nb_path:
+            raise ValueError("W0 and W1 must both have shape [nb_steps, nb_path]")
+        if dt is None:
+            raise ValueError("dt must be supplied with W0 and W1")
+        w0, w1 = eng.upload_randoms((W0, W1))
+        eng.logsv_w(W0.shape[0], dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure, w0, w1)
+    return eng.get_state()
+
+
+def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
+                          strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray], v0: float,
+                          theta: float, kappa1: float, kappa2: float, beta: float, volvol: float,
+                          vol_backbone_etas: np.ndarray, is_spot_measure: bool = True, nb_path: int = 100000,
+                          nb_steps_per_year: int = 360, variable_type: VariableType = VariableType.LOG_RETURN,
+                          seed: Optional[int] = None, comm=None) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """chain MC with on-device randoms (reference :806-867): per slice nb_steps_i = int((T_i - T_{i-1})*spy) + 1."""
+    variable_type_code(variable_type)
+    comm = comm or svdist.get_default_comm()
+    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    eng = get_engine(n_local, path_offset=offset)
+    rng_seed, call_id = next_rng_call(seed)
+    grids, t0 = [], 0.0
+    for ttm in ttms:
+        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        grids.append((nb, dt))
+        t0 = ttm
+    step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
+    eng.fill_state(0.0, v0, 0.0)
+
+    def advance(i: int) -> None:
+        nb, dt = grids[i]
+        eng.logsv_rng(nb, dt, theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]), is_spot_measure,
+                      rng_seed, call_id, int(step0[i]))
+
+    return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                 variable_type, advance)
+
+
+def get_randoms_for_chain_valuation(ttms: np.ndarray, nb_path: int = 100000, nb_steps_per_year: int = 360,
+                                    seed: int = 10) -> Tuple[List[np.ndarray], List[np.ndarray], List[float]]:
+    """host-side fixed randoms, identical to the reference (:1051-1074): a local RandomState(seed) draws, per
+    slice, W0 then W1 of shape [nb_steps_i, nb_path]; the global NumPy RNG is untouched."""
+    rng = np.random.RandomState(seed)
+    W0s, W1s, dts, t0 = [], [], [], 0.0
+    for ttm in ttms:
+        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        W0s.append(rng.normal(0, 1, size=(nb, nb_path)))
+        W1s.append(rng.normal(0, 1, size=(nb, nb_path)))
+        dts.append(dt)
+        t0 = ttm
+    return W0s, W1s, dts
+
+
+def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
+                                        strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray],
+                                        W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], dts: Sequence[float],
+                                        v0: float, theta: float, kappa1: float, kappa2: float, beta: float,
+                                        volvol: float, vol_backbone_etas: np.ndarray, is_spot_measure: bool = True,
+                                        variable_type: VariableType = VariableType.LOG_RETURN, comm=None
+                                        ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """chain MC on supplied randoms (reference :1100-1162): nb_path = W0s[0].shape[1]; each rank uploads only
+    its own column range of the host arrays."""
+    variable_type_code(variable_type)
+    nb_path = np.asarray(W0s[0]).shape[1]
+    comm = comm or svdist.get_default_comm()
+    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    eng = get_engine(n_local, path_offset=offset)
+    eng.fill_state(0.0, v0, 0.0)
+
+    def advance(i: int) -> None:
+        W0, W1 = np.asarray(W0s[i]), np.asarray(W1s[i])
+        if W0.shape != W1.shape or W0.shape[1] != nb_path:
+            raise ValueError("every W0/W1 must have shape [nb_steps_i, nb_path]")
+        w0, w1 = eng.upload_randoms((W0, W1), col0=offset)
+        eng.logsv_w(W0.shape[0], float(dts[i]), theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]),
+                    is_spot_measure, w0, w1)
+
+    return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                 variable_type, advance)

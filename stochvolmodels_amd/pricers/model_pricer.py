@@ -1,0 +1,77 @@
+"""
+ModelParams / ModelPricer: the Monte Carlo part of the reference's pricer interface
+(pricers/model_pricer.py:28-41, :83-265).
+
+Kept: model_mc_price_chain, simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols,
+get_log_return_mc_pdf with the reference's signatures.  Out of scope: the
+analytic price_chain family, calibration, and the matplotlib plotting methods.
+"""
+from __future__ import annotations
+
+from abc import ABC
+from dataclasses import asdict, dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+from ..data.option_chain import OptionChain
+from ..utils.config import VariableType
+
+
+@dataclass
+class ModelParams:
+    @classmethod
+    def copy(cls, obj: "ModelParams") -> "ModelParams":
+        return cls(**asdict(obj))
+
+
+class ModelPricer(ABC):
+    def __init__(self):
+        super().__init__()
+
+    def price_chain(self, option_chain: OptionChain, params: ModelParams, **kwargs) -> List[np.ndarray]:
+        raise NotImplementedError("analytic chain pricing is outside the Monte Carlo hot path of this package")
+
+    def model_mc_price_chain(self, option_chain: OptionChain, params: ModelParams,
+                             variable_type: VariableType = VariableType.LOG_RETURN, **kwargs
+                             ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        raise NotImplementedError("must be implemented in parent class")
+
+    def price_chain_with_mc(self, option_chain: OptionChain, params: ModelParams, **kwargs):
+        """alias named by BASELINE.json; the reference's entry point is model_mc_price_chain."""
+        return self.model_mc_price_chain(option_chain=option_chain, params=params, **kwargs)
+
+    def simulate_vol_paths(self, params: ModelParams, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        raise NotImplementedError("must be implemented in parent class")
+
+    def simulate_terminal_values(self, params: ModelParams, **kwargs) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        raise NotImplementedError("must be implemented in parent class")
+
+    def compute_mc_chain_implied_vols(self, option_chain: OptionChain, params: ModelParams,
+                                      variable_type: VariableType = VariableType.LOG_RETURN, nb_path: int = 100000,
+                                      **kwargs) -> Tuple[List[np.ndarray], ...]:
+        """MC prices +/- 1.96 stderr -> implied vols through the chain (reference :216-241).  The inversion
+        itself is OptionChain.compute_model_ivols_from_chain_data (third-party in the reference)."""
+        prices, stds = self.model_mc_price_chain(option_chain=option_chain, params=params,
+                                                 variable_type=variable_type, nb_path=nb_path, **kwargs)
+        std_factor = 1.96
+        ups = [p + std_factor * s for p, s in zip(prices, stds)]
+        downs = [np.maximum(p - std_factor * s, 1e-10) for p, s in zip(prices, stds)]
+        ivols_mid = option_chain.compute_model_ivols_from_chain_data(model_prices=prices)
+        ivols_up = option_chain.compute_model_ivols_from_chain_data(model_prices=ups)
+        ivols_down = option_chain.compute_model_ivols_from_chain_data(model_prices=downs)
+        return prices, ups, downs, ivols_mid, ivols_up, ivols_down, stds
+
+    def get_log_return_mc_pdf(self, ttm: float, params: ModelParams, x_grid: np.ndarray, nb_path: int = 100000
+                              ) -> np.ndarray:
+        """Gaussian-KDE density of the simulated terminal values on x_grid (reference :243-265)."""
+        from scipy import stats
+        t_values = np.asarray(self.simulate_terminal_values(ttm=ttm, params=params, nb_path=nb_path))
+        cut_off = 1e16
+        nans = np.isnan(t_values)
+        pos = np.logical_and(~nans, t_values > cut_off)
+        neg = np.logical_and(~nans, t_values < -cut_off)
+        print(f"in mc: num -inf = {np.sum(neg)}, num +inf = {np.sum(pos)}, num nans = {np.sum(nans)}")
+        t_values = t_values[np.logical_and(np.logical_and(neg == False, pos == False), nans == False)]  # noqa: E712
+        z = stats.gaussian_kde(t_values)(x_grid)
+        return z / np.nansum(z)
