@@ -273,12 +273,13 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  * numbers: as easy as 1, 2, 3", SC'11 (constants and round function from the paper; checked against
  * the Random123 known-answer vectors in tests/test_oracle_golden.py).
  *
- * svmc stream definition (DESIGN.md section "RNG"):
+ * svmc stream definition (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h):
  *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step, stream | call_id << 8)
  *   r0..r3 = philox(ctr, key)
  *   u1 = ((r0 | r1<<32) >> 12) * 2^-52 + 2^-53      in (0,1), exact in fp64
- *   u2 = ((r2 | r3<<32) >> 12) * 2^-52 + 2^-53
- *   stream 0:  R = sqrt(-2 ln u1);  w0 = R cos(2 pi u2);  w1 = R sin(2 pi u2)
+ *   rr = ((r2 | r3<<32) >> 12) * 2^-52 - 1/2        in [-1/2, 1/2), exact in fp64
+ *   q  = r2 & 3
+ *   stream 0:  R = sqrt(-2 ln u1);  theta = (pi/2)(q + rr);  w0 = R cos(theta);  w1 = R sin(theta)
  *   stream 1:  uniform = u1
  * ---------------------------------------------------------------------------------------------- */
 void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
@@ -297,54 +298,42 @@ void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-static inline double u52(uint32_t lo, uint32_t hi)
+static inline double m52(uint32_t lo, uint32_t hi)
 {
-    uint64_t bits = (((uint64_t)hi << 32) | lo) >> 12;
-    return (double)bits * 0x1.0p-52 + 0x1.0p-53;
+    return (double)((((uint64_t)hi << 32) | lo) >> 12) * 0x1.0p-52;   /* in [0,1), exact */
 }
 
-static inline void draw_u(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
-                          double *u1, double *u2)
+static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
+                               uint32_t r[4])
 {
     uint32_t ctr[4] = { (uint32_t)path, (uint32_t)(path >> 32), step, stream | (call_id << 8) };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    uint32_t r[4];
     svo_philox4x32_10(ctr, key, r);
-    *u1 = u52(r[0], r[1]);
-    *u2 = u52(r[2], r[3]);
-}
-
-/* sin(pi*y), cos(pi*y) for y in (0,2): exact reduction to r in [-1/4, 1/4], then libm */
-static inline void sincospi_0_2(double y, double *s, double *c)
-{
-    static const double PI = 3.14159265358979323846;
-    int q = (int)nearbyint(2.0 * y);          /* 0..4 */
-    double r = y - 0.5 * (double)q;           /* exact */
-    double sr = sin(PI * r), cr = cos(PI * r);
-    switch (q & 3) {
-    case 0: *s = sr;  *c = cr;  break;
-    case 1: *s = cr;  *c = -sr; break;
-    case 2: *s = -sr; *c = -cr; break;
-    default: *s = -cr; *c = sr; break;
-    }
 }
 
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1)
 {
-    double u1, u2, s, c;
-    draw_u(seed, call_id, path, step, 0u, &u1, &u2);
+    static const double HALF_PI = 1.57079632679489661923;
+    uint32_t r[4];
+    philox_draw(seed, call_id, path, step, 0u, r);
+    double u1 = m52(r[0], r[1]) + 0x1.0p-53;
+    double rr = m52(r[2], r[3]) - 0.5;
     double R = sqrt(-2.0 * log(u1));
-    sincospi_0_2(2.0 * u2, &s, &c);
-    *w0 = R * c;
-    *w1 = R * s;
+    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);     /* |angle| <= pi/4: no reduction error */
+    switch (r[2] & 3u) {                                     /* rotate by q quarter turns */
+    case 0: *w0 = R * c;  *w1 = R * s;  break;
+    case 1: *w0 = R * -s; *w1 = R * c;  break;
+    case 2: *w0 = R * -c; *w1 = R * -s; break;
+    default: *w0 = R * s; *w1 = R * -c; break;
+    }
 }
 
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step)
 {
-    double u1, u2;
-    draw_u(seed, call_id, path, step, 1u, &u1, &u2);
-    return u1;
+    uint32_t r[4];
+    philox_draw(seed, call_id, path, step, 1u, r);
+    return m52(r[0], r[1]) + 0x1.0p-53;
 }
 
 void svo_fill_normals(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,

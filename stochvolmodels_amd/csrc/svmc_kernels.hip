@@ -62,18 +62,19 @@ __global__ __launch_bounds__(BLOCK) void fill_uniforms_kernel(double *__restrict
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
-                                                          LogsvConsts c, uint64_t seed, uint32_t c3,
+                                                          LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset)
 {
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p];
     double L = log(s);                                                                          // :1039
+    double s2 = s * s;
     const uint64_t gp = path_offset + p;
     for (int t = 0; t < nb_steps; ++t) {
-        double w0, w1;
-        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), w0, w1);
-        logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);
+        double z0, z1;
+        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), z0, z1);
+        logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
     }
     x[p] = xv;
     sigma[p] = s;
@@ -354,7 +355,8 @@ int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, size_t n_pat
     if (int rc = check_state("svmc_logsv_terminal_rng", x, sigma, qvar, nb_steps, dt)) return rc;
     SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_terminal_rng: call_id must fit 24 bits");
     if (n_path == 0 || nb_steps == 0) return SVMC_OK;
-    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure);
+    const LogsvFast c = make_logsv_fast(
+        make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure));
     hipLaunchKernelGGL(logsv_rng_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
                        n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset);
     return check_launch("svmc_logsv_terminal_rng");

@@ -1,0 +1,213 @@
+// svmc_math.h -- the fp64 elementary functions of the stepping kernels, written for the gfx950 VALU.
+//
+// The on-device-RNG LogSV step is VALU-issue bound (DESIGN.md "Rooflines"): with the device libm (OCML)
+// it spends 34% of its issue slots in log+sqrt, 15% in sincospi, 11% in exp and 5% in the IEEE divide
+// (tools/ubench/ablate.hip).  The versions below do the same fp64 arithmetic with ~2.5x fewer
+// instructions by using what this path knows about its arguments:
+//   neg_log(u)      u in (0,1) normal            -> no denormal/negative/NaN handling, integer frexp
+//   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
+//   sincos_quarter  |r| <= 1/2, quadrant given   -> no range reduction at all
+//   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
+//   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
+// Accuracy (tests/test_math_accuracy.py, vs 80-bit libm on the host build; tests/test_gpu_parity.py on
+// the device build): <= 2 ULP each.  Coefficients: tools/gen_minimax.py.
+//
+// The same source compiles for the host (g++, used only by the accuracy test) -- there the hardware
+// seeds are emulated with single-precision reciprocals, the worst seed the refinement must cope with.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SVMC_HD __host__ __device__ __forceinline__
+#else
+#define SVMC_HD static inline
+#endif
+
+namespace svmc {
+
+SVMC_HD double bits_to_double(uint32_t lo, uint32_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+#else
+    const uint64_t b = (static_cast<uint64_t>(hi) << 32) | lo;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+#endif
+}
+
+SVMC_HD uint32_t double_hi(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<uint32_t>(__double2hiint(d));
+#else
+    uint64_t b;
+    memcpy(&b, &d, 8);
+    return static_cast<uint32_t>(b >> 32);
+#endif
+}
+
+SVMC_HD uint32_t double_lo(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<uint32_t>(__double2loint(d));
+#else
+    uint64_t b;
+    memcpy(&b, &d, 8);
+    return static_cast<uint32_t>(b);
+#endif
+}
+
+// Horner step a*b + K with a wave-uniform constant K.  hipcc turns fma(p, z, K) into v_mov_b64 tmp, K ;
+// v_fmac_f64 tmp, p, z (the VOP2 form needs the addend in the destination), i.e. one extra VALU issue per
+// coefficient -- 30 of the 170 instructions of the LogSV step.  Pinning K to an SGPR pair gives the VOP3
+// form v_fma_f64 d, a, b, s[K] with no move (one scalar operand per VOP3 is within the gfx950 constant-bus
+// limit); the s_mov_b32 that load K issue on the scalar unit, beside the VALU stream.
+SVMC_HD double fma_k(double a, double b, double k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+#else
+    return fma(a, b, k);
+#endif
+}
+
+// hardware reciprocal / reciprocal-square-root seeds
+SVMC_HD double rcp_seed(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(a);
+#else
+    return static_cast<double>(1.0f / static_cast<float>(a));
+#endif
+}
+
+SVMC_HD double rsq_seed(double a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(a);
+#else
+    return static_cast<double>(1.0f / sqrtf(static_cast<float>(a)));
+#endif
+}
+
+// 1/a for a normal and far from the overflow/underflow edges: seed + two Newton steps (quadratic each).
+SVMC_HD double rcp_fast(double a)
+{
+    double y = rcp_seed(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// 1/a to ~2^-48 (one Newton step on the 2^-24 seed): enough wherever the quotient enters a small term.
+SVMC_HD double rcp_1n(double a)
+{
+    const double y = rcp_seed(a);
+    return fma(y, fma(-a, y, 1.0), y);
+}
+
+// sqrt(t) for normal t > 0 (no scaling): Goldschmidt step on the rsq seed, then one Newton correction.
+SVMC_HD double sqrt_pos(double t)
+{
+    const double y = rsq_seed(t);
+    double g = t * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, t);
+    return fma(d, h, g);
+}
+
+// exp(x) = 2^n * (1 + r + r^2 E(r)),  n = rint(x log2 e),  r = x - n ln2 (hi/lo),  |r| <= ln2/2
+SVMC_HD double exp_fast(double x)
+{
+    const double n = rint(x * 0x1.71547652b82fep+0);
+    double r = fma(-n, 0x1.62e42fee00000p-1, x);
+    r = fma(-n, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.af38a9b0ec855p-26;
+    p = fma_k(p, r, 0x1.289185613a3d6p-22);
+    p = fma_k(p, r, 0x1.71de0dae63bb3p-19);
+    p = fma_k(p, r, 0x1.a019b90d2ae7ap-16);
+    p = fma_k(p, r, 0x1.a01a01a7c41d5p-13);
+    p = fma_k(p, r, 0x1.6c16c1788bd90p-10);
+    p = fma_k(p, r, 0x1.11111111109b3p-7);
+    p = fma_k(p, r, 0x1.5555555553d63p-5);
+    p = fma_k(p, r, 0x1.5555555555556p-3);
+    p = fma_k(p, r, 0x1.0000000000001p-1);
+    const double y = fma(p, r * r, r) + 1.0;
+    return ldexp(y, static_cast<int>(n));
+}
+
+// -ln(u) for u in (0,1), normal.  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,
+// f = m - 1, s = f/(2+f), ln(1+f) = f - (f^2/2 - s (f^2/2 + R)), R = s^2 G(s^2)   (Cody-Waite / fdlibm form)
+SVMC_HD double neg_log(double u)
+{
+    uint32_t hx = double_hi(u);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = static_cast<int>(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = bits_to_double(double_lo(u), hx);
+    const double dk = static_cast<double>(k);
+    const double f = m - 1.0;
+    const double s = f * rcp_1n(2.0 + f);   // s only multiplies the O(f^2) tail: 2^-48 is ample
+    const double z = s * s;
+    double p = 0x1.2b5900de53b32p-3;
+    p = fma_k(p, z, 0x1.39fe51a7c18f9p-3);
+    p = fma_k(p, z, 0x1.7462b51cb66b1p-3);
+    p = fma_k(p, z, 0x1.c71c62e3f11e6p-3);
+    p = fma_k(p, z, 0x1.2492492df281ap-2);
+    p = fma_k(p, z, 0x1.99999999952d7p-2);
+    p = fma_k(p, z, 0x1.5555555555558p-1);
+    const double R = p * z;
+    const double hfsq = (0.5 * f) * f;
+    const double t2 = fma(-s, hfsq + R, hfsq);       // f^2/2 - s (f^2/2 + R)
+    const double lg = f - t2;                        // ln(m)
+    const double a = fma(dk, 0x1.a39ef35793c76p-33, lg);
+    return fma(-dk, 0x1.62e42fee00000p-1, -a);      // -(k ln2 + ln m)
+}
+
+// cos and sin of (pi/2)(q + r) for |r| <= 1/2 and q in {0,1,2,3}: two even/odd polynomials in r, then the
+// quadrant rotation by sign flips and one swap.
+SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)
+{
+    const double z = r * r;
+    double ps = -0x1.6c5b875d4e739p-31;
+    ps = fma_k(ps, z, 0x1.e8eed12ee00a3p-25);
+    ps = fma_k(ps, z, -0x1.e3074b4ff3058p-19);
+    ps = fma_k(ps, z, 0x1.50783485cbd83p-13);
+    ps = fma_k(ps, z, -0x1.32d2cce62ac22p-8);
+    ps = fma_k(ps, z, 0x1.466bc6775aad9p-4);
+    ps = fma_k(ps, z, -0x1.4abbce625be53p-1);
+    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);
+    double pc = 0x1.1e745e5e09f6dp-34;
+    pc = fma_k(pc, z, -0x1.b6de8b8e9ba08p-28);
+    pc = fma_k(pc, z, 0x1.f9d3870871194p-22);
+    pc = fma_k(pc, z, -0x1.a6d1f2a086c90p-16);
+    pc = fma_k(pc, z, 0x1.e1f506891ae95p-11);
+    pc = fma_k(pc, z, -0x1.55d3c7e3cbff7p-6);
+    pc = fma_k(pc, z, 0x1.03c1f081b5ac4p-2);
+    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);
+    const double s0 = ps * r;            // sin((pi/2) r)
+    const double c0 = fma_k(pc, z, 1.0);  // cos((pi/2) r)
+    // q=0: (c, s)  q=1: (-s, c)  q=2: (-c, -s)  q=3: (s, -c)
+    const bool swap = (q & 1u) != 0u;
+    const double cq = swap ? s0 : c0;
+    const double sq = swap ? c0 : s0;
+    const uint32_t cneg = ((q + 1u) & 2u) << 30;
+    const uint32_t sneg = (q & 2u) << 30;
+    cs = bits_to_double(double_lo(cq), double_hi(cq) ^ cneg);
+    sn = bits_to_double(double_lo(sq), double_hi(sq) ^ sneg);
+}
+
+}  // namespace svmc

@@ -5,10 +5,19 @@
 // increment it needs in registers, no generator state lives in memory and the result is independent of
 // how paths are sharded over GPUs.  Replaces the reference's serial MT19937+polar draw of two
 // [nb_steps, nb_path] arrays (pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370).
-// The CPU twin used by the parity tests is oracle/svmc_oracle.c (svo_draw_normals).
+//
+// Stream definition (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals):
+//   (r0, r1, r2, r3) = philox4x32_10(ctr = (path_lo, path_hi, step, stream | call_id << 8), key = seed)
+//   u1 = double(1.m) - (1 - 2^-53),  m = top 52 bits of r1:r0          in (0,1), exact
+//   rr = double(1.m) - 1.5,          m = top 52 bits of r3:r2          in [-1/2, 1/2), exact
+//   q  = r2 & 3                                                          quadrant (bits not used by rr)
+//   stream 0:  R = sqrt(-2 ln u1), theta = (pi/2)(q + rr),  (w0, w1) = R (cos theta, sin theta)
+//   stream 1:  uniform = u1
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "svmc_math.h"
 
 namespace svmc {
 
@@ -18,48 +27,57 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
+        // one v_mad_u64_u32 per 32x32->64 product, one v_bitop3_b32 (xor3) per mixed word
+        const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), c3, k1, 0x96);
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
         k0 += W0;
         k1 += W1;
     }
     r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
-// 52 random mantissa bits -> u = m * 2^-52 + 2^-53 in (0,1); both operations are exact in fp64.
-__device__ __forceinline__ double u52(uint32_t lo, uint32_t hi)
+// top 52 bits of hi:lo as the mantissa of a double in [1,2): two v_alignbit_b32
+__device__ __forceinline__ double mantissa_1_2(uint32_t lo, uint32_t hi)
 {
-    const uint64_t bits = ((static_cast<uint64_t>(hi) << 32) | lo) >> 12;
-    return __longlong_as_double(0x3FF0000000000000ll | static_cast<long long>(bits)) - (1.0 - 0x1.0p-53);
+    const uint32_t mhi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12);   // 0x3FF00000 | hi >> 12
+    const uint32_t mlo = __builtin_amdgcn_alignbit(hi, lo, 12);       // (hi:lo) >> 12
+    return __hiloint2double(static_cast<int>(mhi), static_cast<int>(mlo));
 }
 
-// stream 0: Box-Muller pair.  R = sqrt(-2 ln u1), (w0, w1) = R (cos 2 pi u2, sin 2 pi u2)
+__device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step, uint32_t (&r)[4])
+{
+    philox4x32_10(static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32), step, c3,
+                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+}
+
+// stream 0: Box-Muller pair of UNSCALED N(0,1)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
                                              double &w0, double &w1)
 {
     uint32_t r[4];
-    philox4x32_10(static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32), step, c3,
-                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
-    const double u1 = u52(r[0], r[1]);
-    const double u2 = u52(r[2], r[3]);
-    const double R = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    w0 = R * c;
-    w1 = R * s;
+    philox_draw(seed, c3, path, step, r);
+    const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
+    const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
+    const double e = neg_log(u1);
+    const double R = sqrt_pos(e + e);
+    double sn, cs;
+    sincos_quarter(r[2] & 3u, rr, sn, cs);
+    w0 = R * cs;
+    w1 = R * sn;
 }
 
 // stream 1: one uniform in (0,1)
 __device__ __forceinline__ double draw_uniform(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step)
 {
     uint32_t r[4];
-    philox4x32_10(static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32), step, c3 | 1u,
-                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
-    return u52(r[0], r[1]);
+    philox_draw(seed, c3 | 1u, path, step, r);
+    return mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
 }
 
 }  // namespace svmc

@@ -1,0 +1,13 @@
+// Host build of stochvolmodels_amd/csrc/svmc_math.h for tests/test_math_accuracy.py (g++ only).
+#include <stddef.h>
+#include "svmc_math.h"
+extern "C" {
+void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
+void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }
+void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }
+void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
+void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) svmc::sincos_quarter(q[i], r[i], s[i], c[i]);
+}
+}
