@@ -10,7 +10,8 @@
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
 // Accuracy (tests/test_math_accuracy.py, vs 80-bit libm on the host build; tests/test_gpu_parity.py on
-// the device build): <= 2 ULP each.  Coefficients: tools/gen_minimax.py.
+// the device build): exp, sin, cos <= 2 ULP; -log <= 3 ULP; sqrt, 1/x correctly rounded on the sampled
+// ranges.  Coefficients: tools/gen_minimax.py.
 //
 // The same source compiles for the host (g++, used only by the accuracy test) -- there the hardware
 // seeds are emulated with single-precision reciprocals, the worst seed the refinement must cope with.

@@ -1,0 +1,14 @@
+"""shared inputs of the distributed tests"""
+import numpy as np
+
+_KK = np.array([0.8, 1.0, 1.2])
+LOGSV_CASE = dict(
+    ttms=np.array([0.05, 0.1, 0.25]), forwards=np.array([1.0, 1.01, 1.02]), discfactors=np.array([0.999, 0.99, 0.98]),
+    strikes_ttms=tuple(f * _KK for f in (1.0, 1.01, 1.02)),
+    optiontypes_ttms=(np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"]), np.array(["P", "C", "IC"])),
+    v0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458,
+    vol_backbone_etas=np.array([1.0, 0.95, 1.05]), is_spot_measure=True, nb_path=1001, nb_steps_per_year=120, seed=77)
+HESTON_CASE = dict(
+    ttms=np.array([0.05, 0.1]), forwards=np.array([1.0, 1.01]), discfactors=np.array([0.999, 0.99]),
+    strikes_ttms=(_KK, 1.01 * _KK), optiontypes_ttms=(np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"])),
+    v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4, nb_path=1001, seed=78, scheme="qe", nb_steps_per_year=100)

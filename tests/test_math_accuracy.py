@@ -1,0 +1,86 @@
+"""
+Accuracy of the hand-written fp64 functions of stochvolmodels_amd/csrc/svmc_math.h, host build (g++), against
+80-bit libm.  The host build emulates the v_rcp_f64 / v_rsq_f64 seeds with single-precision reciprocals (2^-24,
+what the hardware delivers: tools/ubench/math_probe.hip), so the refinement steps see their worst case.
+Stated bounds: exp, sin, cos <= 2 ULP (measured 1.1 / 1.6 / 1.0); -log <= 3 ULP (measured 2.8: its quotient
+uses a single Newton step, which is what bounds it); sqrt and 1/x correctly rounded on the sampled ranges.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DP = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("probe") / "libmath_probe.so")
+    flags = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", *flags,
+                    "-I" + os.path.join(ROOT, "stochvolmodels_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "math_probe.cpp"), "-o", so], check=True)
+    return C.CDLL(so)
+
+
+def _call(lib, fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    getattr(lib, fn)(x.ctypes.data_as(DP), y.ctypes.data_as(DP), C.c_size_t(x.size))
+    return y
+
+
+def _ulp(y, ref):
+    ref = np.asarray(ref, dtype=np.longdouble)
+    return float(np.max(np.abs((y.astype(np.longdouble) - ref) / np.spacing(np.abs(ref.astype(np.float64))))))
+
+
+N = 400_000
+
+
+def test_exp(probe):
+    rng = np.random.default_rng(0)
+    for lo, hi in ((-1, 1), (-30, 30), (-700, 700)):
+        x = rng.uniform(lo, hi, N)
+        assert _ulp(_call(probe, "probe_exp", x), np.exp(x.astype(np.longdouble))) <= 2.0
+    assert _call(probe, "probe_exp", np.array([800.0]))[0] == np.inf          # v_ldexp saturation semantics
+    assert _call(probe, "probe_exp", np.array([-800.0]))[0] == 0.0
+    assert np.isnan(_call(probe, "probe_exp", np.array([np.nan]))[0])
+
+
+def test_neg_log(probe):
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, 2 ** 52, N).astype(np.float64) * 2.0 ** -52 + 2.0 ** -53       # the RNG lattice
+    assert _ulp(_call(probe, "probe_neg_log", u), -np.log(u.astype(np.longdouble))) <= 3.0
+    u = np.concatenate([2.0 ** -rng.uniform(0, 53, N), 1 - 2.0 ** -rng.uniform(1, 53, N),
+                        [2.0 ** -53, 1 - 2.0 ** -53, 0.5, np.sqrt(0.5)]])
+    u = u[(u > 0) & (u < 1)]
+    assert _ulp(_call(probe, "probe_neg_log", u), -np.log(u.astype(np.longdouble))) <= 3.0
+
+
+def test_sqrt_and_rcp(probe):
+    rng = np.random.default_rng(2)
+    t = 2.0 ** rng.uniform(-60, 9, N)
+    assert _ulp(_call(probe, "probe_sqrt", t), np.sqrt(t.astype(np.longdouble))) <= 1.0
+    a = 2.0 ** rng.uniform(-20, 20, N)
+    assert _ulp(_call(probe, "probe_rcp", a), 1 / a.astype(np.longdouble)) <= 1.0
+
+
+def test_sincos_quarter(probe):
+    rng = np.random.default_rng(3)
+    r = np.concatenate([rng.uniform(-0.5, 0.5, N), [-0.5, 0.0, 0.5 - 2.0 ** -53]])
+    n = r.size
+    pi = np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16)
+    for q in range(4):
+        qq = np.full(n, q, dtype=np.uint32)
+        s, c = np.empty(n), np.empty(n)
+        probe.probe_sincos(qq.ctypes.data_as(C.POINTER(C.c_uint32)), r.ctypes.data_as(DP), s.ctypes.data_as(DP),
+                           c.ctypes.data_as(DP), C.c_size_t(n))
+        ang = pi / 2 * (q + r.astype(np.longdouble))
+        assert np.max(np.abs(s - np.sin(ang))) <= 2.3e-16
+        assert np.max(np.abs(c - np.cos(ang))) <= 2.3e-16
+        if q == 0:
+            assert _ulp(s, np.sin(ang)) <= 2.0 and _ulp(c, np.cos(ang)) <= 2.0
