@@ -26,7 +26,7 @@ from .utils.config import VariableType
 
 
 def variable_type_code(variable_type) -> int:
-    code = variable_type.value if isinstance(variable_type, VariableType) else int(variable_type)
+    code = int(getattr(variable_type, "value", variable_type))   # this package's enum, the reference's, or an int
     if code not in (LOG_RETURN, Q_VAR):
         raise NotImplementedError  # VariableType.SIGMA, reference utils/mc_payoffs.py:69-70
     return code
