@@ -81,6 +81,58 @@ __global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x
     qvar[p] = q;
 }
 
+// Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
+// the NARR*U loads of the next U steps are issued before the current U steps are computed, so every wave keeps
+// NARR*U x 512 B in flight (hipcc does not unroll a loop that contains inline asm, and one load per array in
+// flight leaves the memory system latency-bound: 5.3 -> 5.7 TB/s for LogSV at U = 4; U = 8, 16 give no more).
+constexpr int STREAM_U = 4;
+
+template <int NARR, class Step>
+__device__ __forceinline__ void streamed_time_loop(const double *const (&w)[NARR], size_t ldw, int nb_steps,
+                                                   Step &&step)
+{
+    constexpr int U = STREAM_U;
+    double a[NARR][U], b[NARR][U];
+    int t = 0;
+    if (nb_steps >= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < NARR; ++k) a[k][u] = w[k][static_cast<size_t>(u) * ldw];
+        for (; t + 2 * U <= nb_steps; t += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)                         // prefetch steps t+U .. t+2U-1
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) b[k][u] = w[k][static_cast<size_t>(t + U + u) * ldw];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double v[NARR];
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) v[k] = a[k][u];
+                step(v);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < NARR; ++k) a[k][u] = b[k][u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double v[NARR];
+#pragma unroll
+            for (int k = 0; k < NARR; ++k) v[k] = a[k][u];
+            step(v);
+        }
+        t += U;
+    }
+    for (; t < nb_steps; ++t) {
+        double v[NARR];
+#pragma unroll
+        for (int k = 0; k < NARR; ++k) v[k] = w[k][static_cast<size_t>(t) * ldw];
+        step(v);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                         double *__restrict__ qvar, size_t n, int nb_steps,
                                                         LogsvConsts c, const double *__restrict__ W0,
@@ -90,13 +142,10 @@ __global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, 
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p];
     double L = log(s);
-    const double *w0p = W0 + p, *w1p = W1 + p;
-#pragma unroll 8
-    for (int t = 0; t < nb_steps; ++t) {
-        const double w0 = w0p[static_cast<size_t>(t) * ldw];
-        const double w1 = w1p[static_cast<size_t>(t) * ldw];
-        logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);                                      // :1028-1030
-    }
+    const double *const w[2] = {W0 + p, W1 + p};
+    streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&v)[2]) {
+        logsv_step(c, xv, L, s, q, c.sdt * v[0], c.sdt * v[1]);                                   // :1028-1030
+    });
     x[p] = xv;
     sigma[p] = s;
     qvar[p] = q;
@@ -140,13 +189,10 @@ __global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x,
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], v = var[p], q = qvar[p];
-    const double *w0p = W0 + p, *w1p = W1 + p;
-#pragma unroll 8
-    for (int t = 0; t < nb_steps; ++t) {
-        const double w0 = w0p[static_cast<size_t>(t) * ldw];
-        const double w1 = w1p[static_cast<size_t>(t) * ldw];
-        heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
-    }
+    const double *const w[2] = {W0 + p, W1 + p};
+    streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) {
+        heston_euler_step(c, xv, v, q, c.sdt * z[0], c.sdt * z[1]);
+    });
     x[p] = xv;
     var[p] = v;
     qvar[p] = q;
@@ -161,11 +207,8 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], v = var[p], q = qvar[p];
-#pragma unroll 4
-    for (int t = 0; t < nb_steps; ++t) {
-        const size_t o = static_cast<size_t>(t) * ldw + p;
-        heston_qe_step(qc, xv, v, q, Z0[o], Z1[o], U[o]);
-    }
+    const double *const w[3] = {Z0 + p, Z1 + p, U + p};
+    streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) { heston_qe_step(qc, xv, v, q, z[0], z[1], z[2]); });
     x[p] = xv;
     var[p] = v;
     qvar[p] = q;

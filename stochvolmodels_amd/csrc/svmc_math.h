@@ -130,6 +130,13 @@ SVMC_HD double sqrt_pos(double t)
     return fma(d, h, g);
 }
 
+// sqrt(t) for t >= 0 including exact zero (the rsq seed of 0 is +inf): Heston's variance before its first floor.
+SVMC_HD double sqrt_pos0(double t)
+{
+    const double r = sqrt_pos(t);
+    return (t == 0.0) ? 0.0 : r;
+}
+
 // exp(x) = 2^n * (1 + r + r^2 E(r)),  n = rint(x log2 e),  r = x - n ln2 (hi/lo),  |r| <= ln2/2
 SVMC_HD double exp_fast(double x)
 {

@@ -45,11 +45,11 @@ __device__ __forceinline__ void logsv_step(const LogsvConsts &c, double &x, doub
 {
     const double s = sigma;
     const double s2dt = ((c.eta2 * s) * s) * c.dt;                                              // :1041
-    const double drift = ((((c.k1theta / s) - c.kappa1) + c.kappa2 * (c.theta - s)) + c.adj * s)
-                         - c.half_vartheta2;
+    const double drift = ((((c.k1theta * rcp_fast(s)) - c.kappa1) + c.kappa2 * (c.theta - s)) + c.adj * s)
+                         - c.half_vartheta2;                    // k1theta/s: v_rcp_f64 + 2 Newton steps (<= 1 ULP)
     x = (x + c.alpha_half * s2dt) + (c.eta * s) * w0;                                           // :1042
     L = ((L + drift * c.dt) + c.beta * w0) + c.volvol * w1;                                     // :1043
-    const double sn = exp(L);                                                                   // :1044
+    const double sn = exp_fast(L);                                                              // :1044
     sigma = sn;
     qvar = qvar + 0.5 * (s2dt + ((c.eta2 * sn) * sn) * c.dt);                                   // :1045
 }
@@ -125,7 +125,7 @@ __device__ __forceinline__ void heston_euler_step(const HestonConsts &c, double 
                                                   double w0, double w1)
 {
     const double v = var;
-    const double s = sqrt(v);                                                                   // :374
+    const double s = sqrt_pos0(v);                           // v >= 1e-4 after the first floor    :374
     const double s2dt = v * c.dt;                                                               // :375
     x = (x - 0.5 * s2dt) + s * w0;                                                              // :376
     qvar = qvar + s2dt;                                                                         // :377
