@@ -47,30 +47,57 @@ def parse():
     ap.add_argument("--nb-steps", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true")
-    ap.add_argument("--cpu-sample-paths", type=int, default=1 << 17)
+    ap.add_argument("--cpu-sample-paths", type=int, default=1 << 19)
     return ap.parse_args()
 
 
 def cpu_baseline(nb_steps: int, n_sample: int, params, strikes, types) -> dict:
-    """the reference's algorithm on one host core: materialise W0, W1 [nb_steps, n] with MT19937 + polar
-    normals (numpy RandomState == the reference's generator family), then the step-major fp64 loop and the
-    payoff pass -- oracle/svmc_oracle.c (kind "port")."""
+    """the reference's algorithm on ONE host core (the reference is single-threaded): materialise W0, W1
+    [nb_steps, n] with MT19937 + polar normals (NumPy's legacy RandomState == the reference's generator family),
+    then the step-major fp64 loop and the payoff pass -- oracle/svmc_oracle.c (kind "port").  Done in chunks of
+    2^17 paths (2.1 GB of normals each), like BASELINE.md section 3 prescribes."""
     from oracle import oracle
     oracle.build()
     dt = 1.0 / nb_steps
-    t0 = time.perf_counter()
+    chunk = min(n_sample, 1 << 17)
+    t_rng = t_all = 0.0
     rng = np.random.RandomState(10)
-    W0 = rng.normal(0, 1, size=(nb_steps, n_sample))
-    W1 = rng.normal(0, 1, size=(nb_steps, n_sample))
-    t_rng = time.perf_counter() - t0
-    x, s, q = oracle.logsv_terminal_w(np.zeros(n_sample), params.sigma0 * np.ones(n_sample), np.zeros(n_sample), dt,
-                                      params.theta, params.kappa1, params.kappa2, params.beta, params.volvol, W0, W1)
-    pr, sd = oracle.payoff(x, q, 1.0, 1.0, strikes, types)
-    t_all = time.perf_counter() - t0
-    return {"value": n_sample * nb_steps / t_all, "unit": "path-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} paths x {nb_steps} steps, 21 strikes; RandomState normals {t_rng:.1f}s of "
-                      f"{t_all:.1f}s; host cores available: {os.cpu_count()}",
+    done = 0
+    while done < n_sample:
+        t0 = time.perf_counter()
+        W0 = rng.normal(0, 1, size=(nb_steps, chunk))
+        W1 = rng.normal(0, 1, size=(nb_steps, chunk))
+        t1 = time.perf_counter()
+        x, s, q = oracle.logsv_terminal_w(np.zeros(chunk), params.sigma0 * np.ones(chunk), np.zeros(chunk), dt,
+                                          params.theta, params.kappa1, params.kappa2, params.beta, params.volvol,
+                                          W0, W1)
+        pr, sd = oracle.payoff(x, q, 1.0, 1.0, strikes, types)
+        t2 = time.perf_counter()
+        t_rng += t1 - t0
+        t_all += t2 - t0
+        done += chunk
+        del W0, W1
+    return {"value": done * nb_steps / t_all, "unit": "path-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{done} paths x {nb_steps} steps in chunks of {chunk}, 21 strikes; RandomState normals "
+                      f"{t_rng:.1f}s of {t_all:.1f}s; host cores available: {os.cpu_count()}",
             "prices_head": [float(v) for v in pr[:3]]}
+
+
+def cpu_baseline_all_cores(nb_steps: int, params) -> dict:
+    """the same fp64 step on ALL host cores with the counter-based (Philox + libm Box-Muller) draw generated on
+    the fly, OpenMP over paths (oracle svo_logsv_terminal_rng) -- not the reference's algorithm (which is
+    serial), but the fairest CPU number for the GPU kernel's own algorithm."""
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    n = min(1 << 22, max(1 << 14, (cores * (1 << 13))))
+    x0, s0, q0 = np.zeros(n), params.sigma0 * np.ones(n), np.zeros(n)
+    t0 = time.perf_counter()
+    oracle.logsv_terminal_rng(x0, s0, q0, nb_steps, 1.0 / nb_steps, params.theta, params.kappa1, params.kappa2,
+                              params.beta, params.volvol, 7)
+    t = time.perf_counter() - t0
+    return {"value": n * nb_steps / t, "unit": "path-steps/s", "cores": cores, "kind": "port (counter-based draw, OpenMP)",
+            "sample": f"{n} paths x {nb_steps} steps, stepping only, {t:.1f}s"}
 
 
 def streamed_roofline(eng, params, nb_steps: int) -> dict:
@@ -117,6 +144,7 @@ def main():
         torch.cuda.set_device(0)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -147,7 +175,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = eng.stop_kernel_timing().get("logsv_rng_kernel", [float("nan")])
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -184,9 +212,10 @@ def main():
             "stderr_head": [float(v) for v in stderrs[0][:3]],
         }
         if world == 1 and not args.no_streamed:
-            result["roofline_streamed"] = streamed_roofline(eng, P, min(args.nb_steps, 512))
+            result["roofline_streamed"] = streamed_roofline(eng, P, min(args.nb_steps, 1024))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(nb, args.cpu_sample_paths, P, strikes, types)
+            result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nb, P)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -360,6 +360,10 @@ void svo_logsv_terminal_rng(size_t n_path, int nb_steps, double dt,
                             uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset)
 {
     logsv_consts c = logsv_make_consts(dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure);
+    /* paths are independent: with -fopenmp this loop is the all-host-cores CPU baseline of bench.py */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t p = 0; p < n_path; ++p) {
         double xp = x[p], sp = sigma[p], qp = qvar[p], L = log(sp), w0, w1;
         for (int t = 0; t < nb_steps; ++t) {

@@ -170,8 +170,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         double w0, w1;
         draw_normals(seed, c3, gp, step, w0, w1);
         if (SCHEME == SVMC_HESTON_QE) {
-            const double u = draw_uniform(seed, c3, gp, step);
-            heston_qe_step(qc, xv, v, q, w0, w1, u);
+            heston_qe_step(qc, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
         } else {
             heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
         }
@@ -208,7 +207,9 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
     if (p >= n) return;
     double xv = x[p], v = var[p], q = qvar[p];
     const double *const w[3] = {Z0 + p, Z1 + p, U + p};
-    streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) { heston_qe_step(qc, xv, v, q, z[0], z[1], z[2]); });
+    streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) {
+        heston_qe_step(qc, xv, v, q, z[0], z[1], [&]() { return z[2]; });
+    });
     x[p] = xv;
     var[p] = v;
     qvar[p] = q;

@@ -157,7 +157,7 @@ SVMC_HD double exp_fast(double x)
     return ldexp(y, static_cast<int>(n));
 }
 
-// -ln(u) for u in (0,1), normal.  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,
+// -ln(u) for any positive normal u (the RNG calls it on (0,1); Heston QE on arguments around 1).  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,
 // f = m - 1, s = f/(2+f), ln(1+f) = f - (f^2/2 - s (f^2/2 + R)), R = s^2 G(s^2)   (Cody-Waite / fdlibm form)
 SVMC_HD double neg_log(double u)
 {

@@ -159,29 +159,34 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     return c;
 }
 
+// z0 drives the log-price, z1 the quadratic branch; the uniform of the exponential branch is drawn lazily
+// (draw_u() is only evaluated by waves that have a lane in that branch).  Divides are reciprocal + Newton
+// (<= 1 ULP), log/sqrt are svmc_math.h's; the arithmetic order is the CPU twin's.
+template <class DrawU>
 __device__ __forceinline__ void heston_qe_step(const QeConsts &c, double &x, double &var, double &qvar,
-                                               double z0, double z1, double u)
+                                               double z0, double z1, DrawU &&draw_u)
 {
     const double v0 = var;
     const double m = c.theta + (v0 - c.theta) * c.E;
     const double s2 = v0 * c.c1 + c.c2;
-    const double psi = s2 / (m * m);
+    const double psi = s2 * rcp_fast(m * m);
     double v1, K0;
     if (psi <= 1.5) {
-        const double ip = 2.0 / psi;
-        const double b2 = ip - 1.0 + sqrt(ip * (ip - 1.0));
-        const double a = m / (1.0 + b2);
-        const double b = sqrt(b2);
+        const double ip = 2.0 * rcp_fast(psi);
+        const double b2 = ip - 1.0 + sqrt_pos0(ip * (ip - 1.0));
+        const double a = m * rcp_fast(1.0 + b2);
+        const double b = sqrt_pos0(b2);
         const double den = 1.0 - 2.0 * c.A * a;
         v1 = a * (b + z1) * (b + z1);
-        K0 = (den > 0.0) ? (-c.A * b2 * a / den + 0.5 * log(den) - c.K13 * v0) : c.K0_plain;
+        K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_fast(den) - 0.5 * neg_log(den) - c.K13 * v0) : c.K0_plain;
     } else {
-        const double p = (psi - 1.0) / (psi + 1.0);
-        const double bt = (1.0 - p) / m;
-        v1 = (u <= p) ? 0.0 : log((1.0 - p) / (1.0 - u)) / bt;
-        K0 = (c.A < bt) ? (-log(p + bt * (1.0 - p) / (bt - c.A)) - c.K13 * v0) : c.K0_plain;
+        const double u = draw_u();
+        const double p = (psi - 1.0) * rcp_fast(psi + 1.0);
+        const double bt = (1.0 - p) * rcp_fast(m);
+        v1 = (u <= p) ? 0.0 : -neg_log((1.0 - p) * rcp_fast(1.0 - u)) * rcp_fast(bt);
+        K0 = (c.A < bt) ? (neg_log(p + bt * (1.0 - p) * rcp_fast(bt - c.A)) - c.K13 * v0) : c.K0_plain;
     }
-    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt(c.K3 * v0 + c.K4 * v1) * z0;
+    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0(c.K3 * v0 + c.K4 * v1) * z0;
     qvar = qvar + 0.5 * c.dt * (v0 + v1);
     var = v1;
 }

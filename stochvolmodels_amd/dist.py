@@ -102,14 +102,16 @@ def init_from_env(backend: Optional[str] = None):
     import torch.distributed as dist
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
+        # SVMC_DIST_BACKEND=gloo lets several ranks share one GPU (tests on a 1-GPU box); RCCL is the default
+        backend = os.environ.get("SVMC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        device = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(device)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
     set_default_comm(TorchComm())

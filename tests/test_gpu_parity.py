@@ -409,3 +409,28 @@ def test_config_c2_full_size_properties(sv, golden):
     otm_sd = np.where(kk >= 1.0, sd[0][:21], sd[0][21:])
     ref = g["logsv_btc_prices"][3]                                       # ttm = 1.0 slice of the analytic chain
     assert np.all(np.abs(otm - ref) <= 4.0 * otm_sd + 0.01 * ref), np.abs(otm - ref) / otm_sd
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_share_one_gpu(oracle, tmp_path, world):
+    """the multi-process path on real kernels: `world` ranks (gloo, all on this GPU) shard one path set through
+    the product drivers; every rank must return the single-process oracle result (tests/test_dist_gloo.py does
+    the same on CPU with an engine double)."""
+    import os
+    import subprocess
+    import sys
+    from test_dist_gloo import _expected
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29711 + world), WORLD_SIZE=str(world),
+               SVMC_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_dist_worker.py"), out],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    exp = _expected(oracle)
+    for r in range(world):
+        got = np.load(out + f".rank{r}.npz")
+        for key in got.files:
+            np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} rank {r}/{world}")
