@@ -117,6 +117,17 @@ SVMC_API int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
                           size_t ldw, svmc_stream_t stream);
 
+/* ---- LogSV volatility paths on the full time grid: simulate_vol_paths, pricers/logsv_pricer.py:870-947 ---
+ * sigma_t[(t+1)*ld + p] for t = 0..nb_steps-1, row 0 = v0 (written too): an explicit Euler scheme on L = ln sigma
+ * driven by ONE Brownian motion with volatility vartheta = sqrt(beta^2 + volvol^2) (:937-945).  `brownians` are
+ * the reference's SCALED increments sqrt(dt)*N(0,1), [nb_steps][ldb]; NULL draws them on device (stream 2 of the
+ * counter-based generator: step t uses component t&1 of the Box-Muller pair of counter step t>>1).
+ * HBM-write-bound: 8 B per path-step (+8 B read when brownians are supplied). */
+SVMC_API int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0,
+                                  double theta, double kappa1, double kappa2, double beta, double volvol,
+                                  int is_spot_measure, const double *brownians, size_t ldb, uint64_t seed,
+                                  uint32_t call_id, uint64_t path_offset, svmc_stream_t stream);
+
 /* ---- Heston generator: simulate_heston_x_vol_terminal, pricers/heston_pricer.py:334-381 ----------
  * `var` is the variance (the reference returns variance, not vol).  scheme = SVMC_HESTON_EULER_FLOOR
  * reproduces the reference (Euler, floor max(v, 1e-4)); SVMC_HESTON_QE is Andersen's QE-M. */

@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
                                              u64, u32, u64, u32]
         L.svo_heston_terminal_rng.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, i32,
                                               u64, u32, u64, u32]
+        L.svo_logsv_vol_paths.argtypes = [_dp, sz, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, _dp, sz, u64, u32, u64]
+        L.svo_logsv_vol_paths.restype = None
         for name in ("svo_set_time_grid", "svo_logsv_terminal_w", "svo_heston_terminal_w",
                      "svo_heston_qe_terminal_w", "svo_philox4x32_10", "svo_fill_normals",
                      "svo_fill_uniforms", "svo_logsv_terminal_rng", "svo_heston_terminal_rng"):
@@ -180,6 +182,18 @@ def heston_terminal_rng(x0, var0, qvar0, nb_steps, dt, theta, kappa, rho, volvol
     lib().svo_heston_terminal_rng(x.size, nb_steps, dt, _p(x), _p(v), _p(q), theta, kappa, rho, volvol,
                                   int(scheme), seed, call_id, path_offset, step_offset)
     return x, v, q
+
+
+def logsv_vol_paths(nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, n_path, is_spot_measure=True,
+                    brownians=None, seed=0, call_id=0, path_offset=0):
+    out = np.empty((nb_steps + 1, n_path))
+    if brownians is not None:
+        brownians = _w(brownians)
+        assert brownians.shape == (nb_steps, n_path)
+    lib().svo_logsv_vol_paths(_p(out), n_path, n_path, nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol,
+                              int(bool(is_spot_measure)), _p(brownians) if brownians is not None else None, n_path,
+                              seed, call_id, path_offset)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

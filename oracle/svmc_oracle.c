@@ -311,12 +311,21 @@ static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, u
     svo_philox4x32_10(ctr, key, r);
 }
 
+static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
+                                double *w0, double *w1);
+
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1)
 {
+    draw_normals_stream(seed, call_id, path, step, 0u, w0, w1);
+}
+
+static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
+                                double *w0, double *w1)
+{
     static const double HALF_PI = 1.57079632679489661923;
     uint32_t r[4];
-    philox_draw(seed, call_id, path, step, 0u, r);
+    philox_draw(seed, call_id, path, step, stream, r);
     double u1 = m52(r[0], r[1]) + 0x1.0p-53;
     double rr = m52(r[2], r[3]) - 0.5;
     double R = sqrt(-2.0 * log(u1));
@@ -394,5 +403,39 @@ void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
             }
         }
         x[p] = xp; var[p] = vp; qvar[p] = qp;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * pricers/logsv_pricer.py:920-947 simulate_vol_paths
+ *   sigma0 = v0 ; L = log(sigma0) ; sigma_t[0] = sigma0
+ *   brownians = sqrt(dt) * N(0,1)   (when not supplied)                          (:925)
+ *   adj = 0 | beta ; vartheta = sqrt(beta^2 + volvol^2)                          (:930-936)
+ *   L = L + ((k1*theta/sigma - k1) + k2*(theta-sigma) + adj*sigma - 0.5*vartheta2)*dt + vartheta*w   (:942)
+ *   sigma = exp(L) ; sigma_t[t+1] = sigma                                        (:943-944)
+ * ---------------------------------------------------------------------------------------------- */
+void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0,
+                         double theta, double kappa1, double kappa2, double beta, double volvol,
+                         int is_spot_measure, const double *brownians, size_t ldb,
+                         uint64_t seed, uint32_t call_id, uint64_t path_offset)
+{
+    double adj = is_spot_measure ? 0.0 : beta;
+    double vartheta2 = beta * beta + volvol * volvol, vartheta = sqrt(vartheta2), sdt = sqrt(dt);
+    double k1theta = kappa1 * theta;
+    for (size_t p = 0; p < n_path; ++p) {
+        double s = v0, L = log(v0), z0 = 0.0, z1 = 0.0;
+        sigma_t[p] = s;
+        for (int t = 0; t < nb_steps; ++t) {
+            double w;
+            if (brownians) {
+                w = brownians[(size_t)t * ldb + p];
+            } else {
+                if ((t & 1) == 0) draw_normals_stream(seed, call_id, path_offset + p, (uint32_t)(t >> 1), 2u, &z0, &z1);
+                w = sdt * ((t & 1) ? z1 : z0);
+            }
+            L = (L + ((((k1theta / s) - kappa1) + kappa2 * (theta - s)) + adj * s - 0.5 * vartheta2) * dt) + vartheta * w;
+            s = exp(L);
+            sigma_t[(size_t)(t + 1) * ld + p] = s;
+        }
     }
 }

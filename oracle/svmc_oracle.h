@@ -91,6 +91,13 @@ void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
                              double theta, double kappa, double rho, double volvol, int scheme,
                              uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset);
 
+/* pricers/logsv_pricer.py:870-947 simulate_vol_paths.  brownians: SCALED increments [nb_steps][ldb], or NULL for
+ * the counter-based draw (stream 2: step t uses component t&1 of the pair of counter step t>>1). */
+void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0,
+                         double theta, double kappa1, double kappa2, double beta, double volvol,
+                         int is_spot_measure, const double *brownians, size_t ldb,
+                         uint64_t seed, uint32_t call_id, uint64_t path_offset);
+
 #ifdef __cplusplus
 }
 #endif

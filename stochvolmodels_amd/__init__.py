@@ -29,6 +29,7 @@ _EXPORTS = {
     "logsv_mc_chain_pricer": "pricers.logsv_pricer",
     "logsv_mc_chain_pricer_fixed_randoms": "pricers.logsv_pricer",
     "simulate_logsv_x_vol_terminal": "pricers.logsv_pricer",
+    "simulate_vol_paths": "pricers.logsv_pricer",
     "get_randoms_for_chain_valuation": "pricers.logsv_pricer",
     "HestonPricer": "pricers.heston_pricer", "HestonParams": "pricers.heston_pricer",
     "BTC_HESTON_PARAMS": "pricers.heston_pricer", "heston_mc_chain_pricer": "pricers.heston_pricer",

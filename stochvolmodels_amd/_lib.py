@@ -54,6 +54,7 @@ def _declare(L: C.CDLL) -> None:
         "svmc_logsv_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
                                      vp], i32),
         "svmc_logsv_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, vp, vp, sz, vp], i32),
+        "svmc_logsv_vol_paths": ([vp, sz, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, vp, sz, u64, u32, u64, vp], i32),
         "svmc_heston_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp], i32),
         "svmc_heston_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, vp, vp, sz, vp], i32),
         "svmc_heston_qe_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, vp, vp, vp, sz, vp], i32),

@@ -151,6 +151,37 @@ __global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, 
     qvar[p] = q;
 }
 
+// Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
+template <bool RNG>
+__global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n,
+                                                                int nb_steps, double dt, double v0, double k1theta,
+                                                                double kappa1, double kappa2, double theta, double adj,
+                                                                double half_vartheta2, double vartheta,
+                                                                const double *__restrict__ brownians, size_t ldb,
+                                                                uint64_t seed, uint32_t c3, uint64_t path_offset)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double s = v0, L = log(v0);
+    sigma_t[p] = s;                                                                             // :937
+    const double sdt = sqrt(dt);
+    const uint64_t gp = path_offset + p;
+    double z0 = 0.0, z1 = 0.0;
+    for (int t = 0; t < nb_steps; ++t) {
+        double w;
+        if (RNG) {
+            if ((t & 1) == 0) draw_normals(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 1), z0, z1);
+            w = sdt * ((t & 1) ? z1 : z0);                                                      // :925
+        } else {
+            w = brownians[static_cast<size_t>(t) * ldb + p];
+        }
+        const double drift = ((((k1theta * rcp_fast(s)) - kappa1) + kappa2 * (theta - s)) + adj * s) - half_vartheta2;
+        L = (L + drift * dt) + vartheta * w;                                                    // :942
+        s = exp_fast(L);                                                                        // :943
+        sigma_t[static_cast<size_t>(t + 1) * ld + p] = s;                                       // :944
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Heston generators (pricers/heston_pricer.py:334-381; QE is new)
 // ---------------------------------------------------------------------------------------------------
@@ -419,6 +450,29 @@ int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path,
     hipLaunchKernelGGL(logsv_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
                        n_path, nb_steps, c, W0, W1, ldw);
     return check_launch("svmc_logsv_terminal_w");
+}
+
+int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0, double theta,
+                         double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
+                         const double *brownians, size_t ldb, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                         svmc_stream_t stream)
+{
+    SVMC_REQUIRE(sigma_t != nullptr, "svmc_logsv_vol_paths: null output");
+    SVMC_REQUIRE(nb_steps >= 0 && dt > 0.0 && ld >= n_path, "svmc_logsv_vol_paths: bad nb_steps/dt/ld");
+    SVMC_REQUIRE(brownians == nullptr || ldb >= n_path, "svmc_logsv_vol_paths: ldb < n_path");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_vol_paths: call_id must fit 24 bits");
+    if (n_path == 0) return SVMC_OK;
+    const double adj = is_spot_measure ? 0.0 : beta;                                            // :930-933
+    const double vartheta2 = beta * beta + volvol * volvol;
+    if (brownians != nullptr)
+        hipLaunchKernelGGL(logsv_vol_paths_kernel<false>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
+                           sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
+                           0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
+    else
+        hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
+                           sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
+                           0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
+    return check_launch("svmc_logsv_vol_paths");
 }
 
 int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,

@@ -232,6 +232,21 @@ class HipEngine:
             float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
             w0_ptr, w1_ptr, self.n_path if ldw is None else int(ldw), self.stream)))
 
+    def logsv_vol_paths(self, nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                        brownians: Optional[np.ndarray] = None) -> np.ndarray:
+        """full-grid sigma paths [(nb_steps+1), n_path] (svmc_logsv_vol_paths); returns the host array."""
+        out = DeviceBuffer((nb_steps + 1) * self.n_path)
+        b_ptr = None
+        if brownians is not None:
+            (b_ptr,) = self.upload_randoms((brownians,))
+        _lib.check(self.lib.svmc_logsv_vol_paths(out.ptr, self.n_path, self.n_path, int(nb_steps), float(dt), float(v0),
+                                                 float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
+                                                 int(bool(is_spot_measure)), b_ptr, self.n_path, int(seed),
+                                                 int(call_id), self.path_offset, self.stream))
+        host = self.download(out.ptr, (nb_steps + 1) * self.n_path).reshape(nb_steps + 1, self.n_path)
+        out.free()
+        return host
+
     def heston_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset) -> None:
         self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_terminal_rng(
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),

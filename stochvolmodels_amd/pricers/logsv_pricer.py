@@ -49,6 +49,18 @@ class LogSVPricer(ModelPricer):
                                      seed=kwargs.get("seed"), comm=kwargs.get("comm"))
 
     @timer
+    def simulate_vol_paths(self, params: LogSvParams, brownians: np.ndarray = None, ttm: float = 1.0,
+                           nb_path: int = 100000, is_spot_measure: bool = True, nb_steps: int = None,
+                           year_days: int = 360, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        """volatility paths on the time grid (reference :560-587).  As in the reference, `nb_steps` (default
+        ceil(year_days*ttm)) is handed on as steps PER YEAR."""
+        nb_steps = nb_steps or int(np.ceil(year_days * ttm))
+        return simulate_vol_paths(ttm=ttm, v0=params.sigma0, theta=params.theta, kappa1=params.kappa1,
+                                  kappa2=params.kappa2, beta=params.beta, volvol=params.volvol, nb_path=nb_path,
+                                  is_spot_measure=is_spot_measure, nb_steps_per_year=nb_steps, brownians=brownians,
+                                  **kwargs)
+
+    @timer
     def simulate_terminal_values(self, params: LogSvParams, ttm: float = 1.0, nb_path: int = 100000,
                                  is_spot_measure: bool = True, **kwargs
                                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -104,6 +116,24 @@ def simulate_logsv_x_vol_terminal(ttm: float, x0: np.ndarray, sigma0: np.ndarray
         w0, w1 = eng.upload_randoms((W0, W1))
         eng.logsv_w(W0.shape[0], dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure, w0, w1)
     return eng.get_state()
+
+
+def simulate_vol_paths(ttm: float, v0: float, theta: float, kappa1: float, kappa2: float, beta: float, volvol: float,
+                       is_spot_measure: bool = True, nb_path: int = 100000, nb_steps_per_year: int = 360,
+                       brownians: np.ndarray = None, seed: Optional[int] = None, **kwargs
+                       ) -> Tuple[np.ndarray, np.ndarray]:
+    """sigma_t of shape (nb_steps + 1, nb_path), first row = v0, and the time grid (reference :870-947).
+    `brownians` are the reference's SCALED increments sqrt(dt)*N(0,1), shape (nb_steps, nb_path)."""
+    nb_steps, dt, grid_t = set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
+    if brownians is not None:
+        brownians = np.asarray(brownians)
+        if brownians.shape != (nb_steps, nb_path):
+            raise ValueError("brownians must have shape (nb_steps, nb_path)")
+    rng_seed, call_id = next_rng_call(seed)
+    eng = get_engine(nb_path)
+    sigma_t = eng.logsv_vol_paths(nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, rng_seed,
+                                  call_id, brownians=brownians)
+    return sigma_t, grid_t
 
 
 def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,

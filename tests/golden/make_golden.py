@@ -175,6 +175,24 @@ def g_logsv_reference_test_case():
          expected_qvar=compute_analytic_qvar(TEST, ttm=ttm, n_terms=8))
 
 
+# -- f.2: simulate_vol_paths (pricers/logsv_pricer.py:870-947) --------------------------------------
+def g_vol_paths():
+    rng = np.random.default_rng(17)
+    n, ttm, spy = 64, 0.1, 250
+    nb, dt, grid = set_time_grid(ttm=ttm, nb_steps_per_year=spy)
+    br = np.sqrt(dt) * rng.standard_normal((nb, n))
+    out = dict(brownians=br, ttm=ttm, spy=spy, n_path=n, grid=grid, params=params_vec(BTC))
+    for tag, spot in (("spot", True), ("inv", False)):
+        sig, g = lp.simulate_vol_paths(ttm=ttm, v0=BTC.sigma0, nb_path=n, nb_steps_per_year=spy, brownians=br,
+                                       is_spot_measure=spot, **logsv_kwargs(BTC))
+        out[f"sigma_{tag}"] = sig
+    # the reference's own test inputs (tests/test_logsv_characterization.py:638-673): zero brownians (8, 4)
+    sig0, g0 = lp.simulate_vol_paths(ttm=0.02, v0=TEST.sigma0, nb_path=4, nb_steps_per_year=360,
+                                     brownians=np.zeros((8, 4)), is_spot_measure=True, **logsv_kwargs(TEST))
+    out["test_sigma_zero"], out["test_grid"], out["test_params"] = sig0, g0, params_vec(TEST)
+    save("vol_paths", **out)
+
+
 # -- a6 ------------------------------------------------------------------------------------------
 def g_heston():
     # (i) survey anchor: global NumPy RNG, w0 drawn first then w1 (heston_pricer.py:369-370)
@@ -328,6 +346,7 @@ if __name__ == "__main__":
     g_logsv_tiny_chain()
     g_logsv_chain_philox()
     g_logsv_reference_test_case()
+    g_vol_paths()
     g_heston()
     g_payoff()
     g_analytic()

@@ -434,3 +434,32 @@ def test_ranks_share_one_gpu(oracle, tmp_path, world):
         got = np.load(out + f".rank{r}.npz")
         for key in got.files:
             np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} rank {r}/{world}")
+
+
+def test_vol_paths(sv, oracle, golden):
+    """simulate_vol_paths: reference outputs on supplied brownians; on-device draw vs the CPU twin; the reference's
+    own shape / first-row / measure checks (tests/test_logsv_characterization.py:638-673)"""
+    g = golden("vol_paths")
+    p = P(g["params"])
+    for tag, spot in (("spot", True), ("inv", False)):
+        sig, grid = sv.simulate_vol_paths(ttm=float(g["ttm"]), nb_path=int(g["n_path"]), nb_steps_per_year=int(g["spy"]),
+                                          brownians=g["brownians"], is_spot_measure=spot, **p)
+        np.testing.assert_allclose(sig, g[f"sigma_{tag}"], rtol=1e-11)
+        np.testing.assert_array_equal(grid, g["grid"])
+    t = P(g["test_params"])
+    pricer = sv.LogSVPricer()
+    params = sv.LogSvParams(sigma0=t["v0"], theta=t["theta"], kappa1=t["kappa1"], kappa2=t["kappa2"], beta=t["beta"],
+                            volvol=t["volvol"])
+    spot_paths, grid = sv.simulate_vol_paths(ttm=0.02, nb_path=4, nb_steps_per_year=360, brownians=np.zeros((8, 4)), **t)
+    inv_paths, _ = sv.simulate_vol_paths(ttm=0.02, nb_path=4, nb_steps_per_year=360, brownians=np.zeros((8, 4)),
+                                         is_spot_measure=False, **t)
+    assert spot_paths.shape == inv_paths.shape == (9, 4)
+    np.testing.assert_allclose(spot_paths, g["test_sigma_zero"], rtol=1e-12)
+    np.testing.assert_array_equal(spot_paths[0], t["v0"])
+    assert np.all(spot_paths > 0) and not np.array_equal(spot_paths[-1], inv_paths[-1])
+    sig, grid = pricer.simulate_vol_paths(params, ttm=0.05, nb_path=1000, seed=12)        # nb_steps -> ceil(360*0.05) = 18 /yr
+    nb, dt, _ = sv.set_time_grid(0.05, 18)
+    osig = oracle.logsv_vol_paths(nb, dt, t["v0"], t["theta"], t["kappa1"], t["kappa2"], t["beta"], t["volvol"], 1000,
+                                  seed=12)
+    assert sig.shape == (nb + 1, 1000)
+    np.testing.assert_allclose(sig, osig, rtol=1e-11)

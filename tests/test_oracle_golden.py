@@ -217,3 +217,23 @@ def test_heston_qe_matches_analytic(oracle, golden):
             assert np.all(np.abs(pr - g[f"heston_{tag}_prices"][i]) <= 4.0 * sd + 2e-4), (tag, i)
             assert abs(np.mean(np.exp(x)) - 1.0) <= 4 * np.std(np.exp(x)) / np.sqrt(n)
         assert v.min() >= 0.0
+
+
+def test_vol_paths(oracle, golden):
+    """simulate_vol_paths (pricers/logsv_pricer.py:870-947) restated: supplied scaled brownians, both measures"""
+    g = golden("vol_paths")
+    p = P(g["params"])
+    nb, dt = oracle.set_time_grid(float(g["ttm"]), int(g["spy"]))
+    assert nb == g["brownians"].shape[0] and g["grid"].shape == (nb + 1,)
+    for tag, spot in (("spot", True), ("inv", False)):
+        sig = oracle.logsv_vol_paths(nb, dt, p["sigma0"], p["theta"], p["kappa1"], p["kappa2"], p["beta"],
+                                     p["volvol"], int(g["n_path"]), is_spot_measure=spot, brownians=g["brownians"])
+        np.testing.assert_allclose(sig, g[f"sigma_{tag}"], rtol=RT)
+    t = P(g["test_params"])
+    sig = oracle.logsv_vol_paths(8, 0.0025, t["sigma0"], t["theta"], t["kappa1"], t["kappa2"], t["beta"], t["volvol"], 4,
+                                 brownians=np.zeros((8, 4)))
+    np.testing.assert_allclose(sig, g["test_sigma_zero"], rtol=RT)
+    # counter-based draw: step t uses component t&1 of the pair of counter step t>>1, stream 2 != stream 0
+    sig = oracle.logsv_vol_paths(6, 0.01, 0.5, 1.0, 2.0, 2.0, 0.1, 1.0, 16, seed=5)
+    assert sig.shape == (7, 16) and np.all(sig[0] == 0.5) and np.all(sig > 0)
+    assert len(np.unique(sig[1])) == 16
