@@ -112,6 +112,16 @@ SVMC_API int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, siz
                             double theta, double kappa1, double kappa2, double beta, double volvol,
                             double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
                             uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream);
+/* Fused slice op for chain pricing: advance the state like svmc_logsv_terminal_rng AND, in the same kernel, copy
+ * the terminal x (and qvar when qvar_snapshot != NULL) to the per-expiry snapshots and reduce
+ * spot_sums[0..1] = { sum over non-NaN of forward*exp(x), count } (utils/mc_payoffs.py:61-62; the first step of
+ * compute_mc_vars_payoff, see the payoff section below).  workspace >= svmc_slice_workspace_bytes(n_path). */
+SVMC_API int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                                  double theta, double kappa1, double kappa2, double beta, double volvol,
+                                  double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                                  uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
+                                  double *qvar_snapshot, double *spot_sums, void *workspace,
+                                  size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
                           double theta, double kappa1, double kappa2, double beta, double volvol,
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
@@ -135,6 +145,11 @@ SVMC_API int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size
                              double theta, double kappa, double rho, double volvol, int scheme,
                              uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
                              svmc_stream_t stream);
+SVMC_API int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                                   double theta, double kappa, double rho, double volvol, int scheme,
+                                   uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
+                                   double forward, double *x_snapshot, double *qvar_snapshot, double *spot_sums,
+                                   void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
                            double theta, double kappa, double rho, double volvol, const double *W0,
                            const double *W1, size_t ldw, svmc_stream_t stream);
@@ -155,6 +170,7 @@ SVMC_API int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, siz
  * the intrinsic value at the forward); they only remove the cancellation in E[p^2] - E[p]^2.
  * `workspace` is a device scratch buffer of at least svmc_payoff_workspace_bytes() bytes. */
 SVMC_API int svmc_payoff_workspace_bytes(size_t *bytes);
+SVMC_API int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes); /* covers the fused slice ops too */
 SVMC_API int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_sums, void *workspace,
                    size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double forward, double ttm,

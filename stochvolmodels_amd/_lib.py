@@ -53,12 +53,17 @@ def _declare(L: C.CDLL) -> None:
         "svmc_fill_uniforms": ([vp, sz, sz, i32, u64, u32, u64, u32, vp], i32),
         "svmc_logsv_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
                                      vp], i32),
+        "svmc_logsv_slice_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
+                                  f64, vp, vp, vp, vp, sz, vp], i32),
         "svmc_logsv_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, vp, vp, sz, vp], i32),
         "svmc_logsv_vol_paths": ([vp, sz, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, vp, sz, u64, u32, u64, vp], i32),
         "svmc_heston_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp], i32),
+        "svmc_heston_slice_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
+                                   f64, vp, vp, vp, vp, sz, vp], i32),
         "svmc_heston_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, vp, vp, sz, vp], i32),
         "svmc_heston_qe_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, vp, vp, vp, sz, vp], i32),
         "svmc_payoff_workspace_bytes": ([psz], i32),
+        "svmc_slice_workspace_bytes": ([sz, psz], i32),
         "svmc_spot_sums": ([vp, sz, f64, vp, vp, sz, vp], i32),
         "svmc_payoff_sums": ([vp, vp, sz, f64, f64, vp, pf64, pi8, pf64, sz, i32, vp, vp, sz, vp], i32),
         "svmc_payoff_finalize": ([pf64, pf64, sz, f64, f64, pf64, pf64], i32),

@@ -11,9 +11,10 @@
 
 namespace svmc {
 
-constexpr int BLOCK = 256;           // 4 waves of 64 lanes
-constexpr int MAX_REDUCE_GRID = 2048;  // 256 CUs x 8 blocks: cap for grid-stride reductions
-constexpr int KC = 16;                 // strikes per payoff launch (register accumulators)
+constexpr int BLOCK = 256;             // 4 waves of 64 lanes
+constexpr int MAX_REDUCE_GRID = 1024;  // 256 CUs x 4 blocks: cap for grid-stride reductions
+constexpr int KC = 8;                  // strikes per payoff block (register accumulators: 3 doubles per strike)
+constexpr int KMAX = 32;               // strikes per payoff launch (grid.y = ceil(k / KC) chunks)
 
 static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
 
@@ -58,27 +59,87 @@ __global__ __launch_bounds__(BLOCK) void fill_uniforms_kernel(double *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Deterministic block reductions: wave shuffles in a fixed tree, one LDS exchange, ONE barrier for any number of
+// values (the first version paid two barriers per value: 96 per payoff block).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// every thread of the block calls; thread j < NV ends up writing the block total of v[j] to out[j]
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * NV] */, double *out, int n_out)
+{
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) lds[wave * NV + j] = v[j];
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < n_out) {
+        const int j = threadIdx.x;
+        out[j] = ((lds[j] + lds[NV + j]) + lds[2 * NV + j]) + lds[3 * NV + j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LogSV generators (pricers/logsv_pricer.py:950-1047)
 // ---------------------------------------------------------------------------------------------------
+// Optional slice epilogue fused into the stepping kernels: the terminal x (and qvar) is also written to the
+// per-expiry snapshot the payoff pass reads, and the block's [sum F*exp(x), count] goes to partials[block][2]
+// (utils/mc_payoffs.py:61-62) -- one launch and one pass over x less per expiry.
+struct SliceOut {
+    double *x_snap;     // nullable
+    double *q_snap;     // nullable
+    double *partials;   // nullable: [gridDim.x][2]
+    double forward;
+};
+
+__device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, bool active, double xv, double q)
+{
+    __shared__ double lds[8];
+    if (active) {
+        if (so.x_snap != nullptr) so.x_snap[p] = xv;
+        if (so.q_snap != nullptr) so.q_snap[p] = q;
+    }
+    if (so.partials != nullptr) {
+        const double sp = so.forward * exp(xv);            // full-range exp: x = +-inf must give inf / 0   :61
+        const bool ok = active && (sp == sp);                                                   // nanmean :62
+        double v[2] = {ok ? sp : 0.0, ok ? 1.0 : 0.0};
+        block_sum_store<2>(v, lds, so.partials + 2 * static_cast<size_t>(blockIdx.x), 2);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
-                                                          uint64_t path_offset, uint32_t step_offset)
+                                                          uint64_t path_offset, uint32_t step_offset, SliceOut so)
 {
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    if (p >= n) return;
-    double xv = x[p], s = sigma[p], q = qvar[p];
-    double L = log(s);                                                                          // :1039
-    double s2 = s * s;
-    const uint64_t gp = path_offset + p;
-    for (int t = 0; t < nb_steps; ++t) {
-        double z0, z1;
-        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), z0, z1);
-        logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
+    const bool active = p < n;
+    double xv = 0.0, s = 1.0, q = 0.0;
+    if (active) {
+        xv = x[p];
+        s = sigma[p];
+        q = qvar[p];
+        double L = log(s);                                                                      // :1039
+        double s2 = s * s;
+        const uint64_t gp = path_offset + p;
+        for (int t = 0; t < nb_steps; ++t) {
+            double z0, z1;
+            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), z0, z1);
+            logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
+        }
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
     }
-    x[p] = xv;
-    sigma[p] = s;
-    qvar[p] = q;
+    slice_epilogue(so, p, active, xv, q);
 }
 
 // Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
@@ -190,25 +251,31 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
                                                            double *__restrict__ qvar, size_t n, int nb_steps,
                                                            HestonConsts c, QeConsts qc, uint64_t seed,
                                                            uint32_t c3, uint64_t path_offset,
-                                                           uint32_t step_offset)
+                                                           uint32_t step_offset, SliceOut so)
 {
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    if (p >= n) return;
-    double xv = x[p], v = var[p], q = qvar[p];
-    const uint64_t gp = path_offset + p;
-    for (int t = 0; t < nb_steps; ++t) {
-        const uint32_t step = step_offset + static_cast<uint32_t>(t);
-        double w0, w1;
-        draw_normals(seed, c3, gp, step, w0, w1);
-        if (SCHEME == SVMC_HESTON_QE) {
-            heston_qe_step(qc, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
-        } else {
-            heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+    const bool active = p < n;
+    double xv = 0.0, v = 1.0, q = 0.0;
+    if (active) {
+        xv = x[p];
+        v = var[p];
+        q = qvar[p];
+        const uint64_t gp = path_offset + p;
+        for (int t = 0; t < nb_steps; ++t) {
+            const uint32_t step = step_offset + static_cast<uint32_t>(t);
+            double w0, w1;
+            draw_normals(seed, c3, gp, step, w0, w1);
+            if (SCHEME == SVMC_HESTON_QE) {
+                heston_qe_step(qc, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
+            } else {
+                heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+            }
         }
+        x[p] = xv;
+        var[p] = v;
+        qvar[p] = q;
     }
-    x[p] = xv;
-    var[p] = v;
-    qvar[p] = q;
+    slice_epilogue(so, p, active, xv, q);
 }
 
 __global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x, double *__restrict__ var,
@@ -251,100 +318,68 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
 // fixed tree order, then one block per output column adds the partials -- no fp64 atomics, so a given
 // (n_path, grid) always reproduces the same bits.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// all threads must call; result valid in thread 0
-__device__ __forceinline__ double block_sum(double v, double *lds4)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) lds4[wave] = v;
-    __syncthreads();
-    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
-}
-
 __global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restrict__ x, size_t n, double forward,
                                                           double *__restrict__ partials)
 {
-    __shared__ double lds[4];
+    __shared__ double lds[8];
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
-    double s = 0.0, cnt = 0.0;
+    double v[2] = {0.0, 0.0};
     for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
-        const double sp = forward * exp(x[i]);                                                  // :61
+        const double sp = forward * exp(x[i]);             // full-range exp (user data may hold +-inf)     :61
         if (sp == sp) {                                                                         // nanmean :62
-            s += sp;
-            cnt += 1.0;
+            v[0] += sp;
+            v[1] += 1.0;
         }
     }
-    s = block_sum(s, lds);
-    cnt = block_sum(cnt, lds);
-    if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x + 0] = s;
-        partials[2 * blockIdx.x + 1] = cnt;
-    }
+    block_sum_store<2>(v, lds, partials + 2 * static_cast<size_t>(blockIdx.x), 2);
 }
 
-struct PayoffChunk {
-    double strikes[KC];
-    double shifts[KC];  // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
-    int8_t types[KC];
+struct PayoffArgs {
+    double strikes[KMAX];
+    double shifts[KMAX];  // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
+    int8_t types[KMAX];
     int k;
 };
 
+// grid = (path blocks, strike chunks of KC): every block owns KC strikes of a path range, so the per-strike
+// accumulators stay in 48 VGPRs (8 waves/SIMD) and all strikes of a slice run in ONE launch.
 __global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__restrict__ x,
                                                             const double *__restrict__ qvar, size_t n,
                                                             double forward, double ttm,
                                                             const double *__restrict__ spot_sums,
-                                                            PayoffChunk ch, int variable_type,
+                                                            PayoffArgs pa, int variable_type,
                                                             double *__restrict__ partials)
 {
-    __shared__ double lds[4];
+    __shared__ double lds[4 * 3 * KC];
+    const int k0 = blockIdx.y * KC;
     const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
-    double sum[KC], sq[KC], cnt[KC];
+    double acc[3 * KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) sum[k] = sq[k] = cnt[k] = 0.0;
+    for (int j = 0; j < 3 * KC; ++j) acc[j] = 0.0;
 
     for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
         const double spot = forward * exp(x[i]) - corr;                                         // :61-63
         const double u = (variable_type == SVMC_LOG_RETURN) ? spot : qvar[i] / ttm;             // :65-68
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
-            if (k < ch.k) {
-                const double K = ch.strikes[k];
-                const int ty = ch.types[k];
+            if (k0 + k < pa.k) {
+                const double K = pa.strikes[k0 + k];
+                const int ty = pa.types[k0 + k];
                 double pay = (ty == SVMC_CALL || ty == SVMC_INV_CALL) ? ((u > K) ? (u - K) : 0.0)   // :75-78
                                                                       : ((u < K) ? (K - u) : 0.0);  // :79-82
                 if (ty == SVMC_INV_CALL || ty == SVMC_INV_PUT) pay = pay / spot;
                 if (pay == pay) {                                                               // nanmean/nanstd
-                    const double d = pay - ch.shifts[k];
-                    sum[k] += d;
-                    sq[k] = fma(d, d, sq[k]);
-                    cnt[k] += 1.0;
+                    const double d = pay - pa.shifts[k0 + k];
+                    acc[3 * k + 0] += d;
+                    acc[3 * k + 1] = fma(d, d, acc[3 * k + 1]);
+                    acc[3 * k + 2] += 1.0;
                 }
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-        if (k < ch.k) {
-            const double a = block_sum(sum[k], lds);
-            const double b = block_sum(sq[k], lds);
-            const double c = block_sum(cnt[k], lds);
-            if (threadIdx.x == 0) {
-                double *row = partials + static_cast<size_t>(blockIdx.x) * (3 * KC) + 3 * k;
-                row[0] = a;
-                row[1] = b;
-                row[2] = c;
-            }
-        }
-    }
+    const int n_out = 3 * ((pa.k - k0 < KC) ? (pa.k - k0) : KC);
+    block_sum_store<3 * KC>(acc, lds, partials + static_cast<size_t>(blockIdx.x) * (3 * KMAX) + 3 * k0, n_out);
 }
 
 // out[j] = sum_r partials[r * ld + j]; one block per column j
@@ -353,10 +388,9 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
 {
     __shared__ double lds[4];
     const int j = blockIdx.x;
-    double s = 0.0;
-    for (int r = threadIdx.x; r < n_rows; r += BLOCK) s += partials[static_cast<size_t>(r) * ld + j];
-    s = block_sum(s, lds);
-    if (threadIdx.x == 0) out[j] = s;
+    double v[1] = {0.0};
+    for (int r = threadIdx.x; r < n_rows; r += BLOCK) v[0] += partials[static_cast<size_t>(r) * ld + j];
+    block_sum_store<1>(v, lds, out + j, 1);
 }
 
 static inline unsigned reduce_grid(size_t n)
@@ -422,19 +456,66 @@ int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint6
     return check_launch("svmc_fill_uniforms");
 }
 
+static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps,
+                            double dt, double theta, double kappa1, double kappa2, double beta, double volvol,
+                            double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                            uint64_t path_offset, uint32_t step_offset, const SliceOut &so, svmc_stream_t stream)
+{
+    if (int rc = check_state(fn, x, sigma, qvar, nb_steps, dt)) return rc;
+    if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
+    if (n_path == 0) return SVMC_OK;
+    const LogsvFast c = make_logsv_fast(
+        make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure));
+    hipLaunchKernelGGL(logsv_rng_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
+                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
+    return check_launch(fn);
+}
+
+// the [grid][2] spot partials of a fused slice kernel -> spot_sums[2]
+static int finish_slice_sums(const char *fn, size_t n_path, double *spot_sums, void *workspace, size_t workspace_bytes,
+                             svmc_stream_t stream)
+{
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
+                       static_cast<const double *>(workspace), static_cast<int>(grid_for(n_path)), 2, spot_sums);
+    (void)workspace_bytes;
+    return check_launch(fn);
+}
+
+static int check_slice_args(const char *fn, size_t n_path, const double *x_snapshot, const double *spot_sums,
+                            const void *workspace, size_t workspace_bytes)
+{
+    if (x_snapshot == nullptr || spot_sums == nullptr || workspace == nullptr)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot / spot_sums / workspace");
+    if (workspace_bytes < static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
+    return SVMC_OK;
+}
+
 int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
                             double theta, double kappa1, double kappa2, double beta, double volvol,
                             double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
                             uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
 {
-    if (int rc = check_state("svmc_logsv_terminal_rng", x, sigma, qvar, nb_steps, dt)) return rc;
-    SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_terminal_rng: call_id must fit 24 bits");
-    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
-    const LogsvFast c = make_logsv_fast(
-        make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure));
-    hipLaunchKernelGGL(logsv_rng_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset);
-    return check_launch("svmc_logsv_terminal_rng");
+    const SliceOut none = {nullptr, nullptr, nullptr, 0.0};
+    return logsv_rng_launch("svmc_logsv_terminal_rng", x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta,
+                            volvol, vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, none,
+                            stream);
+}
+
+int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
+                         double kappa1, double kappa2, double beta, double volvol, double vol_backbone_eta,
+                         int is_spot_measure, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                         uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
+                         double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    const char *fn = "svmc_logsv_slice_rng";
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_logsv_slice_rng: n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
+                                  vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream))
+        return rc;
+    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -475,24 +556,52 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
     return check_launch("svmc_logsv_vol_paths");
 }
 
-int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+static int heston_rng_launch(const char *fn, double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
                              double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
-                             uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+                             uint32_t call_id, uint64_t path_offset, uint32_t step_offset, const SliceOut &so,
+                             svmc_stream_t stream)
 {
-    if (int rc = check_state("svmc_heston_terminal_rng", x, var, qvar, nb_steps, dt)) return rc;
-    SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, "svmc_heston_terminal_rng: unknown scheme");
-    SVMC_REQUIRE(call_id < (1u << 24), "svmc_heston_terminal_rng: call_id must fit 24 bits");
-    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
+    if (int rc = check_state(fn, x, var, qvar, nb_steps, dt)) return rc;
+    if (scheme != SVMC_HESTON_EULER_FLOOR && scheme != SVMC_HESTON_QE)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": unknown scheme");
+    if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
+    if (n_path == 0) return SVMC_OK;
     const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
     const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
     if (scheme == SVMC_HESTON_QE)
         hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
-                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset);
+                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so);
     else
         hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(grid_for(n_path)), dim3(BLOCK), 0,
                            as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id),
-                           path_offset, step_offset);
-    return check_launch("svmc_heston_terminal_rng");
+                           path_offset, step_offset, so);
+    return check_launch(fn);
+}
+
+int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
+                             double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
+                             uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream)
+{
+    const SliceOut none = {nullptr, nullptr, nullptr, 0.0};
+    if (nb_steps == 0) return check_state("svmc_heston_terminal_rng", x, var, qvar, nb_steps, dt);
+    return heston_rng_launch("svmc_heston_terminal_rng", x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol,
+                             scheme, seed, call_id, path_offset, step_offset, none, stream);
+}
+
+int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
+                          double kappa, double rho, double volvol, int scheme, uint64_t seed, uint32_t call_id,
+                          uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
+                          double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
+                          svmc_stream_t stream)
+{
+    const char *fn = "svmc_heston_slice_rng";
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_heston_slice_rng: n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
+                                   call_id, path_offset, step_offset, so, stream))
+        return rc;
+    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -526,7 +635,16 @@ int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_pat
 int svmc_payoff_workspace_bytes(size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_payoff_workspace_bytes: null output");
-    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * sizeof(double);
+    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KMAX * sizeof(double);
+    return SVMC_OK;
+}
+
+int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
+{
+    SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
+    const size_t fused = static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double);
+    const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KMAX * sizeof(double);
+    *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;
 }
 
@@ -558,21 +676,22 @@ int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double 
         if (types_host[k] < SVMC_CALL || types_host[k] > SVMC_INV_PUT)
             return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
     const unsigned g = reduce_grid(n_path);
-    if (workspace_bytes < static_cast<size_t>(g) * 3 * KC * sizeof(double))
+    if (workspace_bytes < static_cast<size_t>(g) * 3 * KMAX * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, "svmc_payoff_sums: workspace too small (svmc_payoff_workspace_bytes)");
     double *partials = static_cast<double *>(workspace);
-    for (size_t k0 = 0; k0 < n_strikes; k0 += KC) {
-        PayoffChunk ch;
-        ch.k = static_cast<int>((n_strikes - k0 < static_cast<size_t>(KC)) ? (n_strikes - k0) : KC);
-        for (int k = 0; k < KC; ++k) {
-            ch.strikes[k] = (k < ch.k) ? strikes_host[k0 + k] : 0.0;
-            ch.shifts[k] = (k < ch.k && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
-            ch.types[k] = (k < ch.k) ? types_host[k0 + k] : 0;
+    for (size_t k0 = 0; k0 < n_strikes; k0 += KMAX) {
+        PayoffArgs pa;
+        pa.k = static_cast<int>((n_strikes - k0 < static_cast<size_t>(KMAX)) ? (n_strikes - k0) : KMAX);
+        for (int k = 0; k < KMAX; ++k) {
+            pa.strikes[k] = (k < pa.k) ? strikes_host[k0 + k] : 0.0;
+            pa.shifts[k] = (k < pa.k && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
+            pa.types[k] = (k < pa.k) ? types_host[k0 + k] : 0;
         }
-        hipLaunchKernelGGL(payoff_sums_kernel, dim3(g), dim3(BLOCK), 0, as_stream(stream), x, qvar, n_path, forward,
-                           ttm, spot_sums, ch, variable_type, partials);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * ch.k), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(g), 3 * KC, sums + 3 * k0);
+        const unsigned chunks = static_cast<unsigned>((pa.k + KC - 1) / KC);
+        hipLaunchKernelGGL(payoff_sums_kernel, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar, n_path,
+                           forward, ttm, spot_sums, pa, variable_type, partials);
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * pa.k), dim3(BLOCK), 0, as_stream(stream), partials,
+                           static_cast<int>(g), 3 * KMAX, sums + 3 * k0);
     }
     return check_launch("svmc_payoff_sums");
 }

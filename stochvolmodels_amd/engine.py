@@ -91,7 +91,7 @@ class HipEngine:
         self.vol = DeviceBuffer(self.n_path)
         self.qvar = DeviceBuffer(self.n_path)
         ws = C.c_size_t()
-        _lib.check(self.lib.svmc_payoff_workspace_bytes(C.byref(ws)))
+        _lib.check(self.lib.svmc_slice_workspace_bytes(self.n_path, C.byref(ws)))
         self.ws_bytes = ws.value
         self.ws = DeviceBuffer(self.ws_bytes // 8)
         self._snap: Optional[DeviceBuffer] = None
@@ -224,6 +224,32 @@ class HipEngine:
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
             float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
             int(seed), int(call_id), self.path_offset, int(step_offset), self.stream)))
+
+    def logsv_slice_rng(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
+                        step_offset, forward, snap_row, qvar_row, spot_ptr) -> None:
+        """advance + snapshot + spot sums of one expiry in one kernel (svmc_logsv_slice_rng)"""
+        self._timed("logsv_rng_kernel", lambda: _lib.check(self.lib.svmc_logsv_slice_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
+            int(seed), int(call_id), self.path_offset, int(step_offset), float(forward), self.snapshot_ptr(snap_row),
+            None if qvar_row is None else self.snapshot_ptr(qvar_row), spot_ptr, self.ws.ptr, self.ws_bytes,
+            self.stream)))
+
+    def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
+                         snap_row, qvar_row, spot_ptr) -> None:
+        self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_slice_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa), float(rho), float(volvol), int(scheme), int(seed), int(call_id), self.path_offset,
+            int(step_offset), float(forward), self.snapshot_ptr(snap_row),
+            None if qvar_row is None else self.snapshot_ptr(qvar_row), spot_ptr, self.ws.ptr, self.ws_bytes,
+            self.stream)))
+
+    def finish_slice(self, forward, snap_row, qvar_row, spot_ptr) -> None:
+        """the un-fused equivalent for generators without a slice epilogue (streamed randoms)"""
+        self.snapshot(snap_row, "x")
+        if qvar_row is not None:
+            self.snapshot(qvar_row, "qvar")
+        self.spot_sums(self.snapshot_ptr(snap_row), forward, spot_ptr)
 
     def logsv_w(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0_ptr, w1_ptr,
                 ldw=None) -> None:

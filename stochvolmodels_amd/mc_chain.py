@@ -6,8 +6,8 @@ heston_mc_chain_pricer (reference pricers/logsv_pricer.py:806-867, :1100-1162,
 pricers/heston_pricer.py:285-331): one path set, terminal state carried slice to slice, payoff reduction
 per slice.  Re-ordered for the GPU / multi-GPU case:
 
-  phase 1  for every expiry: advance the resident state (one stepping kernel per slice) and snapshot the
-           terminal x (and qvar for Q_VAR chains) in HBM                      -- no host round trip
+  phase 1  for every expiry ONE kernel: advance the resident state, snapshot the terminal x (and qvar for Q_VAR
+           chains) in HBM and reduce the block partials of [sum F*exp(x), count]  -- no host round trip
   phase 2  per-expiry [sum F*exp(x), count]              -> ONE all-reduce over ranks (2*M doubles)
   phase 3  per-strike [sum d, sum d^2, count]            -> ONE all-reduce over ranks (3*sum K doubles)
   phase 4  D2H of the sums, host finalisation (utils/mc_payoffs.py:85-88)
@@ -35,8 +35,10 @@ def variable_type_code(variable_type) -> int:
 def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, forwards: np.ndarray,
                           discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
                           optiontypes_ttms: Sequence[np.ndarray], variable_type,
-                          advance_slice: Callable[[int], None],
+                          advance_slice: Callable[[int, float, int, object, int], None],
                           finalize: Callable = payoff_finalize) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """advance_slice(i, forward_i, snap_row, qvar_row | None, spot_ptr) must leave the state advanced over slice i,
+    the terminal x (qvar) in snapshot row snap_row (qvar_row) and [sum F*exp(x), count] at spot_ptr."""
     vt = variable_type_code(variable_type)
     m = len(ttms)
     if not (len(forwards) == len(discfactors) == len(strikes_ttms) == len(optiontypes_ttms) == m):
@@ -46,18 +48,13 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     shifts = [payoff_shifts(k, c, float(f), vt) for k, c, f in zip(strikes, codes, forwards)]
     need_q = vt == Q_VAR
 
-    # phase 1: stepping, state resident
+    # phase 1: stepping + snapshot + local spot sums, state resident
     engine.reserve_snapshots(m * (2 if need_q else 1))
-    for i in range(m):
-        advance_slice(i)
-        engine.snapshot(i, "x")
-        if need_q:
-            engine.snapshot(m + i, "qvar")
-
-    # phase 2: forward recentring needs the GLOBAL mean of the terminal spots
     spot_ptr, spot_handle = comm.alloc(engine, 2 * m, "spot")
     for i in range(m):
-        engine.spot_sums(engine.snapshot_ptr(i), float(forwards[i]), spot_ptr + 16 * i)
+        advance_slice(i, float(forwards[i]), i, (m + i) if need_q else None, spot_ptr + 16 * i)
+
+    # phase 2: forward recentring needs the GLOBAL mean of the terminal spots
     comm.all_reduce_sum(engine, spot_handle)
 
     # phase 3: per-strike payoff sums

@@ -116,9 +116,10 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
     step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
     eng.fill_state(0.0, v0, 0.0)
 
-    def advance(i: int) -> None:
+    def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         nb, dt = grids[i]
-        eng.heston_rng(nb, dt, theta, kappa, rho, volvol, code, rng_seed, call_id, int(step0[i]))
+        eng.heston_slice_rng(nb, dt, theta, kappa, rho, volvol, code, rng_seed, call_id, int(step0[i]), forward,
+                             snap_row, qvar_row, spot_ptr)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance)

@@ -156,10 +156,10 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
     step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
     eng.fill_state(0.0, v0, 0.0)
 
-    def advance(i: int) -> None:
+    def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         nb, dt = grids[i]
-        eng.logsv_rng(nb, dt, theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]), is_spot_measure,
-                      rng_seed, call_id, int(step0[i]))
+        eng.logsv_slice_rng(nb, dt, theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]), is_spot_measure,
+                            rng_seed, call_id, int(step0[i]), forward, snap_row, qvar_row, spot_ptr)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance)
@@ -196,13 +196,14 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
     eng = get_engine(n_local, path_offset=offset)
     eng.fill_state(0.0, v0, 0.0)
 
-    def advance(i: int) -> None:
+    def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         W0, W1 = np.asarray(W0s[i]), np.asarray(W1s[i])
         if W0.shape != W1.shape or W0.shape[1] != nb_path:
             raise ValueError("every W0/W1 must have shape [nb_steps_i, nb_path]")
         w0, w1 = eng.upload_randoms((W0, W1), col0=offset)
         eng.logsv_w(W0.shape[0], float(dts[i]), theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]),
                     is_spot_measure, w0, w1)
+        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance)

@@ -69,6 +69,23 @@ class FakeEngine:
             self.x, self.vol, self.qvar, nb_steps, dt, theta, kappa, rho, volvol, seed, scheme=scheme,
             call_id=call_id, path_offset=self.path_offset, step_offset=step_offset)
 
+    def finish_slice(self, forward, snap_row, qvar_row, spot_ptr):
+        self.snapshot(snap_row, "x")
+        if qvar_row is not None:
+            self.snapshot(qvar_row, "qvar")
+        self.spot_sums(self.snapshot_ptr(snap_row), forward, spot_ptr)
+
+    def logsv_slice_rng(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
+                        step_offset, forward, snap_row, qvar_row, spot_ptr):
+        self.logsv_rng(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
+                       step_offset)
+        self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+
+    def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
+                         snap_row, qvar_row, spot_ptr):
+        self.heston_rng(nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset)
+        self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+
     def upload_randoms(self, arrays, col0=0):
         self._rand = [np.ascontiguousarray(np.asarray(a)[:, col0:col0 + self.n_path]) for a in arrays]
         return tuple(range(len(arrays)))
