@@ -180,6 +180,29 @@ SVMC_API int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path
 SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes,
                          double discfactor, double n_path_total, double *prices_host, double *stderrs_host);
 
+/* ---- analytic side: affine-expansion MGF + Fourier inversion ------------------
+ * Complex arrays are interleaved (re, im) doubles, i.e. numpy.complex128 / C99 double complex, on the device.
+ *   svmc_logsv_mgf_grid    compute_logsv_a_mgf_grid, pricers/logsv/affine_expansion.py:570-685 (numerical path):
+ *                          per grid point integrate A' = A^T M A + L A + H (:67-205) over ttm from a[] (in: A at the
+ *                          previous expiry, out: A at this one; [n_grid][5] for expansion_order 2, [n_grid][3] for 1)
+ *                          and return log_mgf = sum_k A_k (sigma0 - theta)^k.  The reference calls SciPy RK45 at its
+ *                          default rtol 1e-3 / atol 1e-6; here the embedded Dormand-Prince pair takes rtol/atol.
+ *   svmc_heston_mgf_grid   compute_heston_mgf_grid, pricers/heston_pricer.py:183-214 (closed form; a, b carried).
+ *   svmc_mgf_vanilla_slice the strike sums of vanilla_slice_pricer_with_mgf_grid, utils/mgf_pricer.py:174-221, for
+ *                          grids with |Re phi| = 1/2: capped[k] = nansum_j Re[ w_j/(pi (p_j^2+1/4))
+ *                          exp(-ln(F/K_k) phi_j + log_mgf_j) ] with the legacy Simpson weights (:158-171); the
+ *                          payoff algebra on top (:208-219) is host code. */
+SVMC_API int svmc_logsv_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double sigma0,
+                                 double theta, double kappa1, double kappa2, double beta, double volvol,
+                                 int is_spot_measure, int expansion_order, double vol_backbone_eta, double *a,
+                                 double *log_mgf, double rtol, double atol, svmc_stream_t stream);
+SVMC_API int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double v0,
+                                  double theta, double kappa, double volvol, double rho, double *a, double *b,
+                                  int have_t0, double *log_mgf, svmc_stream_t stream);
+SVMC_API int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_grid, double forward,
+                                    const double *strikes_host, size_t n_strikes, double *capped,
+                                    svmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

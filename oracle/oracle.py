@@ -30,7 +30,8 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """compile oracle/libsvmc_oracle.so with the committed Makefile (gcc only)."""
-    src_time = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("svmc_oracle.c", "svmc_oracle.h"))
+    src_time = max(os.path.getmtime(os.path.join(_HERE, f))
+                   for f in ("svmc_oracle.c", "svmc_oracle_analytic.c", "svmc_oracle.h", "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_time:
         subprocess.run(["make", "-C", _HERE, "-B", "libsvmc_oracle.so"], check=True, capture_output=True)
     return _SO
@@ -60,6 +61,12 @@ def lib() -> C.CDLL:
                                               u64, u32, u64, u32]
         L.svo_logsv_vol_paths.argtypes = [_dp, sz, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, _dp, sz, u64, u32, u64]
         L.svo_logsv_vol_paths.restype = None
+        L.svo_logsv_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, f64, i32, i32, f64, _dp, _dp, f64, f64]
+        L.svo_logsv_mgf_grid.restype = None
+        L.svo_heston_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, _dp, _dp, i32, _dp]
+        L.svo_heston_mgf_grid.restype = None
+        L.svo_mgf_vanilla_slice.argtypes = [sz, _dp, _dp, f64, sz, _dp, C.POINTER(C.c_int8), f64, i32, _dp]
+        L.svo_mgf_vanilla_slice.restype = i32
         for name in ("svo_set_time_grid", "svo_logsv_terminal_w", "svo_heston_terminal_w",
                      "svo_heston_qe_terminal_w", "svo_philox4x32_10", "svo_fill_normals",
                      "svo_fill_uniforms", "svo_logsv_terminal_rng", "svo_heston_terminal_rng"):
@@ -284,3 +291,96 @@ def np_payoff(x, qvar, ttm, forward, strikes, optiontypes, discfactor=1.0, varia
             prices[i] = discfactor * np.nanmean(pay)
             stds[i] = discfactor * np.nanstd(pay)
     return prices, stds / np.sqrt(x.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# analytic side (oracle/svmc_oracle_analytic.c): affine-expansion MGF + Fourier inversion, config C5
+# ---------------------------------------------------------------------------------------------------
+def _cp(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def phi_grid(vol_scaler: float, is_spot_measure: bool = True, max_phi: int = 1000) -> np.ndarray:
+    """utils/mgf_pricer.py:11-34"""
+    p = np.linspace(0, 5.6 / vol_scaler, max_phi)
+    return (-0.5 if is_spot_measure else 0.5) + 1j * p
+
+
+def set_vol_scaler(sigma0: float, ttm: float) -> float:
+    """pricers/logsv_pricer.py:664-666"""
+    return sigma0 * np.sqrt(np.minimum(np.min(ttm), 0.5 / 12.0))
+
+
+def logsv_mgf_grid(phi, psi, ttm, sigma0, theta, kappa1, kappa2, beta, volvol, a_t0=None, is_spot_measure=True,
+                   expansion_order=2, vol_backbone_eta=1.0, rtol=1e-10, atol=1e-12):
+    phi = np.ascontiguousarray(phi, dtype=np.complex128)
+    psi = np.ascontiguousarray(psi, dtype=np.complex128)
+    n = 5 if expansion_order == 2 else 3
+    a = np.zeros((phi.size, n), dtype=np.complex128) if a_t0 is None else np.array(a_t0, dtype=np.complex128, order="C")
+    lm = np.empty(phi.size, dtype=np.complex128)
+    lib().svo_logsv_mgf_grid(phi.size, _cp(phi), _cp(psi), float(ttm), sigma0, theta, kappa1, kappa2, beta, volvol,
+                             int(bool(is_spot_measure)), int(expansion_order), float(vol_backbone_eta), _cp(a), _cp(lm),
+                             rtol, atol)
+    return a, lm
+
+
+def heston_mgf_grid(phi, psi, ttm, v0, theta, kappa, volvol, rho, a_t0=None, b_t0=None):
+    phi = np.ascontiguousarray(phi, dtype=np.complex128)
+    psi = np.ascontiguousarray(psi, dtype=np.complex128)
+    have = a_t0 is not None
+    a = np.array(a_t0, dtype=np.complex128) if have else np.zeros(phi.size, dtype=np.complex128)
+    b = np.array(b_t0, dtype=np.complex128) if have else np.zeros(phi.size, dtype=np.complex128)
+    lm = np.empty(phi.size, dtype=np.complex128)
+    lib().svo_heston_mgf_grid(phi.size, _cp(phi), _cp(psi), float(ttm), v0, theta, kappa, volvol, rho, _cp(a), _cp(b),
+                              int(have), _cp(lm))
+    return lm, a, b
+
+
+def mgf_vanilla_slice(phi, log_mgf, forward, strikes, optiontypes, discfactor=1.0, is_spot_measure=True):
+    phi = np.ascontiguousarray(phi, dtype=np.complex128)
+    log_mgf = np.ascontiguousarray(log_mgf, dtype=np.complex128)
+    strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+    codes = type_codes(optiontypes)
+    prices = np.empty_like(strikes)
+    rc = lib().svo_mgf_vanilla_slice(phi.size, _cp(phi), _cp(log_mgf), float(forward), strikes.size, _p(strikes),
+                                     codes.ctypes.data_as(C.POINTER(C.c_int8)), float(discfactor),
+                                     int(bool(is_spot_measure)), _p(prices))
+    if rc != 0:
+        raise ValueError("not implemented")
+    return prices
+
+
+def logsv_chain_pricer(params, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, is_spot_measure=True,
+                       expansion_order=2, vol_scaler=None, etas=None, rtol=1e-10, atol=1e-12):
+    """pricers/logsv_pricer.py:669-739 (LOG_RETURN).  params = (sigma0, theta, kappa1, kappa2, beta, volvol)"""
+    sigma0, theta, kappa1, kappa2, beta, volvol = params
+    if vol_scaler is None:
+        vol_scaler = set_vol_scaler(sigma0, np.min(ttms))
+    phi = phi_grid(vol_scaler, is_spot_measure)
+    psi = np.zeros_like(phi)
+    a, t0, out = None, 0.0, []
+    for i, ttm in enumerate(ttms):
+        a, lm = logsv_mgf_grid(phi, psi, ttm - t0, sigma0, theta, kappa1, kappa2, beta, volvol, a_t0=a,
+                               is_spot_measure=is_spot_measure, expansion_order=expansion_order,
+                               vol_backbone_eta=1.0 if etas is None else float(etas[i]), rtol=rtol, atol=atol)
+        out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i],
+                                     is_spot_measure))
+        t0 = ttm
+    return out
+
+
+def heston_chain_pricer(v0, theta, kappa, volvol, rho, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors,
+                        vol_scaler=None):
+    """pricers/heston_pricer.py:217-282 (LOG_RETURN)"""
+    if vol_scaler is None:
+        vol_scaler = np.minimum(0.3, np.sqrt(v0 * ttms[0]))
+    phi = phi_grid(vol_scaler, True)
+    psi = np.zeros_like(phi)
+    a = np.zeros(phi.size, dtype=np.complex128)
+    b = np.zeros(phi.size, dtype=np.complex128)
+    t0, out = 0.0, []
+    for i, ttm in enumerate(ttms):
+        lm, a, b = heston_mgf_grid(phi, psi, ttm - t0, v0, theta, kappa, volvol, rho, a_t0=a, b_t0=b)
+        out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
+        t0 = ttm
+    return out

@@ -98,6 +98,16 @@ void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
                          int is_spot_measure, const double *brownians, size_t ldb,
                          uint64_t seed, uint32_t call_id, uint64_t path_offset);
 
+/* ---- analytic side (svmc_oracle_analytic.c); complex arrays are interleaved (re, im) like numpy.complex128 ---- */
+void svo_logsv_mgf_grid(size_t n_grid, const double *phi, const double *psi, double ttm, double sigma0, double theta,
+                        double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
+                        int expansion_order, double vol_backbone_eta, double *a, double *log_mgf, double rtol, double atol);
+void svo_heston_mgf_grid(size_t n_grid, const double *phi, const double *psi, double ttm, double v0, double theta,
+                         double kappa, double volvol, double rho, double *a, double *b, int have_t0, double *log_mgf);
+int svo_mgf_vanilla_slice(size_t n_grid, const double *phi, const double *log_mgf, double forward, size_t n_strikes,
+                          const double *strikes, const int8_t *types, double discfactor, int is_spot_measure,
+                          double *prices);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libsvmc.so")
-SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip")
-HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h")
+SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip")
+HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h")
 ARCH = "gfx950"
 
 

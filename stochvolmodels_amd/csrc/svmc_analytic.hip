@@ -1,0 +1,318 @@
+// svmc_analytic.hip -- the analytic (Fourier) side of the chain pricers on gfx950: SURVEY.md row a11 / config C5.
+//
+//   logsv_mgf_grid_kernel     one lane per transform-grid point Phi_j: the 5-dim complex quadratic ODE
+//                             A' = A^T M A + L A + H of the affine expansion (pricers/logsv/affine_expansion.py:
+//                             67-205, 229-303, 570-685), integrated from the previous expiry's A with an embedded
+//                             Dormand-Prince 5(4) pair and per-lane step control; log E = sum_k A_k (sigma0-theta)^k
+//   heston_mgf_grid_kernel    closed-form Heston MGF (pricers/heston_pricer.py:183-214)
+//   mgf_vanilla_slice_kernel  one block per strike: Simpson-weighted sum over the grid of
+//                             Re[ w_j / (pi (p_j^2 + 1/4)) exp(-x_K Phi_j + log E_j) ]   (utils/mgf_pricer.py:174-221)
+//
+// The reference runs a Python loop of 1000 scipy.solve_ivp calls per expiry (~4 s); here every grid point is a
+// lane and an expiry is one launch.  The work is tiny (1000 lanes) and latency-bound; it is on the GPU so that the
+// analytic-vs-MC sweep of config C5 needs no host ODE solver.  CPU twin: oracle/svmc_oracle_analytic.c.
+#include "svmc_internal.h"
+
+namespace svmc {
+
+struct cd {
+    double re, im;
+};
+__device__ __forceinline__ cd C(double re, double im = 0.0) { return cd{re, im}; }
+__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cd operator-(cd a) { return cd{-a.re, -a.im}; }
+__device__ __forceinline__ cd operator*(cd a, cd b) { return cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cd operator*(double s, cd a) { return cd{s * a.re, s * a.im}; }
+__device__ __forceinline__ cd operator+(cd a, double s) { return cd{a.re + s, a.im}; }
+__device__ __forceinline__ cd operator+(double s, cd a) { return cd{a.re + s, a.im}; }
+__device__ __forceinline__ cd operator-(cd a, double s) { return cd{a.re - s, a.im}; }
+__device__ __forceinline__ cd operator-(double s, cd a) { return cd{s - a.re, -a.im}; }
+__device__ __forceinline__ double cabs_(cd a) { return hypot(a.re, a.im); }
+__device__ __forceinline__ cd operator/(cd a, cd b)
+{
+    const double d = b.re * b.re + b.im * b.im;
+    return cd{(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__device__ __forceinline__ cd cexp_(cd z)
+{
+    double s, c;
+    sincos(z.im, &s, &c);
+    const double e = exp(z.re);
+    return cd{e * c, e * s};
+}
+__device__ __forceinline__ cd csqrt_(cd z)   // principal branch
+{
+    const double r = cabs_(z);
+    if (r == 0.0) return cd{0.0, 0.0};
+    const double t = sqrt(0.5 * (r + fabs(z.re)));
+    if (z.re >= 0.0) return cd{t, z.im / (2.0 * t)};
+    return cd{fabs(z.im) / (2.0 * t), copysign(t, z.im)};
+}
+__device__ __forceinline__ cd clog_(cd z) { return cd{log(cabs_(z)), atan2(z.im, z.re)}; }
+
+struct OdeConsts {
+    double theta, theta2, vartheta2, qv, qv2, b, eta2, lamda, kappa2_p, kappa_p;
+    int spot, second;
+};
+
+// pricers/logsv/affine_expansion.py:126-182
+inline OdeConsts make_ode_consts(double theta, double kappa1, double kappa2, double beta, double volvol,
+                                 int is_spot_measure, int expansion_order, double eta)
+{
+    OdeConsts c;
+    c.theta = theta;
+    c.theta2 = theta * theta;
+    c.vartheta2 = beta * beta + volvol * volvol;
+    c.qv = theta * c.vartheta2;
+    c.qv2 = c.theta2 * c.vartheta2;
+    c.b = beta * eta;
+    c.eta2 = eta * eta;
+    c.spot = is_spot_measure;
+    c.second = (expansion_order == 2);
+    if (is_spot_measure) {
+        c.lamda = 0.0;
+        c.kappa2_p = kappa2;
+        c.kappa_p = kappa1 + kappa2 * theta;
+    } else {
+        c.lamda = beta * c.theta2 * eta;
+        c.kappa2_p = kappa2 - beta * eta;
+        c.kappa_p = kappa1 + kappa2 * theta - 2.0 * beta * theta * eta;
+    }
+    return c;
+}
+
+// A' = A^T M^(k) A + L^(k) A + H^(k): the non-zero entries of :146-182 written out
+__device__ __forceinline__ void ode_rhs(const OdeConsts &c, cd phi, cd psi, const cd (&A)[5], cd (&out)[5])
+{
+    const double qv = c.qv, qv2 = c.qv2, v2 = c.vartheta2, th = c.theta, th2 = c.theta2;
+    const cd bphi = c.b * phi;
+    const cd A1 = A[1], A2 = A[2];
+    const cd rhs = (c.spot ? phi * (phi + 1.0) : phi * (phi - 1.0)) - 2.0 * psi;
+    const cd L01 = c.lamda - th2 * bphi;
+    const cd L11 = -c.kappa_p - 2.0 * th * bphi, L12 = 2.0 * ((c.lamda + qv) - th2 * bphi);
+    const cd L21 = -c.kappa2_p - bphi, L22 = (v2 - 2.0 * c.kappa_p) - 4.0 * th * bphi;
+    const cd A11 = A1 * A1, A12 = A1 * A2, A22 = A2 * A2;
+    out[0] = 0.5 * qv2 * A11 + L01 * A1 + qv2 * A2 + 0.5 * th2 * c.eta2 * rhs;
+    out[1] = qv * A11 + 2.0 * qv2 * A12 + L11 * A1 + L12 * A2 + th * c.eta2 * rhs;
+    out[2] = 0.5 * v2 * A11 + 2.0 * qv2 * A22 + 4.0 * qv * A12 + L21 * A1 + L22 * A2 + 0.5 * c.eta2 * rhs;
+    if (c.second) {
+        const cd A3 = A[3], A4 = A[4];
+        const cd kb = c.kappa2_p + bphi;
+        const cd L23 = 3.0 * (2.0 * qv - th2 * bphi);
+        const cd L33 = 3.0 * ((v2 - c.kappa_p) - 2.0 * th * bphi), L34 = 4.0 * (3.0 * qv - th2 * bphi);
+        const cd A13 = A1 * A3, A14 = A1 * A4, A23 = A2 * A3, A24 = A2 * A4;
+        out[1] = out[1] + 3.0 * qv2 * A3;
+        out[2] = out[2] + 3.0 * qv2 * A13 + L23 * A3 + 6.0 * qv2 * A4;
+        out[3] = 4.0 * qv * A22 + 2.0 * v2 * A12 + 6.0 * qv * A13 + 4.0 * qv2 * A14 + 6.0 * qv2 * A23 - 2.0 * (kb * A2) +
+                 L33 * A3 + L34 * A4;
+        out[4] = 2.0 * v2 * A22 + 4.5 * qv2 * (A3 * A3) + 3.0 * v2 * A13 + 8.0 * qv * A14 + 12.0 * qv * A23 + 8.0 * qv2 * A24 -
+                 3.0 * (kb * A3) + 2.0 * (L22 * A4);
+    } else {
+        out[3] = C(0.0);
+        out[4] = C(0.0);
+    }
+}
+
+// Dormand-Prince 5(4), FSAL, mixed error scale, RMS norm -- the CPU twin's dopri5() statement for statement
+__device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5], double rtol, double atol)
+{
+    constexpr double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
+                     a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729,
+                     a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+                     a65 = -5103.0 / 18656, b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784,
+                     b6 = 11.0 / 84, e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
+                     e6 = 22.0 / 525, e7 = -1.0 / 40;
+    cd k1[5], k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], yt[5], yn[5];
+    double t = 0.0, h = ttm / 32.0;
+    int tries = 0;
+    ode_rhs(c, phi, psi, y, k1);
+    while (t < ttm && tries < 1000000) {
+        ++tries;
+        if (t + h > ttm) h = ttm - t;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a21 * k1[i]);
+        ode_rhs(c, phi, psi, yt, k2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
+        ode_rhs(c, phi, psi, yt, k3);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+        ode_rhs(c, phi, psi, yt, k4);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+        ode_rhs(c, phi, psi, yt, k5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            yt[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+        ode_rhs(c, phi, psi, yt, k6);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yn[i] = y[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
+        ode_rhs(c, phi, psi, yn, k7);
+        double err2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const cd e = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+            const double sc = atol + rtol * fmax(cabs_(y[i]), cabs_(yn[i]));
+            const double r = cabs_(e) / sc;
+            err2 += r * r;
+        }
+        const double err = sqrt(err2 / 5.0);
+        if (err <= 1.0) {
+            t += h;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                y[i] = yn[i];
+                k1[i] = k7[i];
+            }
+        }
+        const double fac = (err > 0.0) ? 0.9 * pow(err, -0.2) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+    }
+}
+
+constexpr int AB = 64;  // one wave per block: 1000 grid points spread over 16 CUs
+
+__global__ __launch_bounds__(AB) void logsv_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
+                                                            size_t n_grid, double ttm, OdeConsts c, double y0,
+                                                            cd *__restrict__ a, cd *__restrict__ log_mgf, double rtol,
+                                                            double atol)
+{
+    const size_t j = static_cast<size_t>(blockIdx.x) * AB + threadIdx.x;
+    if (j >= n_grid) return;
+    const int n = c.second ? 5 : 3;
+    cd A[5] = {C(0.0), C(0.0), C(0.0), C(0.0), C(0.0)};
+    for (int k = 0; k < n; ++k) A[k] = a[j * n + k];
+    dopri5(c, phi[j], psi[j], ttm, A, rtol, atol);
+    cd lm = C(0.0);
+    double yk = 1.0;
+    for (int k = 0; k < n; ++k) {
+        a[j * n + k] = A[k];
+        lm = lm + yk * A[k];                                          // affine_expansion.py:674-685
+        yk *= y0;
+    }
+    log_mgf[j] = lm;
+}
+
+__global__ __launch_bounds__(AB) void heston_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
+                                                             size_t n_grid, double ttm, double v0, double theta,
+                                                             double kappa, double volvol, double rho, cd *__restrict__ a,
+                                                             cd *__restrict__ b, int have_t0, cd *__restrict__ log_mgf)
+{
+    const size_t j = static_cast<size_t>(blockIdx.x) * AB + threadIdx.x;
+    if (j >= n_grid) return;
+    const double volvol2 = volvol * volvol;
+    const cd ph = phi[j], ps = psi[j];
+    const cd b1 = (rho * volvol) * ph + kappa;                                                   // :197
+    const cd b0 = 0.5 * (ph * (ph + 1.0)) - ps;                                                 // :198
+    const cd zeta = csqrt_(b1 * b1 - (2.0 * volvol2) * b0);                                     // :199
+    const cd exp_zeta = cexp_(-(ttm * zeta));
+    const cd psi_p = zeta - b1, psi_m = zeta + b1;
+    cd c_p, c_m;
+    if (!have_t0) {
+        c_p = psi_p / (2.0 * zeta);
+        c_m = psi_m / (2.0 * zeta);
+    } else {
+        c_p = (psi_p + volvol2 * b[j]) / (2.0 * zeta);
+        c_m = (psi_m - volvol2 * b[j]) / (2.0 * zeta);
+    }
+    const cd den = c_p * exp_zeta + c_m;
+    const cd b_t1 = -((psi_p * c_m - psi_m * c_p * exp_zeta) / (volvol2 * den));                // :207
+    cd a_t1 = -(theta * kappa / volvol2) * (ttm * psi_p + 2.0 * clog_(den));                    // :208
+    if (have_t0) a_t1 = a_t1 + a[j];
+    a[j] = a_t1;
+    b[j] = b_t1;
+    log_mgf[j] = a_t1 + v0 * b_t1;
+}
+
+struct StrikeArgs {
+    double x[32];   // log(forward / strike)
+    int k;
+};
+
+// one block per strike; legacy Simpson weights (utils/mgf_pricer.py:158-171): 1,4,2,...,  every odd index 4
+__global__ __launch_bounds__(256) void mgf_vanilla_slice_kernel(const cd *__restrict__ phi, const cd *__restrict__ log_mgf,
+                                                                int n_grid, StrikeArgs sa, double *__restrict__ capped)
+{
+    __shared__ double lds[4];
+    const double PI = 3.14159265358979323846;
+    const double x = sa.x[blockIdx.x];
+    const double h = phi[1].im - phi[0].im;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n_grid; j += 256) {
+        double w = 2.0;
+        if (j == 0 || j == n_grid - 1) w = 1.0;
+        if (j & 1) w = 4.0;
+        const double p = phi[j].im;
+        const double pw = ((h / 3.0) * w / PI) / (p * p + 0.25);
+        const cd e = cexp_(log_mgf[j] - x * phi[j]);
+        const double term = pw * e.re;
+        if (term == term) s += term;                                                            // nansum
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) capped[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
+static int check_launch_a(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVMC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return SVMC_OK;
+}
+
+}  // namespace svmc
+
+using namespace svmc;
+
+extern "C" {
+
+int svmc_logsv_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double sigma0, double theta,
+                        double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
+                        int expansion_order, double vol_backbone_eta, double *a, double *log_mgf, double rtol,
+                        double atol, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(phi && psi && a && log_mgf, "svmc_logsv_mgf_grid: null pointer");
+    SVMC_REQUIRE(expansion_order == 1 || expansion_order == 2, "svmc_logsv_mgf_grid: expansion_order must be 1 or 2");
+    SVMC_REQUIRE(ttm > 0.0 && rtol > 0.0 && atol > 0.0, "svmc_logsv_mgf_grid: ttm, rtol, atol must be positive");
+    if (n_grid == 0) return SVMC_OK;
+    const OdeConsts c = make_ode_consts(theta, kappa1, kappa2, beta, volvol, is_spot_measure, expansion_order, vol_backbone_eta);
+    hipLaunchKernelGGL(logsv_mgf_grid_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB)), dim3(AB), 0,
+                       as_stream(stream), reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(psi), n_grid, ttm,
+                       c, sigma0 - theta, reinterpret_cast<cd *>(a), reinterpret_cast<cd *>(log_mgf), rtol, atol);
+    return check_launch_a("svmc_logsv_mgf_grid");
+}
+
+int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double v0, double theta,
+                         double kappa, double volvol, double rho, double *a, double *b, int have_t0, double *log_mgf,
+                         svmc_stream_t stream)
+{
+    SVMC_REQUIRE(phi && psi && a && b && log_mgf, "svmc_heston_mgf_grid: null pointer");
+    if (n_grid == 0) return SVMC_OK;
+    hipLaunchKernelGGL(heston_mgf_grid_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB)), dim3(AB), 0,
+                       as_stream(stream), reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(psi), n_grid, ttm,
+                       v0, theta, kappa, volvol, rho, reinterpret_cast<cd *>(a), reinterpret_cast<cd *>(b), have_t0,
+                       reinterpret_cast<cd *>(log_mgf));
+    return check_launch_a("svmc_heston_mgf_grid");
+}
+
+int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_grid, double forward,
+                           const double *strikes_host, size_t n_strikes, double *capped, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(phi && log_mgf && capped, "svmc_mgf_vanilla_slice: null pointer");
+    SVMC_REQUIRE(n_grid >= 3 && n_grid < (1u << 30), "svmc_mgf_vanilla_slice: grid too short or too long");
+    SVMC_REQUIRE(n_strikes == 0 || strikes_host, "svmc_mgf_vanilla_slice: null strikes");
+    for (size_t k0 = 0; k0 < n_strikes; k0 += 32) {
+        StrikeArgs sa;
+        sa.k = static_cast<int>((n_strikes - k0 < 32) ? (n_strikes - k0) : 32);
+        for (int k = 0; k < 32; ++k) sa.x[k] = (k < sa.k) ? log(forward / strikes_host[k0 + k]) : 0.0;    // :199
+        hipLaunchKernelGGL(mgf_vanilla_slice_kernel, dim3(sa.k), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(log_mgf),
+                           static_cast<int>(n_grid), sa, capped + k0);
+    }
+    return check_launch_a("svmc_mgf_vanilla_slice");
+}
+
+}  // extern "C"

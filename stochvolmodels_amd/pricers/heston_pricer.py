@@ -21,6 +21,8 @@ from ..engine import HESTON_EULER_FLOOR, HESTON_QE, get_engine
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
+from ..analytic import AnalyticGrid, vanilla_prices_from_capped
+from ..utils import mgf_pricer as mgfp
 from .logsv_pricer import _broadcast_state
 from .model_pricer import ModelParams, ModelPricer
 
@@ -48,6 +50,13 @@ def _scheme_code(scheme) -> int:
 
 class HestonPricer(ModelPricer):
 
+    def price_chain(self, option_chain: OptionChain, params: HestonParams, **kwargs) -> List[np.ndarray]:
+        """analytic chain prices by Fourier inversion of the closed-form MGF (reference :52-66)"""
+        return heston_chain_pricer(v0=params.v0, theta=params.theta, kappa=params.kappa, volvol=params.volvol,
+                                   rho=params.rho, ttms=option_chain.ttms, forwards=option_chain.forwards,
+                                   discfactors=option_chain.discfactors, strikes_ttms=option_chain.strikes_ttms,
+                                   optiontypes_ttms=option_chain.optiontypes_ttms)
+
     def model_mc_price_chain(self, option_chain: OptionChain, params: HestonParams, nb_path: int = 100000,
                              variable_type: VariableType = VariableType.LOG_RETURN, **kwargs
                              ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
@@ -67,6 +76,49 @@ class HestonPricer(ModelPricer):
                                               qvar0=np.zeros(nb_path), theta=params.theta, kappa=params.kappa,
                                               rho=params.rho, volvol=params.volvol, nb_path=nb_path,
                                               scheme=kwargs.get("scheme", "euler"), seed=kwargs.get("seed"))
+
+
+def compute_heston_mgf_grid(v0: float, theta: float, kappa: float, volvol: float, rho: float, ttm: float,
+                            phi_grid: np.ndarray, psi_grid: np.ndarray, a_t0: np.ndarray = None, b_t0: np.ndarray = None
+                            ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """closed-form Heston log-MGF over the grid, (log_mgf, a_t1, b_t1) (reference :183-214).  A missing a_t0 / b_t0
+    is the zero vector: the reference's `None` branches are exactly the formulas at a_t0 = b_t0 = 0."""
+    from .. import _lib
+    grid = AnalyticGrid(np.asarray(phi_grid), np.asarray(psi_grid), 1)
+    try:
+        if a_t0 is not None:
+            grid.set_a(np.asarray(a_t0, dtype=np.complex128).reshape(-1, 1))
+        if b_t0 is not None:
+            b0 = np.ascontiguousarray(b_t0, dtype=np.complex128)
+            _lib.check(grid.lib.svmc_memcpy_h2d(grid.b.ptr, b0.ctypes.data, b0.nbytes, None))
+            _lib.check(grid.lib.svmc_stream_synchronize(None))
+        grid.heston_advance(ttm, v0, theta, kappa, volvol, rho, True)
+        return grid.get_log_mgf(), grid.get_a().ravel(), grid._down(grid.b, (grid.n,))
+    finally:
+        grid.close()
+
+
+def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rho: float, ttms: np.ndarray,
+                        forwards: np.ndarray, strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray],
+                        discfactors: np.ndarray, variable_type: VariableType = VariableType.LOG_RETURN,
+                        vol_scaler: float = None) -> List[np.ndarray]:
+    """analytic Heston chain prices (reference :217-282), LOG_RETURN"""
+    if int(getattr(variable_type, "value", variable_type)) != 1:
+        raise NotImplementedError(f"variable_type={variable_type}")
+    if vol_scaler is None:
+        vol_scaler = np.minimum(0.3, np.sqrt(v0 * ttms[0]))
+    phi_grid, psi_grid, _ = mgfp.get_transform_var_grid(variable_type=variable_type, vol_scaler=vol_scaler)
+    grid = AnalyticGrid(phi_grid, psi_grid, 1)
+    try:
+        prices, ttm0 = [], 0.0
+        for ttm, forward, discfactor, strikes, types in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms):
+            grid.heston_advance(ttm - ttm0, v0, theta, kappa, volvol, rho, True)     # zero a, b == the None branch
+            capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
+            prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor), True))
+            ttm0 = ttm
+        return prices
+    finally:
+        grid.close()
 
 
 def simulate_heston_x_vol_terminal(ttm: float, x0: np.ndarray, var0: np.ndarray, qvar0: np.ndarray, theta: float,

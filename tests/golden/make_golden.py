@@ -339,6 +339,62 @@ def g_analytic():
     save("analytic", **out)
 
 
+# -- a11: the reference's analytic chain with its ODE solver tightened (isolates solver tolerance from algebra) ---
+def g_analytic_tight():
+    import stochvolmodels.pricers.logsv.affine_expansion as afe
+    from stochvolmodels.pricers.logsv.affine_expansion import ExpansionOrder
+    orig = afe.solve_ivp
+
+    def tight(*a, **k):
+        k.setdefault("rtol", 1e-11)
+        k.setdefault("atol", 1e-13)
+        return orig(*a, **k)
+
+    out = {}
+    ttms = np.array([0.1, 0.25, 0.6])
+    fw, df = np.array([1.0, 1.02, 1.05]), np.array([0.999, 0.99, 0.97])
+    kk = np.linspace(0.7, 1.4, 8)
+    strikes = tuple(f * kk for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    inv_types = tuple(np.where(k >= f, "IC", "IP") for k, f in zip(strikes, fw))
+    out.update(ttms=ttms, forwards=fw, discfactors=df, strikes=np.stack(strikes), types=np.stack(types),
+               inv_types=np.stack(inv_types))
+    afe.solve_ivp = tight
+    try:
+        for tag, p in (("btc", BTC), ("test", TEST)):
+            out[f"{tag}_params"] = params_vec(p)
+            for mtag, spot, ty in (("spot", True, types), ("inv", False, inv_types)):
+                pr = lp.logsv_chain_pricer(params=p, ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes,
+                                           optiontypes_ttms=ty, is_spot_measure=spot)
+                out[f"{tag}_{mtag}_prices"] = np.stack([np.asarray(a) for a in pr])
+            pr = lp.logsv_chain_pricer(params=p, ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes,
+                                       optiontypes_ttms=types, expansion_order=ExpansionOrder.FIRST)
+            out[f"{tag}_first_order_prices"] = np.stack([np.asarray(a) for a in pr])
+        # raw MGF coefficients on a coarse grid, one slice, with a non-zero start (slice-to-slice carry)
+        phi = -0.5 + 1j * np.linspace(0.0, 30.0, 13)
+        psi = np.zeros_like(phi)
+        theta_grid = np.zeros_like(phi)
+        a1, lm1 = afe.compute_logsv_a_mgf_grid(ttm=0.3, phi_grid=phi, psi_grid=psi, theta_grid=theta_grid,
+                                               sigma0=BTC.sigma0, theta=BTC.theta, kappa1=BTC.kappa1, kappa2=BTC.kappa2,
+                                               beta=BTC.beta, volvol=BTC.volvol, vol_backbone_eta=0.9)
+        a2, lm2 = afe.compute_logsv_a_mgf_grid(ttm=0.2, phi_grid=phi, psi_grid=psi, theta_grid=theta_grid, a_t0=a1,
+                                               sigma0=BTC.sigma0, theta=BTC.theta, kappa1=BTC.kappa1, kappa2=BTC.kappa2,
+                                               beta=BTC.beta, volvol=BTC.volvol, vol_backbone_eta=1.1)
+        out.update(mgf_phi=phi, mgf_a1=a1, mgf_lm1=lm1, mgf_a2=a2, mgf_lm2=lm2)
+    finally:
+        afe.solve_ivp = orig
+    # the quickstart's printed goldens (examples/getting_started/quickstart.py:43-46), reference as shipped
+    q = LogSvParams(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0)
+    k5 = np.array([0.8, 0.9, 1.0, 1.1, 1.2])
+    pr = lp.logsv_chain_pricer(params=q, ttms=np.array([0.25, 0.5]), forwards=np.ones(2), discfactors=np.ones(2),
+                               strikes_ttms=(k5, k5), optiontypes_ttms=(np.where(k5 >= 1.0, "C", "P"),) * 2)
+    van = lp.logsv_chain_pricer(params=q, ttms=np.array([0.25]), forwards=np.ones(1), discfactors=np.ones(1),
+                                strikes_ttms=(np.array([1.0]),), optiontypes_ttms=(np.array(["C"]),))
+    out.update(quick_params=params_vec(q), quick_chain_prices=np.stack([np.asarray(a) for a in pr]),
+               quick_vanilla_price=float(van[0][0]))
+    save("analytic_tight", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
     g_time_grid()
@@ -350,3 +406,4 @@ if __name__ == "__main__":
     g_heston()
     g_payoff()
     g_analytic()
+    g_analytic_tight()

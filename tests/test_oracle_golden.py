@@ -237,3 +237,52 @@ def test_vol_paths(oracle, golden):
     sig = oracle.logsv_vol_paths(6, 0.01, 0.5, 1.0, 2.0, 2.0, 0.1, 1.0, 16, seed=5)
     assert sig.shape == (7, 16) and np.all(sig[0] == 0.5) and np.all(sig > 0)
     assert len(np.unique(sig[1])) == 16
+
+
+# ---- analytic side (row a11): oracle/svmc_oracle_analytic.c vs the reference ---------------------------------------
+def test_analytic_logsv_vs_reference_tight_solver(oracle, golden):
+    """with the reference's solve_ivp tightened to rtol 1e-11 the only difference left is rounding: 1e-11 on prices
+    (spot and inverse measure, first and second order, non-unit forwards / discount factors), 1e-10 on raw A"""
+    g = golden("analytic_tight")
+    strikes = tuple(g["strikes"])
+    for tag in ("btc", "test"):
+        p = tuple(float(v) for v in g[f"{tag}_params"])
+        for mtag, spot, ty in (("spot", True, g["types"]), ("inv", False, g["inv_types"])):
+            pr = oracle.logsv_chain_pricer(p, g["ttms"], g["forwards"], g["discfactors"], strikes, tuple(ty),
+                                           is_spot_measure=spot)
+            np.testing.assert_allclose(np.stack(pr), g[f"{tag}_{mtag}_prices"], rtol=0, atol=1e-11)
+        pr = oracle.logsv_chain_pricer(p, g["ttms"], g["forwards"], g["discfactors"], strikes, tuple(g["types"]),
+                                       expansion_order=1)
+        np.testing.assert_allclose(np.stack(pr), g[f"{tag}_first_order_prices"], rtol=0, atol=1e-11)
+    b = tuple(float(v) for v in g["btc_params"])
+    z = np.zeros(13)
+    a1, lm1 = oracle.logsv_mgf_grid(g["mgf_phi"], z, 0.3, *b, vol_backbone_eta=0.9)
+    a2, lm2 = oracle.logsv_mgf_grid(g["mgf_phi"], z, 0.2, *b, a_t0=a1, vol_backbone_eta=1.1)     # slice-to-slice carry
+    np.testing.assert_allclose(a1, g["mgf_a1"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(a2, g["mgf_a2"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(lm2, g["mgf_lm2"], rtol=1e-9, atol=1e-10)
+
+
+def test_analytic_vs_reference_as_shipped(oracle, golden):
+    """against the reference with its default RK45 tolerances (rtol 1e-3): agreement to the reference's own solver
+    error, 2e-6 in price over 5 parameter sets x 4 expiries x 21 strikes; Heston (closed form) to 1e-13; and the
+    quickstart's printed goldens (examples/getting_started/quickstart.py:43-46)"""
+    g = golden("analytic")
+    kk, types, ttms = g["strikes"], g["types"], g["ttms"]
+    one = np.ones(4)
+    for tag in ("btc", "readme", "quick", "test", "fig3"):
+        pr = oracle.logsv_chain_pricer(tuple(float(v) for v in g[f"logsv_{tag}_params"]), ttms, one, one, (kk,) * 4,
+                                       (types,) * 4)
+        np.testing.assert_allclose(np.stack(pr), g[f"logsv_{tag}_prices"], rtol=0, atol=2e-6)
+    for tag in ("base", "btc"):
+        v0, theta, kappa, rho, volvol = (float(v) for v in g[f"heston_{tag}_params"])
+        pr = oracle.heston_chain_pricer(v0, theta, kappa, volvol, rho, ttms, one, (kk,) * 4, (types,) * 4, one)
+        np.testing.assert_allclose(np.stack(pr), g[f"heston_{tag}_prices"], rtol=0, atol=1e-13)
+    t = golden("analytic_tight")
+    q = tuple(float(v) for v in t["quick_params"])
+    k5 = np.array([0.8, 0.9, 1.0, 1.1, 1.2])
+    pr = oracle.logsv_chain_pricer(q, np.array([0.25, 0.5]), np.ones(2), np.ones(2), (k5, k5),
+                                   (np.where(k5 >= 1.0, "C", "P"),) * 2)
+    np.testing.assert_allclose(pr[0][2], 0.197331, rtol=5e-6, atol=1e-8)
+    np.testing.assert_allclose(pr[1][2], 0.275202, rtol=5e-6, atol=1e-8)
+    np.testing.assert_allclose(np.stack(pr), t["quick_chain_prices"], rtol=0, atol=2e-6)
