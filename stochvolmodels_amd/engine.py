@@ -312,6 +312,42 @@ class HipEngine:
                 b.free()
 
 
+class DeviceRandoms:
+    """fixed randoms of a chain kept resident in HBM: upload once, re-price at kernel speed on
+    every calibration iterate.  Holds, per expiry, this rank's column range of W0 and W1 ([nb_steps_i][n_local])."""
+
+    def __init__(self, W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], dts: Sequence[float], n_local: int,
+                 col0: int = 0):
+        lib = _lib.load()
+        self.nb_path = int(np.asarray(W0s[0]).shape[1])
+        self.n_local, self.col0 = int(n_local), int(col0)
+        self.dts = [float(d) for d in dts]
+        self.nb_steps, self.w0, self.w1 = [], [], []
+        for W0, W1 in zip(W0s, W1s):
+            W0 = np.ascontiguousarray(W0, dtype=np.float64)
+            W1 = np.ascontiguousarray(W1, dtype=np.float64)
+            if W0.shape != W1.shape or W0.shape[1] != self.nb_path:
+                raise ValueError("every W0/W1 must have shape [nb_steps_i, nb_path]")
+            nb = W0.shape[0]
+            bufs = []
+            for a in (W0, W1):
+                buf = DeviceBuffer(nb * self.n_local)
+                _lib.check(lib.svmc_memcpy2d_h2d(buf.ptr, 8 * self.n_local, a.ctypes.data + 8 * self.col0,
+                                                 8 * a.shape[1], 8 * self.n_local, nb, None))
+                bufs.append(buf)
+            _lib.check(lib.svmc_stream_synchronize(None))
+            self.nb_steps.append(nb)
+            self.w0.append(bufs[0])
+            self.w1.append(bufs[1])
+
+    def __len__(self):
+        return len(self.nb_steps)
+
+    def free(self) -> None:
+        for b in self.w0 + self.w1:
+            b.free()
+
+
 def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float
                     ) -> Tuple[np.ndarray, np.ndarray]:
     """host arithmetic of utils/mc_payoffs.py:85-88 on the reduced sums (svmc_payoff_finalize)."""

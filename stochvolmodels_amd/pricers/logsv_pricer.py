@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
-from ..engine import get_engine
+from ..engine import DeviceRandoms, get_engine
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
@@ -230,6 +230,16 @@ def get_randoms_for_chain_valuation(ttms: np.ndarray, nb_path: int = 100000, nb_
     return W0s, W1s, dts
 
 
+def upload_fixed_randoms(W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], dts: Sequence[float], comm=None
+                         ) -> DeviceRandoms:
+    """copy the chain's fixed randoms to HBM once (this rank's path columns); pass the result as `W0s` to
+    logsv_mc_chain_pricer_fixed_randoms.  This is what makes an MC calibration loop kernel-bound instead of
+    PCIe-bound (reference logsv_pricer.py:520-527 draws the randoms once and re-prices per optimizer iterate)."""
+    comm = comm or svdist.get_default_comm()
+    offset, n_local = svdist.shard_range(np.asarray(W0s[0]).shape[1], comm.rank, comm.world)
+    return DeviceRandoms(W0s, W1s, dts, n_local, offset)
+
+
 def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
                                         strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray],
                                         W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], dts: Sequence[float],
@@ -238,15 +248,24 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                         variable_type: VariableType = VariableType.LOG_RETURN, comm=None
                                         ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """chain MC on supplied randoms (reference :1100-1162): nb_path = W0s[0].shape[1]; each rank uploads only
-    its own column range of the host arrays."""
+    its own column range of the host arrays.  W0s may instead be a DeviceRandoms (upload_fixed_randoms): the
+    randoms then stay in HBM across calls and W1s / dts are taken from it."""
     variable_type_code(variable_type)
-    nb_path = np.asarray(W0s[0]).shape[1]
     comm = comm or svdist.get_default_comm()
+    resident = W0s if isinstance(W0s, DeviceRandoms) else None
+    nb_path = resident.nb_path if resident else np.asarray(W0s[0]).shape[1]
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    if resident and (resident.n_local, resident.col0) != (n_local, offset):
+        raise ValueError("DeviceRandoms were uploaded for a different path shard")
     eng = get_engine(n_local, path_offset=offset)
     eng.fill_state(0.0, v0, 0.0)
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
+        if resident:
+            eng.logsv_w(resident.nb_steps[i], resident.dts[i], theta, kappa1, kappa2, beta, volvol,
+                        float(vol_backbone_etas[i]), is_spot_measure, resident.w0[i].ptr, resident.w1[i].ptr)
+            eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+            return
         W0, W1 = np.asarray(W0s[i]), np.asarray(W1s[i])
         if W0.shape != W1.shape or W0.shape[1] != nb_path:
             raise ValueError("every W0/W1 must have shape [nb_steps_i, nb_path]")

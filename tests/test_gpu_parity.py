@@ -535,3 +535,23 @@ def test_analytic_heston_and_c5_sweep(sv, golden):
         tol = 4.0 * np.stack(sd) + 1.5e-2 * np.abs(np.stack(analytic)) + 1e-4
         assert np.all(np.abs(np.stack(mc) - np.stack(analytic)) <= tol), (tag, z.max())
     print("C5 sweep: max |MC - analytic| / stderr =", worst)
+
+
+def test_resident_fixed_randoms(sv, golden):
+    """randoms uploaded once and re-used across calls give the same prices as per-call upload, and a
+    second parameter set (a 'calibration iterate') prices on the same resident randoms"""
+    g = golden("logsv_tiny_chain")
+    p = P(g["params"])
+    W0s, W1s = [g["W0_0"], g["W0_1"]], [g["W1_0"], g["W1_1"]]
+    common = dict(ttms=g["ttms"], forwards=g["forwards"], discfactors=g["discfactors"], strikes_ttms=tuple(g["strikes"]),
+                  optiontypes_ttms=tuple(g["types"]), vol_backbone_etas=np.ones(2))
+    res = sv.upload_fixed_randoms(W0s, W1s, g["dts"])
+    for _ in range(2):
+        pr, sd = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **p)
+        np.testing.assert_allclose(np.stack(pr), g["prices"], **ST)
+        np.testing.assert_allclose(np.stack(sd), g["stderrs"], **ST)
+    p2 = dict(p, volvol=1.2, beta=-0.1)
+    a, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **p2)
+    b, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=g["dts"], **common, **p2)
+    np.testing.assert_array_equal(np.stack(a), np.stack(b))
+    res.free()

@@ -90,6 +90,19 @@ def main():
     steps = W0s[0].shape[0]
     res.append(dict(config=f"fixed randoms from host (pageable numpy), 2^18 x {steps}", ms=1e3 * dt,
                     path_steps_per_s=npth * steps / dt, host_to_device_GBps=16.0 * npth * steps / dt / 1e9))
+    res_dev = sv.upload_fixed_randoms(W0s, W1s, dts)
+    dt, _ = timed(lambda: sv.logsv_mc_chain_pricer_fixed_randoms(
+        ttms=c1.ttms, forwards=c1.forwards, discfactors=c1.discfactors, strikes_ttms=c1.strikes_ttms,
+        optiontypes_ttms=c1.optiontypes_ttms, W0s=res_dev, W1s=None, dts=None, v0=P.sigma0, theta=P.theta,
+        kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta, volvol=P.volvol, vol_backbone_etas=np.ones(1)), reps=10, warm=2)
+    res.append(dict(config=f"fixed randoms RESIDENT in HBM (upload_fixed_randoms), 2^18 x {steps}", ms=1e3 * dt,
+                    path_steps_per_s=npth * steps / dt, hbm_GBps=16.0 * npth * steps / dt / 1e9))
+    # C5 analytic side
+    g5 = sv.OptionChain(ttms=np.array([0.125, 0.25, 0.375, 0.5]), forwards=np.ones(4), strikes_ttms=(kk,) * 4,
+                        optiontypes_ttms=(types,) * 4, ids=None)
+    dt, _ = timed(lambda: pricer.price_chain(g5, P), reps=5, warm=1)
+    res.append(dict(config="C5 analytic side: LogSV affine-expansion chain 4 x 21 strikes, 1000-point phi grid", ms=1e3 * dt,
+                    prices_per_s=84 / dt))
     for r in res:
         print(json.dumps(r))
 
