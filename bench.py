@@ -100,6 +100,20 @@ def cpu_baseline_all_cores(nb_steps: int, params) -> dict:
             "sample": f"{n} paths x {nb_steps} steps, stepping only, {t:.1f}s"}
 
 
+def pmc_traffic(kernel: str, n_paths: int, nb_steps: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json; FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command and corrected as the microarch guide
+    prescribes).  Only returned when the profile was taken at the configuration being benchmarked."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            prof = json.load(fh)
+        if prof["config"] == {"paths": n_paths, "steps": nb_steps}:
+            return float(prof[kernel]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def streamed_roofline(eng, params, nb_steps: int) -> dict:
     """the fixed-randoms kernel (logsv_w_kernel) reads 16 B per path-step from HBM: the HBM-bound leg."""
     n = eng.n_path
@@ -119,8 +133,8 @@ def streamed_roofline(eng, params, nb_steps: int) -> dict:
     alg_bytes = (16.0 * nb_steps + 48.0) * n
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return {"kernel": "logsv_w_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms,
-            "path_steps_per_s": n * nb_steps / (ms * 1e-3),
+            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("logsv_w_kernel", n, nb_steps),
+            "algorithmic_bytes": alg_bytes, "ms_per_launch": ms, "path_steps_per_s": n * nb_steps / (ms * 1e-3),
             "config": {"paths": n, "steps": nb_steps, "bytes_per_path_step": 16}}
 
 
@@ -185,8 +199,8 @@ def main():
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         # dominant kernel: logsv_rng_kernel.  Algorithmic HBM bytes per launch: state read +
-        # terminal write = 48 B per path, nothing inside the time loop.
-        alg_bytes = 48.0 * n_local
+        # terminal write (+ the fused snapshot), nothing inside the time loop.
+        alg_bytes = 56.0 * n_local    # 24 B state read + 24 B state write + 8 B terminal-x snapshot (fused epilogue)
         hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
         kernel_rate = n_local * nb / (k_ms * 1e-3)
         valu_tflops = kernel_rate * LOGSV_FLOP_EQ_PER_PATH_STEP / 1e12
@@ -199,9 +213,10 @@ def main():
                        "expiries": 1, "strikes": 21, "parallelism": f"path-sharded x{world}"},
             "option_prices_per_s": 21 * args.steps / elapsed,
             "roofline": {"kernel": "logsv_rng_kernel", "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("logsv_rng_kernel", n_local, nb), "algorithmic_bytes": alg_bytes,
                          "ms_per_launch": k_ms, "launches": len(kernel_ms),
-                         "note": "on-device-RNG stepping moves only 48 B per path per expiry: not HBM-bound by "
+                         "note": "on-device-RNG stepping moves only 56 B per path per expiry: not HBM-bound by "
                                  "construction; the binding roof is fp64 VALU (roofline_valu)"},
             "roofline_valu": {"kernel": "logsv_rng_kernel", "bound": "valu_fp64", "achieved": valu_tflops,
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

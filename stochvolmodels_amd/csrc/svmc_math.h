@@ -124,10 +124,9 @@ SVMC_HD double sqrt_pos(double t)
     double g = t * y;
     double h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
+    g = fma(g, r, g);                     // relative error ~2^-47 after the Goldschmidt step
     const double d = fma(-g, g, t);
-    return fma(d, h, g);
+    return fma(d, h, g);                  // h is only 2^-24 accurate: its error enters at 2^-71
 }
 
 // sqrt(t) for t >= 0 including exact zero (the rsq seed of 0 is +inf): Heston's variance before its first floor.
@@ -185,26 +184,24 @@ SVMC_HD double neg_log(double u)
     return fma(-dk, 0x1.62e42fee00000p-1, -a);      // -(k ln2 + ln m)
 }
 
-// cos and sin of (pi/2)(q + r) for |r| <= 1/2 and q in {0,1,2,3}: two even/odd polynomials in r, then the
+// cos and sin of (pi/2)(q + r) for |r| <= 1/2 and q in {0,1,2,3}: two 7-term even/odd polynomials in r (degree 13 / 14), then the
 // quadrant rotation by sign flips and one swap.
 SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)
 {
     const double z = r * r;
-    double ps = -0x1.6c5b875d4e739p-31;
-    ps = fma_k(ps, z, 0x1.e8eed12ee00a3p-25);
-    ps = fma_k(ps, z, -0x1.e3074b4ff3058p-19);
-    ps = fma_k(ps, z, 0x1.50783485cbd83p-13);
-    ps = fma_k(ps, z, -0x1.32d2cce62ac22p-8);
-    ps = fma_k(ps, z, 0x1.466bc6775aad9p-4);
-    ps = fma_k(ps, z, -0x1.4abbce625be53p-1);
+    double ps = 0x1.e3f38399551bfp-25;
+    ps = fma_k(ps, z, -0x1.e30071afc3e59p-19);
+    ps = fma_k(ps, z, 0x1.50782fda12d96p-13);
+    ps = fma_k(ps, z, -0x1.32d2cce2e5b19p-8);
+    ps = fma_k(ps, z, 0x1.466bc677587f8p-4);
+    ps = fma_k(ps, z, -0x1.4abbce625be41p-1);
     ps = fma_k(ps, z, 0x1.921fb54442d18p+0);
-    double pc = 0x1.1e745e5e09f6dp-34;
-    pc = fma_k(pc, z, -0x1.b6de8b8e9ba08p-28);
-    pc = fma_k(pc, z, 0x1.f9d3870871194p-22);
-    pc = fma_k(pc, z, -0x1.a6d1f2a086c90p-16);
-    pc = fma_k(pc, z, 0x1.e1f506891ae95p-11);
-    pc = fma_k(pc, z, -0x1.55d3c7e3cbff7p-6);
-    pc = fma_k(pc, z, 0x1.03c1f081b5ac4p-2);
+    double pc = -0x1.b2f3eb054afcdp-28;
+    pc = fma_k(pc, z, 0x1.f9ce245cada0bp-22);
+    pc = fma_k(pc, z, -0x1.a6d1eef479be1p-16);
+    pc = fma_k(pc, z, 0x1.e1f5068688d5bp-11);
+    pc = fma_k(pc, z, -0x1.55d3c7e3cb241p-6);
+    pc = fma_k(pc, z, 0x1.03c1f081b5ac0p-2);
     pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);
     const double s0 = ps * r;            // sin((pi/2) r)
     const double c0 = fma_k(pc, z, 1.0);  // cos((pi/2) r)
