@@ -169,22 +169,29 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, double &x, dou
     const double v0 = var;
     const double m = c.theta + (v0 - c.theta) * c.E;
     const double s2 = v0 * c.c1 + c.c2;
-    const double psi = s2 * rcp_fast(m * m);
+    const double m2 = m * m;
     double v1, K0;
-    if (psi <= 1.5) {
-        const double ip = 2.0 * rcp_fast(psi);
+    if (s2 <= 1.5 * m2) {                                 // psi = s2/m^2 <= psi_c, decided without the divide
+        const double ip = 2.0 * m2 * rcp_fast(s2);        // 2/psi
         const double b2 = ip - 1.0 + sqrt_pos0(ip * (ip - 1.0));
         const double a = m * rcp_fast(1.0 + b2);
         const double b = sqrt_pos0(b2);
-        const double den = 1.0 - 2.0 * c.A * a;
         v1 = a * (b + z1) * (b + z1);
-        K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_fast(den) - 0.5 * neg_log(den) - c.K13 * v0) : c.K0_plain;
+        if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
+            K0 = -c.K13 * v0;
+        } else {
+            const double den = 1.0 - 2.0 * c.A * a;
+            K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_fast(den) - 0.5 * neg_log(den) - c.K13 * v0) : c.K0_plain;
+        }
     } else {
         const double u = draw_u();
-        const double p = (psi - 1.0) * rcp_fast(psi + 1.0);
+        const double p = (s2 - m2) * rcp_fast(s2 + m2);   // (psi - 1)/(psi + 1)
         const double bt = (1.0 - p) * rcp_fast(m);
         v1 = (u <= p) ? 0.0 : -neg_log((1.0 - p) * rcp_fast(1.0 - u)) * rcp_fast(bt);
-        K0 = (c.A < bt) ? (neg_log(p + bt * (1.0 - p) * rcp_fast(bt - c.A)) - c.K13 * v0) : c.K0_plain;
+        if (c.A == 0.0)
+            K0 = -c.K13 * v0;
+        else
+            K0 = (c.A < bt) ? (neg_log(p + bt * (1.0 - p) * rcp_fast(bt - c.A)) - c.K13 * v0) : c.K0_plain;
     }
     x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0(c.K3 * v0 + c.K4 * v1) * z0;
     qvar = qvar + 0.5 * c.dt * (v0 + v1);
