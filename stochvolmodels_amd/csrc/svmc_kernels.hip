@@ -36,12 +36,14 @@ __global__ __launch_bounds__(BLOCK) void fill_normals_kernel(double *__restrict_
                                                              uint32_t c3, uint64_t path_offset,
                                                              uint32_t step_offset)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     const uint64_t gp = path_offset + p;
     for (int t = 0; t < nb_steps; ++t) {
         double w0, w1;
-        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), w0, w1);
+        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, w0, w1);
         W0[static_cast<size_t>(t) * ldw + p] = w0;
         W1[static_cast<size_t>(t) * ldw + p] = w1;
     }
@@ -120,6 +122,8 @@ __global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x
         const uint64_t gp = path_offset + p;
         for (int t = 0; t < nb_steps; ++t) {
             double z0, z1;
-            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), z0, z1);
+            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
             logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
         }
         x[p] = xv;
@@ -221,6 +225,8 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
                                                                 const double *__restrict__ brownians, size_t ldb,
                                                                 uint64_t seed, uint32_t c3, uint64_t path_offset)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double s = v0, L = log(v0);
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
     for (int t = 0; t < nb_steps; ++t) {
         double w;
         if (RNG) {
-            if ((t & 1) == 0) draw_normals(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 1), z0, z1);
+            if ((t & 1) == 0) draw_normals(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 1), tab, z0, z1);
             w = sdt * ((t & 1) ? z1 : z0);                                                      // :925
         } else {
             w = brownians[static_cast<size_t>(t) * ldb + p];
@@ -253,6 +259,8 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
                                                            uint32_t c3, uint64_t path_offset,
                                                            uint32_t step_offset, SliceOut so)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         for (int t = 0; t < nb_steps; ++t) {
             const uint32_t step = step_offset + static_cast<uint32_t>(t);
             double w0, w1;
-            draw_normals(seed, c3, gp, step, w0, w1);
+            draw_normals(seed, c3, gp, step, tab, w0, w1);
             if (SCHEME == SVMC_HESTON_QE) {
                 heston_qe_step(qc, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
             } else {

@@ -184,6 +184,36 @@ SVMC_HD double neg_log(double u)
     return fma(-dk, 0x1.62e42fee00000p-1, -a);      // -(k ln2 + ln m)
 }
 
+// Table-assisted -ln(u), any positive normal u: the top 8 bits of the [sqrt(1/2), sqrt(2)) mantissa pick
+// { fl(1/c_j), -ln fl(1/c_j) } (tools/gen_log_table.py); f = fma(m, 1/c_j, -1) has |f| <= 2^-9, so ln(1+f) is its
+// 6-term Taylor polynomial -- no reciprocal and a 5-step Horner chain instead of the divide + 7-term polynomial of
+// neg_log().  The interval containing m = 1 has c = 1 exactly, keeping full relative accuracy as u -> 1.
+// On the device `tab` is a 4 KB LDS copy: a 16-byte ds_read per call, in the LDS pipe beside the VALU stream.
+struct LogTabEntry {
+    double inv_c, log_c;
+};
+
+SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
+{
+    uint32_t hx = double_hi(u);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = static_cast<int>(hx >> 20) - 0x3ff;
+    const uint32_t frac = hx & 0x000fffffu;
+    const LogTabEntry e = tab[frac >> 12];
+    const double m = bits_to_double(double_lo(u), frac + 0x3fe6a09eu);
+    const double dk = static_cast<double>(k);
+    const double f = fma(m, e.inv_c, -1.0);
+    double p = -0x1.5555555555555p-3;              // -1/6
+    p = fma_k(p, f, 0x1.999999999999ap-3);         //  1/5
+    p = fma_k(p, f, -0x1.0000000000000p-2);        // -1/4
+    p = fma_k(p, f, 0x1.5555555555555p-2);         //  1/3
+    p = fma_k(p, f, -0x1.0000000000000p-1);        // -1/2
+    const double r = fma(f * f, p, f);             // log1p(f)
+    const double lg = e.log_c + r;                 // ln(m)
+    const double a = fma(dk, 0x1.a39ef35793c76p-33, lg);
+    return fma(-dk, 0x1.62e42fee00000p-1, -a);
+}
+
 // cos and sin of (pi/2)(q + r) for |r| <= 1/2 and q in {0,1,2,3}: two 7-term even/odd polynomials in r (degree 13 / 14), then the
 // quadrant rotation by sign flips and one swap.
 SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)

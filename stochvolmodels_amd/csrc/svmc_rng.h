@@ -17,9 +17,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "svmc_log_table.h"
 #include "svmc_math.h"
 
 namespace svmc {
+
+// the 4 KB table of neg_log_tab(): constant memory -> LDS once per block (blocks are 256 threads = 256 entries)
+__constant__ LogTabEntry g_log_table[256] = {SVMC_LOG_TABLE_INIT};
+
+__device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)[256])
+{
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds[i] = g_log_table[i];
+    __syncthreads();
+    return lds;
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&r)[4])
@@ -58,13 +69,13 @@ __device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t
 
 // stream 0: Box-Muller pair of UNSCALED N(0,1)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
-                                             double &w0, double &w1)
+                                             const LogTabEntry *tab, double &w0, double &w1)
 {
     uint32_t r[4];
     philox_draw(seed, c3, path, step, r);
     const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
     const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
-    const double e = neg_log(u1);
+    const double e = neg_log_tab(u1, tab);
     const double R = sqrt_pos(e + e);
     double sn, cs;
     sincos_quarter(r[2] & 3u, rr, sn, cs);

@@ -1,9 +1,12 @@
 // Host build of stochvolmodels_amd/csrc/svmc_math.h for tests/test_math_accuracy.py (g++ only).
 #include <stddef.h>
+#include "svmc_log_table.h"
 #include "svmc_math.h"
+static const svmc::LogTabEntry LOG_TAB[256] = {SVMC_LOG_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
 void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }
+void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log_tab(x[i], LOG_TAB); }
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }
 void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
 void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)

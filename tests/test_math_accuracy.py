@@ -61,6 +61,31 @@ def test_neg_log(probe):
     assert _ulp(_call(probe, "probe_neg_log", u), -np.log(u.astype(np.longdouble))) <= 3.0
 
 
+def test_neg_log_table(probe):
+    """the table-assisted -ln of the RNG, called on u in (0,1) only: <= 2 ULP (1.1 typical; the intervals next to
+    the c = 1 one cancel log_c against log1p(f) and reach 1.8) on the RNG lattice, in both tails (u -> 0, and
+    u -> 1 where the c = 1 interval keeps the RELATIVE accuracy) and at both ends of every table interval below 1.
+    (Above 1 the doubled interval width lets the cancellation reach ~9 ULP of a ~1e-4 result, 1e-19 absolute;
+    Heston QE, the only caller with such arguments, uses the divide-based neg_log.)"""
+    rng = np.random.default_rng(4)
+    u = rng.integers(0, 2 ** 52, N).astype(np.float64) * 2.0 ** -52 + 2.0 ** -53
+    assert _ulp(_call(probe, "probe_neg_log_tab", u), -np.log(u.astype(np.longdouble))) <= 2.0
+    u = np.concatenate([2.0 ** -rng.uniform(0, 53, N), 1 - 2.0 ** -rng.uniform(1, 53, N),
+                        [2.0 ** -53, 1 - 2.0 ** -53, 0.5, np.sqrt(0.5)]])
+    u = u[(u > 0) & (u < 1)]
+    assert _ulp(_call(probe, "probe_neg_log_tab", u), -np.log(u.astype(np.longdouble))) <= 2.0
+    hi = (0x3FE6A09E + np.arange(256, dtype=np.uint64) * 4096)
+    ends = np.concatenate([(hi << np.uint64(32)), ((hi + np.uint64(4095)) << np.uint64(32)) | np.uint64(0xFFFFFFFF)]).view(np.float64)
+    for scale in (1.0, 0.5, 2.0 ** -20):
+        e = ends * scale
+        e = e[e < 1.0]
+        assert _ulp(_call(probe, "probe_neg_log_tab", e), -np.log(e.astype(np.longdouble))) <= 2.0
+    assert _call(probe, "probe_neg_log_tab", np.array([1.0]))[0] == 0.0
+    v = 2.0 ** rng.uniform(-30, 30, N)                              # general arguments: absolute accuracy only
+    err = np.abs(_call(probe, "probe_neg_log_tab", v).astype(np.longdouble) + np.log(v.astype(np.longdouble)))
+    assert float(err.max()) <= 4e-15
+
+
 def test_sqrt_and_rcp(probe):
     rng = np.random.default_rng(2)
     t = 2.0 ** rng.uniform(-60, 9, N)
