@@ -151,7 +151,44 @@ class OptionChain:
                    ask_ivs=[flat_vol * np.ones_like(strikes) for _ in ttms],
                    optiontypes_ttms=[np.where(strikes >= f, "C", "P") for f in forwards])
 
-    def compute_model_ivols_from_chain_data(self, model_prices, forwards=None):
-        raise NotImplementedError(
-            "price -> Black implied-vol inversion lives in the third-party vanilla_option_pricers package "
-            "(reference data/option_chain.py:327-346) and is outside the Monte Carlo hot path (SURVEY.md 8f.3)")
+    def compute_model_ivols_from_chain_data(self, model_prices, forwards=None) -> List[np.ndarray]:
+        """model prices -> Black implied vols, slice by slice (reference data/option_chain.py:327-346).
+
+        The reference delegates to the third-party `vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices`,
+        which is not available here: this is a textbook Black-76 inversion on the host (a few dozen numbers per
+        chain; not on the GPU path), for 'C' and 'P'.  Parity with the third-party routine is UNPINNED
+        (SURVEY.md 8c); prices outside the no-arbitrage band give NaN."""
+        forwards = self.forwards if forwards is None else forwards
+        return [infer_black_ivols(np.asarray(p, dtype=float), float(t), float(f), np.asarray(k, dtype=float), ty, float(d))
+                for p, t, f, k, ty, d in zip(model_prices, self.ttms, forwards, self.strikes_ttms,
+                                             self.optiontypes_ttms, self.discfactors)]
+
+
+def black_price(forward: float, strikes: np.ndarray, ttm: float, vol: np.ndarray, is_call: np.ndarray,
+                discfactor: float = 1.0) -> np.ndarray:
+    """Black-76 price of calls / puts on a forward"""
+    from scipy.special import ndtr
+    sv = np.maximum(vol, 1e-300) * np.sqrt(ttm)
+    d1 = np.log(forward / strikes) / sv + 0.5 * sv
+    d2 = d1 - sv
+    call = discfactor * (forward * ndtr(d1) - strikes * ndtr(d2))
+    return np.where(is_call, call, call - discfactor * (forward - strikes))
+
+
+def infer_black_ivols(prices: np.ndarray, ttm: float, forward: float, strikes: np.ndarray, optiontypes,
+                      discfactor: float = 1.0, lo: float = 1e-6, hi: float = 10.0) -> np.ndarray:
+    """Black-76 implied vols by bisection on [lo, hi] (monotone in vol; 60 halvings reach 1e-17 of the bracket)"""
+    types = np.asarray(optiontypes).astype(str)
+    if not np.all(np.isin(types, ("C", "P"))):
+        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
+    is_call = types == "C"
+    a = np.full(strikes.shape, lo)
+    b = np.full(strikes.shape, hi)
+    ok = (prices > black_price(forward, strikes, ttm, a, is_call, discfactor)) & \
+         (prices < black_price(forward, strikes, ttm, b, is_call, discfactor))
+    for _ in range(60):
+        mid = 0.5 * (a + b)
+        below = black_price(forward, strikes, ttm, mid, is_call, discfactor) < prices
+        a = np.where(below, mid, a)
+        b = np.where(below, b, mid)
+    return np.where(ok, 0.5 * (a + b), np.nan)

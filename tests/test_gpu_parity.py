@@ -555,3 +555,20 @@ def test_resident_fixed_randoms(sv, golden):
     b, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=g["dts"], **common, **p2)
     np.testing.assert_array_equal(np.stack(a), np.stack(b))
     res.free()
+
+
+def test_mc_chain_implied_vols(sv):
+    """ModelPricer.compute_mc_chain_implied_vols (reference model_pricer.py:216-241): MC price +/- 1.96 stderr -> Black
+    vols; shape / ordering contract of the reference's tests/test_model_calibration_contracts.py:97-118"""
+    kk = np.array([0.8, 0.9, 1.0, 1.1, 1.2])
+    chain = sv.OptionChain.get_uniform_chain(ttms=np.array([0.25, 0.5]), ids=np.array(["3m", "6m"]),
+                                             forwards=np.array([1.0, 1.0]), strikes=kk)
+    p = sv.LogSvParams(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0)
+    out = sv.LogSVPricer().compute_mc_chain_implied_vols(chain, p, nb_path=1 << 18, seed=3)
+    prices, ups, downs, mid, up, down, stds = out
+    assert len(prices) == len(mid) == 2 and mid[0].shape == (5,)
+    for i in range(2):
+        assert np.all(downs[i] <= prices[i]) and np.all(prices[i] <= ups[i])
+        assert np.all(down[i] <= mid[i] + 1e-12) and np.all(mid[i] <= up[i] + 1e-12)
+        assert np.all((mid[i] > 0.7) & (mid[i] < 1.3))               # ~100% vol model
+    np.testing.assert_allclose(mid[1][2], 0.995757, atol=0.01)         # quickstart's analytic 6m ATM vol

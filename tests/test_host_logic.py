@@ -123,3 +123,19 @@ def test_lazy_exports():
     assert "logsv_mc_chain_pricer_fixed_randoms" in dir(sv)
     with pytest.raises(AttributeError):
         sv.not_a_symbol
+
+
+def test_black_implied_vol_round_trip():
+    """the host-side Black-76 inversion used by compute_mc_chain_implied_vols (parity with the reference's third-party
+    routine is unpinned; this only checks self-consistency)"""
+    from stochvolmodels_amd.data.option_chain import black_price, infer_black_ivols
+    k = np.array([0.7, 0.9, 1.0, 1.1, 1.4])
+    vols = np.array([0.9, 0.6, 0.5, 0.55, 0.8])
+    types = np.array(["P", "P", "C", "C", "C"])
+    pr = black_price(1.02, k, 0.5, vols, types == "C", 0.97)
+    np.testing.assert_allclose(infer_black_ivols(pr, 0.5, 1.02, k, types, 0.97), vols, rtol=1e-12)
+    chain = sv.OptionChain.slice_to_chain(0.5, 1.02, k, types, discfactor=0.97)
+    np.testing.assert_allclose(chain.compute_model_ivols_from_chain_data([pr])[0], vols, rtol=1e-12)
+    assert np.isnan(infer_black_ivols(np.array([2.0]), 0.5, 1.0, np.array([1.0]), np.array(["C"]))[0])
+    with pytest.raises(NotImplementedError):
+        infer_black_ivols(pr[:1], 0.5, 1.0, k[:1], np.array(["IC"]))
