@@ -199,6 +199,11 @@ SVMC_API int svmc_logsv_mgf_grid(const double *phi, const double *psi, size_t n_
 SVMC_API int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double v0,
                                   double theta, double kappa, double volvol, double rho, double *a, double *b,
                                   int have_t0, double *log_mgf, svmc_stream_t stream);
+/* the strike sums of slice_qvar_pricer_with_a_grid, utils/mgf_pricer.py:322-356 (options on the annualised quadratic
+ * variance): capped[k] = nansum_j Re[ w_j/(pi psi_j^2) exp(K_k ttm psi_j + log_mgf_j) ], legacy Simpson weights */
+SVMC_API int svmc_mgf_qvar_slice(const double *psi, const double *log_mgf, size_t n_grid, double ttm,
+                                 const double *strikes_host, size_t n_strikes, double *capped,
+                                 svmc_stream_t stream);
 SVMC_API int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_grid, double forward,
                                     const double *strikes_host, size_t n_strikes, double *capped,
                                     svmc_stream_t stream);

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         L.svo_logsv_mgf_grid.restype = None
         L.svo_heston_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, _dp, _dp, i32, _dp]
         L.svo_heston_mgf_grid.restype = None
+        L.svo_mgf_qvar_slice.argtypes = [sz, _dp, _dp, f64, sz, _dp, C.POINTER(C.c_int8), f64, _dp]
+        L.svo_mgf_qvar_slice.restype = i32
         L.svo_mgf_vanilla_slice.argtypes = [sz, _dp, _dp, f64, sz, _dp, C.POINTER(C.c_int8), f64, i32, _dp]
         L.svo_mgf_vanilla_slice.restype = i32
         for name in ("svo_set_time_grid", "svo_logsv_terminal_w", "svo_heston_terminal_w",
@@ -350,21 +352,46 @@ def mgf_vanilla_slice(phi, log_mgf, forward, strikes, optiontypes, discfactor=1.
     return prices
 
 
+def psi_grid() -> np.ndarray:
+    """utils/mgf_pricer.py:37-47"""
+    return -0.5 + 1j * np.linspace(0, 4000, 40000)
+
+
+def mgf_qvar_slice(psi, log_mgf, ttm, strikes, optiontypes, discfactor=1.0):
+    psi = np.ascontiguousarray(psi, dtype=np.complex128)
+    log_mgf = np.ascontiguousarray(log_mgf, dtype=np.complex128)
+    strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+    codes = type_codes(optiontypes)
+    prices = np.empty_like(strikes)
+    rc = lib().svo_mgf_qvar_slice(psi.size, _cp(psi), _cp(log_mgf), float(ttm), strikes.size, _p(strikes),
+                                  codes.ctypes.data_as(C.POINTER(C.c_int8)), float(discfactor), _p(prices))
+    if rc != 0:
+        raise ValueError("not implemented")
+    return prices
+
+
 def logsv_chain_pricer(params, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, is_spot_measure=True,
-                       expansion_order=2, vol_scaler=None, etas=None, rtol=1e-10, atol=1e-12):
-    """pricers/logsv_pricer.py:669-739 (LOG_RETURN).  params = (sigma0, theta, kappa1, kappa2, beta, volvol)"""
+                       expansion_order=2, vol_scaler=None, etas=None, rtol=1e-10, atol=1e-12, variable_type=LOG_RETURN):
+    """pricers/logsv_pricer.py:669-739.  params = (sigma0, theta, kappa1, kappa2, beta, volvol)"""
     sigma0, theta, kappa1, kappa2, beta, volvol = params
     if vol_scaler is None:
         vol_scaler = set_vol_scaler(sigma0, np.min(ttms))
-    phi = phi_grid(vol_scaler, is_spot_measure)
-    psi = np.zeros_like(phi)
+    if variable_type == LOG_RETURN:
+        phi = phi_grid(vol_scaler, is_spot_measure)
+        psi = np.zeros_like(phi)
+    else:                                              # utils/mgf_pricer.py:77-83
+        psi = psi_grid()
+        phi = (np.zeros_like if is_spot_measure else np.ones_like)(psi)
     a, t0, out = None, 0.0, []
     for i, ttm in enumerate(ttms):
         a, lm = logsv_mgf_grid(phi, psi, ttm - t0, sigma0, theta, kappa1, kappa2, beta, volvol, a_t0=a,
                                is_spot_measure=is_spot_measure, expansion_order=expansion_order,
                                vol_backbone_eta=1.0 if etas is None else float(etas[i]), rtol=rtol, atol=atol)
-        out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i],
-                                     is_spot_measure))
+        if variable_type == LOG_RETURN:
+            out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i],
+                                         is_spot_measure))
+        else:
+            out.append(mgf_qvar_slice(psi, lm, ttm, strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
         t0 = ttm
     return out
 

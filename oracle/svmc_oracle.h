@@ -104,6 +104,8 @@ void svo_logsv_mgf_grid(size_t n_grid, const double *phi, const double *psi, dou
                         int expansion_order, double vol_backbone_eta, double *a, double *log_mgf, double rtol, double atol);
 void svo_heston_mgf_grid(size_t n_grid, const double *phi, const double *psi, double ttm, double v0, double theta,
                          double kappa, double volvol, double rho, double *a, double *b, int have_t0, double *log_mgf);
+int svo_mgf_qvar_slice(size_t n_grid, const double *psi, const double *log_mgf, double ttm, size_t n_strikes,
+                       const double *strikes, const int8_t *types, double discfactor, double *prices);
 int svo_mgf_vanilla_slice(size_t n_grid, const double *phi, const double *log_mgf, double forward, size_t n_strikes,
                           const double *strikes, const int8_t *types, double discfactor, int is_spot_measure,
                           double *prices);

@@ -228,3 +228,26 @@ int svo_mgf_vanilla_slice(size_t n_grid, const double *phi, const double *log_mg
     }
     return 0;
 }
+
+/* slice_qvar_pricer_with_a_grid, utils/mgf_pricer.py:322-356: calls on the annualised quadratic variance.
+ * Returns 0, or -1 for a payoff code other than 'C' (the reference raises ValueError("not implemented")). */
+int svo_mgf_qvar_slice(size_t n_grid, const double *psi, const double *log_mgf, double ttm, size_t n_strikes,
+                       const double *strikes, const int8_t *types, double discfactor, double *prices)
+{
+    const double PI = 3.14159265358979323846;
+    const double h = psi[2 * 1 + 1] - psi[1];
+    for (size_t k = 0; k < n_strikes; ++k) {
+        if (types[k] != SVO_CALL) return -1;
+        double sum = 0.0;
+        for (size_t j = 0; j < n_grid; ++j) {
+            double w = 2.0;
+            if (j == 0 || j == n_grid - 1) w = 1.0;
+            if (j % 2 == 1) w = 4.0;
+            cd ps = psi[2 * j] + I * psi[2 * j + 1], lm = log_mgf[2 * j] + I * log_mgf[2 * j + 1];
+            double term = creal((((h / 3.0) * w / PI) / (ps * ps)) * cexp((strikes[k] * ttm) * ps + lm));
+            if (term == term) sum += term;
+        }
+        prices[k] = fmax(discfactor * sum / ttm, 1e-10);                              /* :344 */
+    }
+    return 0;
+}

@@ -87,6 +87,18 @@ class AnalyticGrid:
         _lib.check(self.lib.svmc_stream_synchronize(None))
         return out
 
+    def qvar_sums(self, ttm: float, strikes: np.ndarray) -> np.ndarray:
+        strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+        k = strikes.size
+        if self._capped is None or self._capped.n < k:
+            self._capped = DeviceBuffer(max(k, 32))
+        _lib.check(self.lib.svmc_mgf_qvar_slice(self.psi.ptr, self.log_mgf.ptr, self.n, float(ttm),
+                                                strikes.ctypes.data_as(C.POINTER(C.c_double)), k, self._capped.ptr, None))
+        out = np.empty(k)
+        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, 8 * k, None))
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        return out
+
     def close(self) -> None:
         for b in (self.phi, self.psi, self.a, self.b, self.log_mgf, self._capped):
             if b is not None:
@@ -115,4 +127,14 @@ def vanilla_prices_from_capped(capped: np.ndarray, forward: float, strikes: np.n
                 prices[idx] = forward * discfactor * (np.exp(-xk) - cap)
             else:
                 raise ValueError("not implemented")
+    return prices
+
+
+def qvar_prices_from_sums(sums: np.ndarray, ttm: float, optiontypes: Sequence, discfactor: float) -> np.ndarray:
+    """the payoff algebra of slice_qvar_pricer_with_a_grid, reference utils/mgf_pricer.py:343-356 (calls only)"""
+    prices = np.zeros_like(sums)
+    for idx, (s, type_) in enumerate(zip(sums, optiontypes)):
+        if str(type_) != "C":
+            raise ValueError("not implemented")
+        prices[idx] = np.maximum(discfactor * s / ttm, 1e-10)
     return prices

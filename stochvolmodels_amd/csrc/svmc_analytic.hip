@@ -256,6 +256,31 @@ __global__ __launch_bounds__(256) void mgf_vanilla_slice_kernel(const cd *__rest
     if (threadIdx.x == 0) capped[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
 }
 
+// options on quadratic variance, utils/mgf_pricer.py:322-356: one block per strike,
+// sum_j Re[ w_j / (pi psi_j^2) exp(K ttm psi_j + log E_j) ] over the 40 000-point psi grid
+__global__ __launch_bounds__(256) void mgf_qvar_slice_kernel(const cd *__restrict__ psi, const cd *__restrict__ log_mgf,
+                                                             int n_grid, StrikeArgs sa, double *__restrict__ capped)
+{
+    __shared__ double lds[4];
+    const double PI = 3.14159265358979323846;
+    const double kt = sa.x[blockIdx.x];                  // strike * ttm
+    const double h = psi[1].im - psi[0].im;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n_grid; j += 256) {
+        double w = 2.0;
+        if (j == 0 || j == n_grid - 1) w = 1.0;
+        if (j & 1) w = 4.0;
+        const cd ps = psi[j];
+        const cd term = (C((h / 3.0) * w / PI) / (ps * ps)) * cexp_(kt * ps + log_mgf[j]);
+        if (term.re == term.re) s += term.re;                                                   // nansum
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) capped[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
 static int check_launch_a(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -313,6 +338,23 @@ int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_gr
                            static_cast<int>(n_grid), sa, capped + k0);
     }
     return check_launch_a("svmc_mgf_vanilla_slice");
+}
+
+int svmc_mgf_qvar_slice(const double *psi, const double *log_mgf, size_t n_grid, double ttm, const double *strikes_host,
+                        size_t n_strikes, double *capped, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(psi && log_mgf && capped, "svmc_mgf_qvar_slice: null pointer");
+    SVMC_REQUIRE(n_grid >= 3 && n_grid < (1u << 30), "svmc_mgf_qvar_slice: grid too short or too long");
+    SVMC_REQUIRE(n_strikes == 0 || strikes_host, "svmc_mgf_qvar_slice: null strikes");
+    for (size_t k0 = 0; k0 < n_strikes; k0 += 32) {
+        StrikeArgs sa;
+        sa.k = static_cast<int>((n_strikes - k0 < 32) ? (n_strikes - k0) : 32);
+        for (int k = 0; k < 32; ++k) sa.x[k] = (k < sa.k) ? strikes_host[k0 + k] * ttm : 0.0;             // :343
+        hipLaunchKernelGGL(mgf_qvar_slice_kernel, dim3(sa.k), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const cd *>(psi), reinterpret_cast<const cd *>(log_mgf),
+                           static_cast<int>(n_grid), sa, capped + k0);
+    }
+    return check_launch_a("svmc_mgf_qvar_slice");
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ from ..engine import DeviceRandoms, get_engine
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
-from ..analytic import AnalyticGrid, vanilla_prices_from_capped
+from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
 from ..utils import mgf_pricer as mgfp
 from .logsv.affine_expansion import ExpansionOrder, _order_code
 from .logsv.logsv_params import LogSvParams
@@ -93,11 +93,12 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
                        expansion_order: ExpansionOrder = ExpansionOrder.SECOND,
                        variable_type: VariableType = VariableType.LOG_RETURN, vol_scaler: float = None, **kwargs
                        ) -> List[np.ndarray]:
-    """analytic LogSV chain prices (reference :669-739): 1000-point phi grid, per expiry one launch integrating the
-    coefficient ODEs of every grid point from the previous expiry's A, then one launch of per-strike Simpson sums.
-    LOG_RETURN only (options on quadratic variance go through a 40 000-point psi grid: not built)."""
-    if int(getattr(variable_type, "value", variable_type)) != 1:
-        raise NotImplementedError("analytic pricing is implemented for VariableType.LOG_RETURN")
+    """analytic LogSV chain prices (reference :669-739): per expiry one launch integrating the coefficient ODEs of every
+    transform-grid point from the previous expiry's A, then one launch of per-strike Simpson sums.  LOG_RETURN uses
+    the 1000-point phi grid; Q_VAR (calls on the annualised quadratic variance) the 40 000-point psi grid."""
+    vt = int(getattr(variable_type, "value", variable_type))
+    if vt not in (1, 2):
+        raise NotImplementedError
     if is_analytic:
         raise NotImplementedError("the semi-analytic fixed-point path is not part of this package")
     order = _order_code(expansion_order)
@@ -112,9 +113,13 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
             eta = params.get_vol_backbone_eta(tau=ttm)
             grid.logsv_advance(ttm - ttm0, params.sigma0, params.theta, params.kappa1, params.kappa2, params.beta,
                                params.volvol, is_spot_measure, order, eta)
-            capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
-            prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor),
-                                                     is_spot_measure))
+            if vt == 1:
+                capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
+                prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor),
+                                                         is_spot_measure))
+            else:
+                sums = grid.qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64))
+                prices.append(qvar_prices_from_sums(sums, float(ttm), types, float(discfactor)))
             ttm0 = ttm
         return prices
     finally:

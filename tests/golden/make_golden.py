@@ -395,6 +395,33 @@ def g_analytic_tight():
     save("analytic_tight", **out)
 
 
+# -- a11, options on quadratic variance: 40 000-point psi grid (utils/mgf_pricer.py:37-47, :322-356) ------------
+def g_analytic_qvar():
+    import stochvolmodels.pricers.logsv.affine_expansion as afe
+    orig = afe.solve_ivp
+    out = {}
+    ttms = np.array([0.25, 0.5])
+    fw, df = np.ones(2), np.array([0.99, 0.98])
+    sets = {"test": (TEST, np.linspace(0.02, 0.09, 8)), "btc": (BTC, np.linspace(0.3, 1.7, 8))}
+    for tag, (p, kk) in sets.items():
+        strikes, types = (kk, kk), (np.array(["C"] * 8),) * 2
+        out[f"{tag}_params"], out[f"{tag}_strikes"] = params_vec(p), kk
+        pr = lp.logsv_chain_pricer(params=p, ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes,
+                                   optiontypes_ttms=types, variable_type=VariableType.Q_VAR)
+        out[f"{tag}_prices"] = np.stack([np.asarray(a) for a in pr])
+        print("qvar analytic (default solver)", tag, "done", flush=True)
+    afe.solve_ivp = lambda *a, **k: orig(*a, **{**dict(rtol=1e-10, atol=1e-12), **k})
+    try:
+        p, kk = sets["test"]
+        pr = lp.logsv_chain_pricer(params=p, ttms=ttms[:1], forwards=fw[:1], discfactors=df[:1], strikes_ttms=(kk,),
+                                   optiontypes_ttms=(np.array(["C"] * 8),), variable_type=VariableType.Q_VAR)
+        out["test_tight_prices"] = np.stack([np.asarray(a) for a in pr])
+    finally:
+        afe.solve_ivp = orig
+    out.update(ttms=ttms, forwards=fw, discfactors=df)
+    save("analytic_qvar", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
     g_time_grid()
@@ -407,3 +434,4 @@ if __name__ == "__main__":
     g_payoff()
     g_analytic()
     g_analytic_tight()
+    g_analytic_qvar()

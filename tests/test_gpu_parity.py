@@ -572,3 +572,27 @@ def test_mc_chain_implied_vols(sv):
         assert np.all(down[i] <= mid[i] + 1e-12) and np.all(mid[i] <= up[i] + 1e-12)
         assert np.all((mid[i] > 0.7) & (mid[i] < 1.3))               # ~100% vol model
     np.testing.assert_allclose(mid[1][2], 0.995757, atol=0.01)         # quickstart's analytic 6m ATM vol
+
+
+def test_analytic_qvar(sv, golden):
+    """analytic calls on quadratic variance (40 000 psi-grid lanes per expiry) vs the reference, and vs the GPU Monte
+    Carlo Q_VAR price within 4 stderr + 1% (affine-expansion approximation)"""
+    g = golden("analytic_qvar")
+    for tag in ("test", "btc"):
+        v = [float(a) for a in g[f"{tag}_params"]]
+        params = sv.LogSvParams(sigma0=v[0], theta=v[1], kappa1=v[2], kappa2=v[3], beta=v[4], volvol=v[5])
+        kk = g[f"{tag}_strikes"]
+        chain = sv.OptionChain(ttms=g["ttms"], forwards=g["forwards"], strikes_ttms=(kk, kk),
+                               optiontypes_ttms=(np.array(["C"] * 8),) * 2, ids=None, discfactors=g["discfactors"])
+        pricer = sv.LogSVPricer()
+        an = pricer.price_chain(chain, params, variable_type=sv.VariableType.Q_VAR)
+        np.testing.assert_allclose(np.stack(an), g[f"{tag}_prices"], rtol=0, atol=5e-6)
+        if tag == "test":
+            np.testing.assert_allclose(an[0], g["test_tight_prices"][0], rtol=0, atol=1e-8)
+        mc, sd = pricer.model_mc_price_chain(chain, params, variable_type=sv.VariableType.Q_VAR, nb_path=1 << 20,
+                                             nb_steps=720, seed=8)
+        tol = 4.0 * np.stack(sd) + 1e-2 * np.stack(an) + 1e-6
+        assert np.all(np.abs(np.stack(mc) - np.stack(an)) <= tol), (tag, np.abs(np.stack(mc) - np.stack(an)) / np.stack(sd))
+    with pytest.raises(ValueError):
+        chain_p = sv.OptionChain.slice_to_chain(0.25, 1.0, np.array([0.04]), np.array(["P"]))
+        sv.LogSVPricer().price_chain(chain_p, sv.LogSvParams(), variable_type=sv.VariableType.Q_VAR)

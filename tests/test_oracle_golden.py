@@ -286,3 +286,22 @@ def test_analytic_vs_reference_as_shipped(oracle, golden):
     np.testing.assert_allclose(pr[0][2], 0.197331, rtol=5e-6, atol=1e-8)
     np.testing.assert_allclose(pr[1][2], 0.275202, rtol=5e-6, atol=1e-8)
     np.testing.assert_allclose(np.stack(pr), t["quick_chain_prices"], rtol=0, atol=2e-6)
+
+
+def test_analytic_qvar_vs_reference(oracle, golden):
+    """calls on the annualised quadratic variance through the 40 000-point psi grid (utils/mgf_pricer.py:322-356):
+    reference as shipped (its RK45 default error) and, for one slice, with its solver tightened"""
+    g = golden("analytic_qvar")
+    for tag in ("test", "btc"):
+        p = tuple(float(v) for v in g[f"{tag}_params"])
+        kk = g[f"{tag}_strikes"]
+        pr = oracle.logsv_chain_pricer(p, g["ttms"], g["forwards"], g["discfactors"], (kk, kk), (np.array(["C"] * 8),) * 2,
+                                       variable_type=2)
+        np.testing.assert_allclose(np.stack(pr), g[f"{tag}_prices"], rtol=0, atol=5e-6)
+    p = tuple(float(v) for v in g["test_params"])
+    kk = g["test_strikes"]
+    pr = oracle.logsv_chain_pricer(p, g["ttms"][:1], g["forwards"][:1], g["discfactors"][:1], (kk,),
+                                   (np.array(["C"] * 8),), variable_type=2)
+    np.testing.assert_allclose(np.stack(pr), g["test_tight_prices"], rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        oracle.mgf_qvar_slice(oracle.psi_grid()[:5], np.zeros(5), 0.25, np.array([0.04]), np.array(["P"]))
