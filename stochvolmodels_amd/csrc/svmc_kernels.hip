@@ -274,7 +274,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
             double w0, w1;
             draw_normals(seed, c3, gp, step, tab, w0, w1);
             if (SCHEME == SVMC_HESTON_QE) {
-                heston_qe_step(qc, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
+                heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
             } else {
                 heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
             }
@@ -309,12 +309,14 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
                                                             const double *__restrict__ Z1,
                                                             const double *__restrict__ U, size_t ldw)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], v = var[p], q = qvar[p];
     const double *const w[3] = {Z0 + p, Z1 + p, U + p};
     streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) {
-        heston_qe_step(qc, xv, v, q, z[0], z[1], [&]() { return z[2]; });
+        heston_qe_step(qc, tab, xv, v, q, z[0], z[1], [&]() { return z[2]; });
     });
     x[p] = xv;
     var[p] = v;

@@ -160,11 +160,13 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
 }
 
 // z0 drives the log-price, z1 the quadratic branch; the uniform of the exponential branch is drawn lazily
-// (draw_u() is only evaluated by waves that have a lane in that branch).  Divides are reciprocal + Newton
-// (<= 1 ULP), log/sqrt are svmc_math.h's; the arithmetic order is the CPU twin's.
+// (draw_u() is only evaluated by waves that have a lane in that branch).  Quotients are reciprocal + one Newton
+// step (2^-48: far inside the 1e-9 the parity tests state), logs go through the LDS table (absolute accuracy
+// 1e-19 on arguments near 1, which is what the martingale correction feeds it), sqrt is svmc_math.h's; the
+// arithmetic order is the CPU twin's.
 template <class DrawU>
-__device__ __forceinline__ void heston_qe_step(const QeConsts &c, double &x, double &var, double &qvar,
-                                               double z0, double z1, DrawU &&draw_u)
+__device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEntry *tab, double &x, double &var,
+                                               double &qvar, double z0, double z1, DrawU &&draw_u)
 {
     const double v0 = var;
     const double m = c.theta + (v0 - c.theta) * c.E;
@@ -172,26 +174,26 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, double &x, dou
     const double m2 = m * m;
     double v1, K0;
     if (s2 <= 1.5 * m2) {                                 // psi = s2/m^2 <= psi_c, decided without the divide
-        const double ip = 2.0 * m2 * rcp_fast(s2);        // 2/psi
-        const double b2 = ip - 1.0 + sqrt_pos0(ip * (ip - 1.0));
-        const double a = m * rcp_fast(1.0 + b2);
-        const double b = sqrt_pos0(b2);
+        const double ip = 2.0 * m2 * rcp_1n(s2);          // 2/psi >= 4/3
+        const double b2 = ip - 1.0 + sqrt_pos(ip * (ip - 1.0));
+        const double a = m * rcp_1n(1.0 + b2);
+        const double b = sqrt_pos(b2);
         v1 = a * (b + z1) * (b + z1);
         if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
             K0 = -c.K13 * v0;
         } else {
             const double den = 1.0 - 2.0 * c.A * a;
-            K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_fast(den) - 0.5 * neg_log(den) - c.K13 * v0) : c.K0_plain;
+            K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_1n(den) - 0.5 * neg_log_tab(den, tab) - c.K13 * v0) : c.K0_plain;
         }
     } else {
         const double u = draw_u();
-        const double p = (s2 - m2) * rcp_fast(s2 + m2);   // (psi - 1)/(psi + 1)
-        const double bt = (1.0 - p) * rcp_fast(m);
-        v1 = (u <= p) ? 0.0 : -neg_log((1.0 - p) * rcp_fast(1.0 - u)) * rcp_fast(bt);
+        const double p = (s2 - m2) * rcp_1n(s2 + m2);     // (psi - 1)/(psi + 1)
+        const double bt = (1.0 - p) * rcp_1n(m);
+        v1 = (u <= p) ? 0.0 : -neg_log_tab((1.0 - p) * rcp_1n(1.0 - u), tab) * rcp_1n(bt);
         if (c.A == 0.0)
             K0 = -c.K13 * v0;
         else
-            K0 = (c.A < bt) ? (neg_log(p + bt * (1.0 - p) * rcp_fast(bt - c.A)) - c.K13 * v0) : c.K0_plain;
+            K0 = (c.A < bt) ? (neg_log_tab(p + bt * (1.0 - p) * rcp_1n(bt - c.A), tab) - c.K13 * v0) : c.K0_plain;
     }
     x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0(c.K3 * v0 + c.K4 * v1) * z0;
     qvar = qvar + 0.5 * c.dt * (v0 + v1);
