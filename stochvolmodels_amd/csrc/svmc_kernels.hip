@@ -117,7 +117,7 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
