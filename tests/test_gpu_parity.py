@@ -596,3 +596,55 @@ def test_analytic_qvar(sv, golden):
     with pytest.raises(ValueError):
         chain_p = sv.OptionChain.slice_to_chain(0.25, 1.0, np.array([0.04]), np.array(["P"]))
         sv.LogSVPricer().price_chain(chain_p, sv.LogSvParams(), variable_type=sv.VariableType.Q_VAR)
+
+
+def test_config_c4_btc_style_chain(sv, oracle):
+    """BASELINE config 4 (one rank's share): LogSV, 8 expiries.  (a) the irregular BTC-style maturities
+    [1/52, 1/24, 1/12, 1/6, 1/4, 1/2, 3/4, 1] at spy = 1016 -- per-slice step counts follow int(dT*spy)+1 -- with
+    forwards 67000 e^{0.05 T}, mixed C/P/IC/IP, path-wise against the CPU twin at 4096 paths; (b) the regular k/8
+    chain at full per-rank size (2^21 paths x 1024 steps): per-slice put-call parity, martingale, determinism."""
+    P_ = sv.LOGSV_BTC_PARAMS
+    spy = 1016
+    ttms = np.array([1 / 52, 1 / 24, 1 / 12, 1 / 6, 1 / 4, 1 / 2, 3 / 4, 1.0])
+    fw = 67000.0 * np.exp(0.05 * ttms)
+    dfs = np.exp(-0.05 * ttms)
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    base = np.array((["P", "IP", "C", "IC"] * 6)[:21])
+    types = tuple(base for _ in ttms)
+    n, seed = 4096, 77
+    pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=dfs, strikes_ttms=strikes, optiontypes_ttms=types,
+                                      v0=P_.sigma0, theta=P_.theta, kappa1=P_.kappa1, kappa2=P_.kappa2, beta=P_.beta,
+                                      volvol=P_.volvol, vol_backbone_etas=np.ones(8), nb_path=n, nb_steps_per_year=spy,
+                                      seed=seed)
+    x, s, q = np.zeros(n), P_.sigma0 * np.ones(n), np.zeros(n)
+    t0, step0, total = 0.0, 0, 0
+    for i, ttm in enumerate(ttms):
+        nb, dt, _ = sv.set_time_grid(ttm - t0, spy)
+        assert nb == int((ttm - t0) * spy) + 1
+        x, s, q = oracle.logsv_terminal_rng(x, s, q, nb, dt, P_.theta, P_.kappa1, P_.kappa2, P_.beta, P_.volvol, seed,
+                                            step_offset=step0)
+        step0, t0, total = step0 + nb, ttm, total + nb
+        opr, osd = oracle.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]))
+        np.testing.assert_allclose(pr[i], opr, rtol=1e-9, atol=1e-9 * fw[i], err_msg=f"slice {i}")
+        np.testing.assert_allclose(sd[i], osd, rtol=1e-8, atol=1e-9 * fw[i], err_msg=f"slice {i}")
+    assert total == 1021                                           # sum over the 8 slices of int(dT*1016)+1: the
+    #                                                                actual step count is what enters path-steps/s
+    # (b) regular chain, full per-rank size
+    ttms = np.arange(1, 9) / 8.0
+    fw = 67000.0 * np.exp(0.05 * ttms)
+    kk = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    both = tuple(np.concatenate([k, k]) for k in kk)
+    cp = tuple(np.array(["C"] * 21 + ["P"] * 21) for _ in ttms)
+    chain = sv.OptionChain(ttms=ttms, forwards=fw, strikes_ttms=both, optiontypes_ttms=cp, ids=None)
+    pricer = sv.LogSVPricer()
+    n = 1 << 21
+    a, sa = pricer.model_mc_price_chain(chain, P_, nb_path=n, nb_steps=1016, seed=5)
+    b, sb = pricer.model_mc_price_chain(chain, P_, nb_path=n, nb_steps=1016, seed=5)
+    for i in range(8):
+        np.testing.assert_array_equal(a[i], b[i])
+        np.testing.assert_allclose(a[i][:21] - a[i][21:], fw[i] - kk[i], rtol=0, atol=1e-9 * fw[i])   # exact parity
+        assert np.all(np.isfinite(a[i])) and np.all(sa[i] > 0)
+    from stochvolmodels_amd.engine import get_engine
+    x, s, q = get_engine(n).get_state()
+    assert abs(np.mean(np.exp(x)) - 1.0) <= 4.0 * np.std(np.exp(x)) / np.sqrt(n)
+    assert np.all(s > 0) and np.all(q >= 0)
