@@ -18,7 +18,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
-        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        path = os.path.join(GOLDEN, name + ".npz")
+        if not os.path.exists(path):
+            pytest.skip(f"golden fixture {name}.npz not generated (tests/golden/make_golden.py)")
+        return np.load(path, allow_pickle=False)
     return load
 
 
