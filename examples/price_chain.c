@@ -1,0 +1,69 @@
+/*
+ * price_chain.c -- a plain-C host of libsvmc.so: prices a two-expiry LogSV chain and a one-expiry Heston chain by
+ * Monte Carlo on the GPU through the fused chain drivers of include/svmc.h and prints the results as JSON.
+ *
+ *   gcc -O2 -Iinclude examples/price_chain.c -o price_chain -Lstochvolmodels_amd -lsvmc \
+ *       -Wl,-rpath,$PWD/stochvolmodels_amd -lm
+ *   ./price_chain [n_path] [seed]
+ *
+ * The same chain priced through the Python host (stochvolmodels_amd.logsv_mc_chain_pricer with the same seed) gives
+ * the same numbers: tests/test_gpu_parity.py::test_c_host_example.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "svmc.h"
+
+#define CHECK(call)                                                                  \
+    do {                                                                             \
+        int rc_ = (call);                                                            \
+        if (rc_ != SVMC_OK) {                                                        \
+            fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, svmc_last_error()); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+static void print_array(const char *name, const double *a, size_t n, int last)
+{
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < n; ++i) printf("%s%.17g", i ? ", " : "", a[i]);
+    printf("]%s", last ? "" : ", ");
+}
+
+int main(int argc, char **argv)
+{
+    const size_t n_path = (argc > 1) ? (size_t)strtoull(argv[1], NULL, 10) : 65536;
+    const uint64_t seed = (argc > 2) ? strtoull(argv[2], NULL, 10) : 20240601ull;
+
+    int n_dev = 0;
+    CHECK(svmc_device_count(&n_dev));
+    CHECK(svmc_set_device(0));
+
+    /* chain: ttms 0.1 and 0.25; strikes 0.8, 1.0, 1.2 x forward; P, C, C then IP, IC, C */
+    const double ttms[2] = {0.1, 0.25}, forwards[2] = {1.0, 1.01}, discfactors[2] = {0.99, 0.98};
+    const double strikes[6] = {0.8, 1.0, 1.2, 0.8 * 1.01, 1.0 * 1.01, 1.2 * 1.01};
+    const int8_t types[6] = {SVMC_PUT, SVMC_CALL, SVMC_CALL, SVMC_INV_PUT, SVMC_INV_CALL, SVMC_CALL};
+    const size_t offsets[3] = {0, 3, 6};
+    double prices[6], stderrs[6];
+
+    svmc_session_t session;
+    CHECK(svmc_session_create(&session, n_path, 2, 6));
+
+    /* LOGSV_BTC_PARAMS of the reference (pricers/logsv_pricer.py:102) */
+    CHECK(svmc_logsv_chain_price(session, ttms, forwards, discfactors, NULL, 2, strikes, types, offsets,
+                                 0.8376, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, /*spot measure*/ 1,
+                                 /*steps per year*/ 120, SVMC_LOG_RETURN, seed, 0, prices, stderrs));
+    printf("{\"svmc_version\": %d, \"n_path\": %zu, ", svmc_version(), n_path);
+    print_array("logsv_prices", prices, 6, 0);
+    print_array("logsv_stderrs", stderrs, 6, 0);
+
+    /* Heston, the reference's default parameters (pricers/heston_pricer.py:36-40), Euler scheme, first expiry only */
+    CHECK(svmc_heston_chain_price(session, ttms, forwards, discfactors, 1, strikes, types, offsets, 0.04, 0.04, 4.0, -0.5,
+                                  0.4, SVMC_HESTON_EULER_FLOOR, 360, SVMC_LOG_RETURN, seed, 0, prices, stderrs));
+    print_array("heston_prices", prices, 3, 0);
+    print_array("heston_stderrs", stderrs, 3, 1);
+    printf("}\n");
+
+    CHECK(svmc_session_destroy(session));
+    return 0;
+}

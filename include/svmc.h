@@ -57,7 +57,8 @@ extern "C" {
 #define SVMC_HESTON_EULER_FLOOR 0 /* the reference's scheme, pricers/heston_pricer.py:373-379 */
 #define SVMC_HESTON_QE 1          /* Andersen QE-M; new capability */
 
-typedef void *svmc_stream_t; /* hipStream_t */
+typedef void *svmc_stream_t;  /* hipStream_t */
+typedef void *svmc_session_t; /* opaque: one GPU's resident chain-pricing buffers */
 typedef void *svmc_event_t;  /* hipEvent_t */
 
 /* ---- library / device plumbing (no reference counterpart: the reference is single-process NumPy) -- */
@@ -179,6 +180,34 @@ SVMC_API int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path
                      void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes,
                          double discfactor, double n_path_total, double *prices_host, double *stderrs_host);
+
+/* ---- fused single-GPU chain drivers: one call per option chain -----------------------------------------------
+ * logsv_mc_chain_pricer (pricers/logsv_pricer.py:806-867) and heston_mc_chain_pricer (pricers/heston_pricer.py:
+ * 285-331) as host C++ over the kernels above.  A session owns the resident state / snapshot / scratch buffers of
+ * n_path paths on the current device and its own stream; chains of up to max_expiries maturities and
+ * max_strikes_total strikes can be priced with it, any number of times.  Chain arrays are HOST arrays in the
+ * reference's layout: ttms / forwards / discfactors [n_expiries], strikes and int8 payoff codes concatenated over the
+ * expiries with strike_offsets[n_expiries + 1] delimiting each slice; prices / stderrs come back in the same
+ * concatenated layout.  nb_steps_per_year is the reference's rule nb_steps_i = int((T_i - T_{i-1}) * spy) + 1
+ * (utils/funcs.py:44).  vol_backbone_etas_host may be NULL (ones).  svmc_session_state copies the terminal state out
+ * (x, sigma | variance, qvar; any pointer may be NULL).  The multi-GPU case is driven from the host mirror
+ * (stochvolmodels_amd/mc_chain.py), which places the two all-reduces between the same kernels. */
+SVMC_API int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total);
+SVMC_API int svmc_session_destroy(svmc_session_t session);
+SVMC_API int svmc_session_state(svmc_session_t session, double *x_host, double *vol_host, double *qvar_host);
+SVMC_API int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                    const double *discfactors_host, const double *vol_backbone_etas_host,
+                                    int n_expiries, const double *strikes_host, const int8_t *types_host,
+                                    const size_t *strike_offsets_host, double v0, double theta, double kappa1,
+                                    double kappa2, double beta, double volvol, int is_spot_measure,
+                                    int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
+                                    double *prices_host, double *stderrs_host);
+SVMC_API int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                     const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                     const int8_t *types_host, const size_t *strike_offsets_host, double v0,
+                                     double theta, double kappa, double rho, double volvol, int scheme,
+                                     int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
+                                     double *prices_host, double *stderrs_host);
 
 /* ---- analytic side: affine-expansion MGF + Fourier inversion ------------------
  * Complex arrays are interleaved (re, im) doubles, i.e. numpy.complex128 / C99 double complex, on the device.

@@ -17,8 +17,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libsvmc.so")
-SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip")
-HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h")
+SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip")
+HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h", "svmc_log_table.h")
 ARCH = "gfx950"
 
 

@@ -65,3 +65,16 @@ def test_no_cpu_fallback():
     with pytest.raises(SvmcError):
         sv.compute_mc_vars_payoff(x0=np.zeros(4), sigma0=np.ones(4), qvar0=np.zeros(4), ttm=1.0, forward=1.0,
                                   strikes_ttm=np.array([1.0]), optiontypes_ttm=np.array(["C"]))
+
+
+def test_c_example_compiles_and_links(tmp_path):
+    """examples/price_chain.c is a plain-C host of the library: it must compile with gcc against include/svmc.h and link
+    against libsvmc.so (it is RUN by the gpu suite)"""
+    from stochvolmodels_amd import build
+    lib = build.build()
+    exe = str(tmp_path / "price_chain")
+    libdir = os.path.dirname(lib)
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "price_chain.c"), "-o", exe, "-L" + libdir, "-lsvmc",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"], check=True)
+    assert os.path.exists(exe)

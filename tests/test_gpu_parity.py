@@ -648,3 +648,35 @@ def test_config_c4_btc_style_chain(sv, oracle):
     x, s, q = get_engine(n).get_state()
     assert abs(np.mean(np.exp(x)) - 1.0) <= 4.0 * np.std(np.exp(x)) / np.sqrt(n)
     assert np.all(s > 0) and np.all(q >= 0)
+
+
+def test_c_host_example(sv, tmp_path):
+    """the drop-in boundary is a C ABI: examples/price_chain.c (plain C, gcc, no Python, no torch) prices a chain through
+    the fused drivers svmc_logsv_chain_price / svmc_heston_chain_price; the Python host with the same seed must give
+    the same prices (same kernels, same order of launches)"""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "price_chain")
+    libdir = os.path.join(root, "stochvolmodels_amd")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "price_chain.c"),
+                    "-o", exe, "-L" + libdir, "-lsvmc", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"],
+                   check=True)
+    out = json.loads(subprocess.run([exe, "65536", "123"], check=True, capture_output=True, text=True).stdout)
+    P_ = sv.LOGSV_BTC_PARAMS
+    ttms, fw, df = np.array([0.1, 0.25]), np.array([1.0, 1.01]), np.array([0.99, 0.98])
+    kk = np.array([0.8, 1.0, 1.2])
+    strikes = (kk, 1.01 * kk)
+    types = (np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"]))
+    pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes, optiontypes_ttms=types,
+                                      v0=P_.sigma0, theta=P_.theta, kappa1=P_.kappa1, kappa2=P_.kappa2, beta=P_.beta,
+                                      volvol=P_.volvol, vol_backbone_etas=np.ones(2), nb_path=65536, nb_steps_per_year=120,
+                                      seed=123)
+    np.testing.assert_array_equal(np.concatenate(pr), out["logsv_prices"])
+    np.testing.assert_array_equal(np.concatenate(sd), out["logsv_stderrs"])
+    pr, sd = sv.heston_mc_chain_pricer(ttms=ttms[:1], forwards=fw[:1], discfactors=df[:1], strikes_ttms=strikes[:1],
+                                       optiontypes_ttms=types[:1], v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4,
+                                       nb_path=65536, seed=123)
+    np.testing.assert_array_equal(pr[0], out["heston_prices"])
+    np.testing.assert_array_equal(sd[0], out["heston_stderrs"])
