@@ -16,6 +16,11 @@ constexpr int MAX_REDUCE_GRID = 1024;  // 256 CUs x 4 blocks: cap for grid-strid
 constexpr int KC = 8;                  // strikes per payoff block (register accumulators: 3 doubles per strike)
 constexpr int KMAX = 32;               // strikes per payoff launch (grid.y = ceil(k / KC) chunks)
 
+// block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
+// 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
+static constexpr int rng_block() { return BLOCK; }
+static inline unsigned rng_grid(size_t n) { return static_cast<unsigned>((n + rng_block() - 1) / rng_block()); }
+
 static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -77,7 +82,7 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* 
 {
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) lds[wave * NV + j] = v[j];
@@ -85,7 +90,9 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* 
     __syncthreads();
     if (static_cast<int>(threadIdx.x) < n_out) {
         const int j = threadIdx.x;
-        out[j] = ((lds[j] + lds[NV + j]) + lds[2 * NV + j]) + lds[3 * NV + j];
+        double t = lds[j];
+        for (int w = 1; w < n_waves; ++w) t += lds[w * NV + j];      // fixed order: wave 0, 1, 2, 3
+        out[j] = t;
     }
 }
 
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 {
     __shared__ LogTabEntry s_tab[256];
     const LogTabEntry *tab = stage_log_table(s_tab);
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
     if (active) {
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
 {
     __shared__ LogTabEntry s_tab[256];
     const LogTabEntry *tab = stage_log_table(s_tab);
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
     if (active) {
@@ -476,7 +483,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (n_path == 0) return SVMC_OK;
     const LogsvFast c = make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure));
-    hipLaunchKernelGGL(logsv_rng_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
+    hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
                        n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
     return check_launch(fn);
 }
@@ -486,7 +493,7 @@ static int finish_slice_sums(const char *fn, size_t n_path, double *spot_sums, v
                              svmc_stream_t stream)
 {
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
-                       static_cast<const double *>(workspace), static_cast<int>(grid_for(n_path)), 2, spot_sums);
+                       static_cast<const double *>(workspace), static_cast<int>(rng_grid(n_path)), 2, spot_sums);
     (void)workspace_bytes;
     return check_launch(fn);
 }
@@ -496,7 +503,7 @@ static int check_slice_args(const char *fn, size_t n_path, const double *x_snaps
 {
     if (x_snapshot == nullptr || spot_sums == nullptr || workspace == nullptr)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot / spot_sums / workspace");
-    if (workspace_bytes < static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double))
+    if (workspace_bytes < static_cast<size_t>(rng_grid(n_path)) * 2 * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
     return SVMC_OK;
 }
@@ -579,10 +586,10 @@ static int heston_rng_launch(const char *fn, double *x, double *var, double *qva
     const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
     const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
     if (scheme == SVMC_HESTON_QE)
-        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream),
                            x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so);
     else
-        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(grid_for(n_path)), dim3(BLOCK), 0,
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(rng_grid(n_path)), dim3(rng_block()), 0,
                            as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id),
                            path_offset, step_offset, so);
     return check_launch(fn);
@@ -652,7 +659,7 @@ int svmc_payoff_workspace_bytes(size_t *bytes)
 int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
-    const size_t fused = static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double);
+    const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * sizeof(double);
     const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KMAX * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;
