@@ -89,7 +89,7 @@ def cpu_baseline_all_cores(nb_steps: int, params) -> dict:
     serial), but the fairest CPU number for the GPU kernel's own algorithm."""
     from oracle import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = oracle.set_threads(oracle.effective_cores())      # affinity capped by the cgroup quota
     n = min(1 << 22, max(1 << 14, (cores * (1 << 13))))
     x0, s0, q0 = np.zeros(n), params.sigma0 * np.ones(n), np.zeros(n)
     t0 = time.perf_counter()
@@ -97,7 +97,7 @@ def cpu_baseline_all_cores(nb_steps: int, params) -> dict:
                               params.beta, params.volvol, 7)
     t = time.perf_counter() - t0
     return {"value": n * nb_steps / t, "unit": "path-steps/s", "cores": cores, "kind": "port (counter-based draw, OpenMP)",
-            "sample": f"{n} paths x {nb_steps} steps, stepping only, {t:.1f}s"}
+            "sample": f"{n} paths x {nb_steps} steps, stepping only, {t:.1f}s; os.cpu_count() = {os.cpu_count()}"}
 
 
 def pmc_traffic(kernel: str, n_paths: int, nb_steps: int):

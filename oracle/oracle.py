@@ -81,6 +81,32 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(_dp)
 
 
+def effective_cores() -> int:
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_threads(n: int) -> int:
+    lib().svo_set_threads.argtypes = [C.c_int]
+    lib().svo_set_threads.restype = C.c_int
+    return lib().svo_set_threads(int(n))
+
+
 def _state(*arrs) -> Tuple[np.ndarray, ...]:
     return tuple(np.array(a, dtype=np.float64, order="C", copy=True) for a in arrs)
 

@@ -14,6 +14,21 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* thread count of the OpenMP loops (bench.py's all-host-cores CPU baseline); returns the count in effect */
+int svo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------------
  * utils/funcs.py:24-48 set_time_grid

@@ -29,6 +29,8 @@ enum { SVO_LOG_RETURN = 1, SVO_Q_VAR = 2, SVO_SIGMA = 3 };
 /* Heston discretisation */
 enum { SVO_HESTON_EULER_FLOOR = 0, SVO_HESTON_QE = 1 };
 
+int svo_set_threads(int n);
+
 /* utils/funcs.py:24-48  set_time_grid */
 void svo_set_time_grid(double ttm, int nb_steps_per_year, int *nb_steps, double *dt);
 
