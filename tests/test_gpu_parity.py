@@ -680,3 +680,29 @@ def test_c_host_example(sv, tmp_path):
                                        nb_path=65536, seed=123)
     np.testing.assert_array_equal(pr[0], out["heston_prices"])
     np.testing.assert_array_equal(sd[0], out["heston_stderrs"])
+
+
+def test_reference_heston_and_logsv_mc_ci_tests(sv):
+    """the reference's own end-to-end MC tests, run verbatim against this package:
+    tests/test_heston_characterization.py:269-292 (analytic Heston inside the seeded 40 000-path MC confidence interval)
+    and tests/test_logsv_characterization.py:605-635 (un-fixed LogSV MC, 512 paths: finite, non-negative)"""
+    chain = sv.OptionChain.slice_to_chain(ttm=0.25, forward=1.0, strikes=np.array([0.9, 1.0, 1.1]),
+                                          optiontypes=np.array(["P", "C", "C"]), discfactor=0.98, id="3m")
+    params = sv.HestonParams(v0=0.04, theta=0.05, kappa=2.0, rho=-0.5, volvol=0.4)
+    analytic = np.asarray(sv.HestonPricer().price_chain(chain, params)[0])
+    sv.set_seed(123)
+    mc_prices, mc_errors = sv.HestonPricer().model_mc_price_chain(chain, params, nb_path=40_000)
+    mc_prices, mc_errors = np.asarray(mc_prices[0]), np.asarray(mc_errors[0])
+    assert np.all(np.isfinite(mc_prices)) and np.all(np.isfinite(mc_errors)) and np.all(mc_errors > 0.0)
+    assert np.all(np.abs(analytic - mc_prices) <= 4.0 * mc_errors)
+
+    chain = sv.OptionChain.slice_to_chain(ttm=0.02, forward=1.0, strikes=np.array([0.9, 1.0, 1.1]),
+                                          optiontypes=np.array(["P", "C", "C"]), discfactor=0.99, id="short")
+    p = sv.LogSvParams(sigma0=0.2, theta=0.22, kappa1=3.0, kappa2=12.0, beta=-0.3, volvol=0.4)
+    prices, errors = sv.logsv_mc_chain_pricer(ttms=chain.ttms, forwards=chain.forwards, discfactors=chain.discfactors,
+                                              strikes_ttms=chain.strikes_ttms, optiontypes_ttms=chain.optiontypes_ttms,
+                                              v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta,
+                                              volvol=p.volvol, vol_backbone_etas=p.get_vol_backbone_etas(chain.ttms),
+                                              nb_path=512, nb_steps_per_year=360)
+    assert np.all(np.isfinite(prices[0])) and np.all(np.asarray(prices[0]) >= 0.0)
+    assert np.all(np.isfinite(errors[0])) and np.all(np.asarray(errors[0]) >= 0.0)
