@@ -99,6 +99,21 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* 
 // ---------------------------------------------------------------------------------------------------
 // LogSV generators (pricers/logsv_pricer.py:950-1047)
 // ---------------------------------------------------------------------------------------------------
+// Least-progress-first wave priority.  The SIMD arbiter picks by priority, then age; with equal priorities the
+// oldest wave always wins, younger waves starve and each launch ends in a long ramp-down where lone, late waves run
+// at ~60 % of the saturated rate (tools/ubench/tail_probe.hip).  Dropping a wave's own priority as it progresses
+// through the time loop (3 -> 0 at the quarter points) lets waves that are behind catch up: residency stays at 8
+// waves per SIMD and the ramp-down shrinks from ~30 % to ~10 % of the launch.
+__device__ __forceinline__ void progress_priority(int stage)
+{
+    switch (stage) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
+
 // Optional slice epilogue fused into the stepping kernels: the terminal x (and qvar) is also written to the
 // per-expiry snapshot the payoff pass reads, and the block's [sum F*exp(x), count] goes to partials[block][2]
 // (utils/mc_payoffs.py:61-62) -- one launch and one pass over x less per expiry.
@@ -124,7 +139,7 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
     }
 }
 
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
@@ -141,7 +156,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         double L = log(s);                                                                      // :1039
         double s2 = s * s;
         const uint64_t gp = path_offset + p;
+        const int quarter = (nb_steps + 3) >> 2;
+        int stage = 0, next_stage_t = 0;
         for (int t = 0; t < nb_steps; ++t) {
+            if (t == next_stage_t) {                       // wave-uniform
+                progress_priority(stage++);
+                next_stage_t += quarter;
+            }
             double z0, z1;
             draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
             logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
