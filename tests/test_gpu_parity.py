@@ -706,3 +706,31 @@ def test_reference_heston_and_logsv_mc_ci_tests(sv):
                                               nb_path=512, nb_steps_per_year=360)
     assert np.all(np.isfinite(prices[0])) and np.all(np.asarray(prices[0]) >= 0.0)
     assert np.all(np.isfinite(errors[0])) and np.all(np.asarray(errors[0]) >= 0.0)
+
+
+def test_payoff_randomised_against_numpy_semantics(sv, oracle):
+    """compute_mc_vars_payoff on 60 random slices -- ragged sizes, all four payoff codes, both variable types, NaN / +-inf
+    injected into x and qvar -- against the NumPy restatement of the reference (nanmean / nanstd / where semantics)"""
+    rng = np.random.default_rng(2024)
+    import warnings
+    for trial in range(60):
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, 1000, 4097, 20011]))
+        x = 0.5 * rng.standard_normal(n) - 0.1
+        q = 0.3 * np.exp(0.7 * rng.standard_normal(n))
+        if trial % 3 == 1 and n > 3:
+            idx = rng.choice(n, size=max(1, n // 50), replace=False)
+            x[idx] = rng.choice([np.nan, -np.inf], size=idx.size)          # +inf makes every spot NaN: tested in golden
+            q[rng.choice(n, size=max(1, n // 70), replace=False)] = np.nan
+        k = int(rng.integers(1, 40))
+        vt = int(rng.choice([1, 2]))
+        fwd = float(rng.uniform(0.5, 3.0))
+        strikes = (fwd if vt == 1 else 0.3) * rng.uniform(0.4, 1.8, k)
+        types = rng.choice(["C", "P", "IC", "IP"], size=k)
+        df, ttm = float(rng.uniform(0.8, 1.0)), float(rng.uniform(0.05, 2.0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            epr, esd = oracle.np_payoff(x, q, ttm, fwd, strikes, types, df, vt)
+        pr, sd = sv.compute_mc_vars_payoff(x0=x, sigma0=np.ones(n), qvar0=q, ttm=ttm, forward=fwd, strikes_ttm=strikes,
+                                           optiontypes_ttm=types, discfactor=df, variable_type=sv.VariableType(vt))
+        np.testing.assert_allclose(pr, epr, rtol=1e-10, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
+        np.testing.assert_allclose(sd, esd, rtol=1e-8, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
