@@ -72,10 +72,13 @@ class HestonPricer(ModelPricer):
     def simulate_terminal_values(self, params: HestonParams, ttm: float = 1.0, nb_path: int = 100000,
                                  x0: float = 0.0, **kwargs) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """returns (x, VARIANCE, qvar) like the reference (:89-108); the x0 argument is ignored there too."""
-        return simulate_heston_x_vol_terminal(ttm=ttm, x0=np.zeros(nb_path), var0=params.v0 * np.ones(nb_path),
-                                              qvar0=np.zeros(nb_path), theta=params.theta, kappa=params.kappa,
-                                              rho=params.rho, volvol=params.volvol, nb_path=nb_path,
-                                              scheme=kwargs.get("scheme", "euler"), seed=kwargs.get("seed"))
+        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=360)
+        rng_seed, call_id = next_rng_call(kwargs.get("seed"))
+        eng = get_engine(nb_path)
+        eng.fill_state(0.0, params.v0, 0.0)           # constant initial state written on the device (reference :98-107)
+        eng.heston_rng(nb_steps, dt, params.theta, params.kappa, params.rho, params.volvol,
+                       _scheme_code(kwargs.get("scheme", "euler")), rng_seed, call_id, 0)
+        return eng.get_state()
 
 
 def compute_heston_mgf_grid(v0: float, theta: float, kappa: float, volvol: float, rho: float, ttm: float,

@@ -75,11 +75,15 @@ class LogSVPricer(ModelPricer):
     def simulate_terminal_values(self, params: LogSvParams, ttm: float = 1.0, nb_path: int = 100000,
                                  is_spot_measure: bool = True, **kwargs
                                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        return simulate_logsv_x_vol_terminal(ttm=ttm, x0=np.zeros(nb_path), sigma0=params.sigma0 * np.ones(nb_path),
-                                             qvar0=np.zeros(nb_path), theta=params.theta, kappa1=params.kappa1,
-                                             kappa2=params.kappa2, beta=params.beta, volvol=params.volvol,
-                                             nb_path=nb_path, is_spot_measure=is_spot_measure,
-                                             seed=kwargs.get("seed"))
+        # same as simulate_logsv_x_vol_terminal(x0=zeros, sigma0=sigma0*ones, qvar0=zeros, ...) (reference :600-610),
+        # with the constant initial state written on the device instead of uploaded
+        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=360)
+        rng_seed, call_id = next_rng_call(kwargs.get("seed"))
+        eng = get_engine(nb_path)
+        eng.fill_state(0.0, params.sigma0, 0.0)
+        eng.logsv_rng(nb_steps, dt, params.theta, params.kappa1, params.kappa2, params.beta, params.volvol, 1.0,
+                      is_spot_measure, rng_seed, call_id, 0)
+        return eng.get_state()
 
 
 def set_vol_scaler(sigma0: float, ttm: float) -> float:
