@@ -90,7 +90,7 @@ def cpu_baseline_all_cores(nb_steps: int, params) -> dict:
     from oracle import oracle
     oracle.build()
     cores = oracle.set_threads(oracle.effective_cores())      # affinity capped by the cgroup quota
-    n = min(1 << 22, max(1 << 14, (cores * (1 << 13))))
+    n = min(1 << 22, max(1 << 14, (cores * (1 << 16))))
     x0, s0, q0 = np.zeros(n), params.sigma0 * np.ones(n), np.zeros(n)
     t0 = time.perf_counter()
     oracle.logsv_terminal_rng(x0, s0, q0, nb_steps, 1.0 / nb_steps, params.theta, params.kappa1, params.kappa2,
