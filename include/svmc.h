@@ -139,6 +139,21 @@ SVMC_API int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int
                                   int is_spot_measure, const double *brownians, size_t ldb, uint64_t seed,
                                   uint32_t call_id, uint64_t path_offset, svmc_stream_t stream);
 
+/* ---- rough LogSV (Markovian lift, n_factors <= 3): log_spot_full_combined_f64, pricers/rough_logsv/
+ * split_simulation.py:335-356 (Strang splitting :249-278 over drift_ode_solve2 :86-128 and diffus_sde_solve_f64
+ * :228-246; log-spot update :281-332).  In-place advance of (log_s[n], vol[n_factors][n], qvar[n]) over nb_steps of
+ * size h.  nodes / weights / v0 are HOST arrays of n_factors entries (v0 = the factors' fixed reference level,
+ * sigma0 / sum(weights) in the chain pricer :1187).  Z0 (factors) and Z1 (spot) are UNSCALED N(0,1), [nb_steps][ldw],
+ * the reference's only interface for this model; pass both NULL to draw them on device (stream 3 of the
+ * counter-based generator).  from_origin != 0 starts every path at (0, v0, 0) instead of reading the state arrays
+ * (the chain pricer re-simulates each expiry from time 0, :1206-1216).  rho = beta / volvol, volvol = sqrt(beta^2 + orthog_vol^2) (:1190-1191). */
+SVMC_API int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
+                                       int n_factors, const double *nodes_host, const double *weights_host,
+                                       const double *v0_host, double theta, double kappa1, double kappa2, double rho,
+                                       double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
+                                       uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
+                                       svmc_stream_t stream);
+
 /* ---- Heston generator: simulate_heston_x_vol_terminal, pricers/heston_pricer.py:334-381 ----------
  * `var` is the variance (the reference returns variance, not vol).  scheme = SVMC_HESTON_EULER_FLOOR
  * reproduces the reference (Euler, floor max(v, 1e-4)); SVMC_HESTON_QE is Andersen's QE-M. */

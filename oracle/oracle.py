@@ -31,7 +31,7 @@ _lib = None
 def build(force: bool = False) -> str:
     """compile oracle/libsvmc_oracle.so with the committed Makefile (gcc only)."""
     src_time = max(os.path.getmtime(os.path.join(_HERE, f))
-                   for f in ("svmc_oracle.c", "svmc_oracle_analytic.c", "svmc_oracle.h", "Makefile"))
+                   for f in ("svmc_oracle.c", "svmc_oracle_analytic.c", "svmc_oracle_rough.c", "svmc_oracle.h", "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_time:
         subprocess.run(["make", "-C", _HERE, "-B", "libsvmc_oracle.so"], check=True, capture_output=True)
     return _SO
@@ -54,6 +54,7 @@ def lib() -> C.CDLL:
         L.svo_payoff.restype = i32
         L.svo_philox4x32_10.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
         L.svo_fill_normals.argtypes = [u64, u32, u64, u32, sz, i32, _dp, _dp, sz]
+        L.svo_fill_normals_stream.argtypes = [u64, u32, u32, u64, u32, sz, i32, _dp, _dp, sz]
         L.svo_fill_uniforms.argtypes = [u64, u32, u64, u32, sz, i32, _dp, sz]
         L.svo_logsv_terminal_rng.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, f64, f64, i32,
                                              u64, u32, u64, u32]
@@ -61,6 +62,9 @@ def lib() -> C.CDLL:
                                               u64, u32, u64, u32]
         L.svo_logsv_vol_paths.argtypes = [_dp, sz, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, _dp, sz, u64, u32, u64]
         L.svo_logsv_vol_paths.restype = None
+        L.svo_rough_logsv_terminal_w.argtypes = [sz, i32, f64, i32, _dp, _dp, _dp, f64, f64, f64, f64, f64, _dp, _dp, _dp,
+                                                 _dp, _dp, sz]
+        L.svo_rough_logsv_terminal_w.restype = None
         L.svo_logsv_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, f64, i32, i32, f64, _dp, _dp, f64, f64]
         L.svo_logsv_mgf_grid.restype = None
         L.svo_heston_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, _dp, _dp, i32, _dp]
@@ -70,7 +74,7 @@ def lib() -> C.CDLL:
         L.svo_mgf_vanilla_slice.argtypes = [sz, _dp, _dp, f64, sz, _dp, C.POINTER(C.c_int8), f64, i32, _dp]
         L.svo_mgf_vanilla_slice.restype = i32
         for name in ("svo_set_time_grid", "svo_logsv_terminal_w", "svo_heston_terminal_w",
-                     "svo_heston_qe_terminal_w", "svo_philox4x32_10", "svo_fill_normals",
+                     "svo_heston_qe_terminal_w", "svo_philox4x32_10", "svo_fill_normals", "svo_fill_normals_stream",
                      "svo_fill_uniforms", "svo_logsv_terminal_rng", "svo_heston_terminal_rng"):
             getattr(L, name).restype = None
         _lib = L
@@ -190,10 +194,11 @@ def philox4x32_10(ctr: Sequence[int], key: Sequence[int]) -> Tuple[int, int, int
     return tuple(int(v) for v in o)
 
 
-def fill_normals(seed, n_path, nb_steps, call_id=0, path_offset=0, step_offset=0):
+def fill_normals(seed, n_path, nb_steps, call_id=0, path_offset=0, step_offset=0, stream=0):
     W0 = np.empty((nb_steps, n_path)), np.empty((nb_steps, n_path))
     W0, W1 = W0
-    lib().svo_fill_normals(seed, call_id, path_offset, step_offset, n_path, nb_steps, _p(W0), _p(W1), n_path)
+    lib().svo_fill_normals_stream(seed, call_id, stream, path_offset, step_offset, n_path, nb_steps, _p(W0), _p(W1),
+                                  n_path)
     return W0, W1
 
 
@@ -437,3 +442,45 @@ def heston_chain_pricer(v0, theta, kappa, volvol, rho, ttms, forwards, strikes_t
         out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
         t0 = ttm
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# rough LogSV (oracle/svmc_oracle_rough.c), SURVEY.md row f.4
+# ---------------------------------------------------------------------------------------------------
+def rough_randoms(ttms, nb_path, nb_steps_per_year=360, seed=10):
+    """get_randoms_for_rough_vol_chain_valuation, pricers/logsv_pricer.py:1075-1097"""
+    rng = np.random.RandomState(seed)
+    grids = [np.linspace(0.0, t, int(t * nb_steps_per_year) + 2) for t in ttms]
+    nb_last = grids[-1].size - 1
+    Z0 = rng.normal(0, 1, size=(nb_last, nb_path))
+    Z1 = rng.normal(0, 1, size=(nb_last, nb_path))
+    return Z0, Z1, grids
+
+
+def rough_logsv_chain_fixed_randoms(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, Z0, Z1, sigma0, theta,
+                                    kappa1, kappa2, beta, orthog_vol, weights, nodes, timegrids, variable_type=LOG_RETURN,
+                                    return_states=False):
+    """rough_logsv_mc_chain_pricer_fixed_randoms, pricers/logsv_pricer.py:1164-1232: every expiry is simulated from
+    time 0 on the first nb_steps rows of Z0/Z1"""
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    n = nodes.size
+    v0 = np.full(n, sigma0 / np.sum(weights))
+    volvol = np.sqrt(beta ** 2 + orthog_vol ** 2)
+    rho = beta / volvol
+    Z0, Z1 = _w(Z0), _w(Z1)
+    nb_path = Z0.shape[1]
+    prices, stderrs, states = [], [], []
+    for ttm, F, DF, K, ty, grid in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, timegrids):
+        nb = grid.size - 1
+        h = float(grid[1] - grid[0])
+        ls, y = np.zeros(nb_path), np.zeros(nb_path)
+        vol = np.ascontiguousarray(np.repeat(v0[:, None], nb_path, axis=1))
+        lib().svo_rough_logsv_terminal_w(nb_path, nb, h, n, _p(nodes), _p(weights), _p(v0), theta, kappa1, kappa2, rho,
+                                         volvol, _p(ls), _p(vol), _p(y), _p(Z0), _p(Z1), nb_path)
+        p, e = payoff(ls, y, float(ttm), float(F), K, ty, float(DF), variable_type)
+        # the reference hands compute_mc_vars_payoff a [1, nb_path] log-spot, so its "/ sqrt(x0.shape[0])"
+        # (utils/mc_payoffs.py:88) divides by 1: the second return is the payoff's std, not its standard error
+        e = e * np.sqrt(nb_path)
+        prices.append(p), stderrs.append(e), states.append((ls, vol, y))
+    return (prices, stderrs, states) if return_states else (prices, stderrs)

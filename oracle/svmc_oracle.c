@@ -369,6 +369,16 @@ void svo_fill_normals(uint64_t seed, uint32_t call_id, uint64_t path_offset, uin
                              &W0[(size_t)t * ldw + p], &W1[(size_t)t * ldw + p]);
 }
 
+/* same generator on a named stream tag (3 = the rough-LogSV kernel's device-side normals) */
+void svo_fill_normals_stream(uint64_t seed, uint32_t call_id, uint32_t stream, uint64_t path_offset,
+                             uint32_t step_offset, size_t n_path, int nb_steps, double *W0, double *W1, size_t ldw)
+{
+    for (int t = 0; t < nb_steps; ++t)
+        for (size_t p = 0; p < n_path; ++p)
+            draw_normals_stream(seed, call_id, path_offset + p, step_offset + (uint32_t)t, stream,
+                                &W0[(size_t)t * ldw + p], &W1[(size_t)t * ldw + p]);
+}
+
 void svo_fill_uniforms(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
                        size_t n_path, int nb_steps, double *U, size_t ldw)
 {

@@ -77,6 +77,8 @@ double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t
 
 /* Materialise the streams the kernels consume: W0/W1[t*ldw + p] for global path ids
  * path_offset + p, global step ids step_offset + t. */
+void svo_fill_normals_stream(uint64_t seed, uint32_t call_id, uint32_t stream, uint64_t path_offset,
+                             uint32_t step_offset, size_t n_path, int nb_steps, double *W0, double *W1, size_t ldw);
 void svo_fill_normals(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
                       size_t n_path, int nb_steps, double *W0, double *W1, size_t ldw);
 void svo_fill_uniforms(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
@@ -99,6 +101,12 @@ void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
                          double theta, double kappa1, double kappa2, double beta, double volvol,
                          int is_spot_measure, const double *brownians, size_t ldb,
                          uint64_t seed, uint32_t call_id, uint64_t path_offset);
+
+/* ---- rough LogSV (svmc_oracle_rough.c): pricers/rough_logsv/split_simulation.py:335-356; vol is [n_factors][n_path] */
+void svo_rough_logsv_terminal_w(size_t n_path, int nb_steps, double h, int n_factors, const double *nodes,
+                                const double *weights, const double *v0, double theta, double kappa1, double kappa2,
+                                double rho, double volvol, double *log_s, double *vol, double *y, const double *Z0,
+                                const double *Z1, size_t ldw);
 
 /* ---- analytic side (svmc_oracle_analytic.c); complex arrays are interleaved (re, im) like numpy.complex128 ---- */
 void svo_logsv_mgf_grid(size_t n_grid, const double *phi, const double *psi, double ttm, double sigma0, double theta,

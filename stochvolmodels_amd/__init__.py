@@ -32,6 +32,9 @@ _EXPORTS = {
     "simulate_vol_paths": "pricers.logsv_pricer",
     "get_randoms_for_chain_valuation": "pricers.logsv_pricer",
     "upload_fixed_randoms": "pricers.logsv_pricer",
+    "get_randoms_for_rough_vol_chain_valuation": "pricers.logsv_pricer",
+    "rough_logsv_mc_chain_pricer_fixed_randoms": "pricers.logsv_pricer",
+    "rough_logsv_mc_chain_pricer": "pricers.logsv_pricer",
     "logsv_chain_pricer": "pricers.logsv_pricer", "set_vol_scaler": "pricers.logsv_pricer",
     "ExpansionOrder": "pricers.logsv.affine_expansion", "compute_logsv_a_mgf_grid": "pricers.logsv.affine_expansion",
     "heston_chain_pricer": "pricers.heston_pricer", "compute_heston_mgf_grid": "pricers.heston_pricer",

@@ -278,6 +278,139 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Rough LogSV, Markovian lift with N <= 3 factors (pricers/rough_logsv/split_simulation.py:86-128, 228-356):
+// Strang splitting D(h/2) S(h) D(h/2) per step -- RK4 on the factor drift, exact lognormal step of the weighted
+// factor sum -- then the log-spot / quadratic-variance update.  One lane per path, the N factors in registers.
+// ---------------------------------------------------------------------------------------------------
+struct RoughConsts {
+    double nodes[3], w[3], v0[3], wlam[3];
+    double theta, kappa1, kappa2, rho, rho_comp, volvol, inv_volvol, h, sqrt_h, wsum, w_inv, volvol_w, w_lam_v0;
+};
+
+template <int N>
+__device__ __forceinline__ void rough_rk4_drift(const RoughConsts &c, const double (&z0)[N], double h, double (&zh)[N])
+{
+    double s1[N], s2[N], s3[N], s4[N], zt[N], zw, g;
+    zw = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) zw += c.w[i] * z0[i];
+    g = (c.kappa1 + c.kappa2 * zw) * (c.theta - zw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s1[i] = -c.nodes[i] * (z0[i] - c.v0[i]) + g;                         // :101-103
+    zw = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        zt[i] = z0[i] + 0.5 * h * s1[i];
+        zw += c.w[i] * zt[i];
+    }
+    g = (c.kappa1 + c.kappa2 * zw) * (c.theta - zw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s2[i] = -c.nodes[i] * (zt[i] - c.v0[i]) + g;                         // :106-109
+    zw = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        zt[i] = z0[i] + 0.5 * h * s2[i];
+        zw += c.w[i] * zt[i];
+    }
+    g = (c.kappa1 + c.kappa2 * zw) * (c.theta - zw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s3[i] = -c.nodes[i] * (zt[i] - c.v0[i]) + g;                         // :112-115
+    zw = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        zt[i] = z0[i] + h * s3[i];
+        zw += c.w[i] * zt[i];
+    }
+    g = (c.kappa1 + c.kappa2 * zw) * (c.theta - zw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) s4[i] = -c.nodes[i] * (zt[i] - c.v0[i]) + g;                         // :118-121
+#pragma unroll
+    for (int i = 0; i < N; ++i) zh[i] = z0[i] + (h / 6.0) * (s1[i] + 2.0 * s2[i] + 2.0 * s3[i] + s4[i]);
+}
+
+template <int N>
+__device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N], double &ls, double &y, double z0, double z1)
+{
+    double d[N], sn[N], vh[N];
+    rough_rk4_drift<N>(c, v, 0.5 * c.h, d);                                                      // :273
+    double yw = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) yw += c.w[i] * d[i];
+    const double Yh = yw * exp(-0.5 * c.volvol_w * c.volvol_w * c.h + c.volvol_w * (z0 * c.sqrt_h));   // :238-239
+    const double Q = c.w_inv * (Yh - yw);
+#pragma unroll
+    for (int i = 0; i < N; ++i) sn[i] = d[i] + Q;
+    rough_rk4_drift<N>(c, sn, 0.5 * c.h, vh);                                                    // :275
+    double volw_h = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) volw_h += c.w[i] * vh[i];
+    if (!(volw_h > 0.0)) {                                                                       // NaN or <= 0, :299-300
+        volw_h = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            vh[i] = 1e-6;
+            volw_h += c.w[i] * vh[i];
+        }
+    }
+    double vw = 0.0, w_lam_vol = 0.0, w_lam_vol_h = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        vw += c.w[i] * v[i];
+        w_lam_vol += c.wlam[i] * v[i];
+        w_lam_vol_h += c.wlam[i] * vh[i];
+    }
+    const double sq_vw = vw * vw, sq_vhw = volw_h * volw_h;
+    const double term1 = c.inv_volvol * (((volw_h - vw) / c.h + 0.5 * w_lam_vol + 0.5 * w_lam_vol_h - c.w_lam_v0) * c.w_inv
+                                         - c.kappa1 * c.theta + (c.kappa1 - c.kappa2 * c.theta) * (0.5 * vw + 0.5 * volw_h)
+                                         + c.kappa2 * (0.5 * sq_vw + 0.5 * sq_vhw)) * c.h;       // :319-321
+    const double term2 = 0.5 * c.h * sq_vw + 0.5 * c.h * sq_vhw;
+    ls = ls - 0.5 * term2 + c.rho * term1 + c.rho_comp * sqrt(term2) * z1;                         // :324
+    y = y + 0.5 * c.h * (vw * vw + volw_h * volw_h);                                               // :326
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = vh[i];
+}
+
+// RNG = false: Z0/Z1 supplied (the reference's only interface for this model); true: counter-based draw
+template <int N, bool RNG>
+__global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__ log_s, double *__restrict__ vol,
+                                                            double *__restrict__ yq, size_t n, int nb_steps,
+                                                            RoughConsts c, const double *__restrict__ Z0,
+                                                            const double *__restrict__ Z1, size_t ldw, uint64_t seed,
+                                                            uint32_t c3, uint64_t path_offset, uint32_t step_offset,
+                                                            int from_origin)
+{
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n) return;
+    double v[N], ls = 0.0, y = 0.0;
+    if (from_origin) {                       // (log_s, v, y) = (0, v0, 0): the chain pricer restarts every expiry here
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = c.v0[i];
+    } else {
+        ls = log_s[p];
+        y = yq[p];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = vol[static_cast<size_t>(i) * n + p];
+    }
+    if (RNG) {
+        const uint64_t gp = path_offset + p;
+        for (int t = 0; t < nb_steps; ++t) {
+            double z0, z1;
+            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
+            rough_step<N>(c, v, ls, y, z0, z1);
+        }
+    } else {
+        const double *const w[2] = {Z0 + p, Z1 + p};
+        streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1]); });
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];
+    log_s[p] = ls;
+    yq[p] = y;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Heston generators (pricers/heston_pricer.py:334-381; QE is new)
 // ---------------------------------------------------------------------------------------------------
 template <int SCHEME>
@@ -640,6 +773,55 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
                                    call_id, path_offset, step_offset, so, stream))
         return rc;
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+}
+
+int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
+                              int n_factors, const double *nodes_host, const double *weights_host,
+                              const double *v0_host, double theta, double kappa1, double kappa2, double rho,
+                              double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
+                              uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
+                              svmc_stream_t stream)
+{
+    const char *fn = "svmc_rough_logsv_terminal";
+    if (int rc = check_state(fn, log_s, vol, qvar, nb_steps, h)) return rc;
+    SVMC_REQUIRE(n_factors >= 1 && n_factors <= 3, "svmc_rough_logsv_terminal: 1 <= n_factors <= 3");
+    SVMC_REQUIRE(nodes_host && weights_host && v0_host, "svmc_rough_logsv_terminal: null nodes/weights/v0");
+    SVMC_REQUIRE((Z0 == nullptr) == (Z1 == nullptr), "svmc_rough_logsv_terminal: Z0 and Z1 go together");
+    SVMC_REQUIRE(Z0 == nullptr || ldw >= n_path, "svmc_rough_logsv_terminal: ldw < n_path");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_rough_logsv_terminal: call_id must fit 24 bits");
+    SVMC_REQUIRE(volvol > 0.0 && rho * rho <= 1.0, "svmc_rough_logsv_terminal: volvol > 0 and |rho| <= 1");
+    if (n_path == 0 || (nb_steps == 0 && !from_origin)) return SVMC_OK;
+    RoughConsts c{};
+    c.wsum = 0.0;
+    c.w_lam_v0 = 0.0;
+    for (int i = 0; i < n_factors; ++i) {
+        c.nodes[i] = nodes_host[i];
+        c.w[i] = weights_host[i];
+        c.v0[i] = v0_host[i];
+        c.wlam[i] = weights_host[i] * nodes_host[i];
+        c.wsum += weights_host[i];
+        c.w_lam_v0 += c.wlam[i] * v0_host[i];
+    }
+    c.theta = theta; c.kappa1 = kappa1; c.kappa2 = kappa2; c.rho = rho; c.rho_comp = sqrt(1.0 - rho * rho);
+    c.volvol = volvol; c.inv_volvol = 1.0 / volvol; c.h = h; c.sqrt_h = sqrt(h); c.w_inv = 1.0 / c.wsum;
+    c.volvol_w = volvol * c.wsum;
+    const dim3 g(grid_for(n_path)), b(BLOCK);
+    const hipStream_t st = as_stream(stream);
+    const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals
+#define SVMC_ROUGH_LAUNCH(NF)                                                                                          \
+    do {                                                                                                               \
+        if (Z0 != nullptr)                                                                                             \
+            hipLaunchKernelGGL((rough_logsv_kernel<NF, false>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0, \
+                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin);                              \
+        else                                                                                                           \
+            hipLaunchKernelGGL((rough_logsv_kernel<NF, true>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0,  \
+                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin);                              \
+    } while (0)
+    if (n_factors == 1) SVMC_ROUGH_LAUNCH(1);
+    else if (n_factors == 2) SVMC_ROUGH_LAUNCH(2);
+    else SVMC_ROUGH_LAUNCH(3);
+#undef SVMC_ROUGH_LAUNCH
+    return check_launch(fn);
 }
 
 int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,

@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
-from ..engine import DeviceRandoms, get_engine
+from ..engine import DeviceRandoms, get_engine, payoff_finalize
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
@@ -48,7 +48,23 @@ class LogSVPricer(ModelPricer):
         """price an option chain by Monte Carlo.  `nb_steps` is steps PER YEAR and defaults to
         int(360*max(ttms)) + 1, exactly the reference's rule (:427)."""
         if kwargs.get("use_rough_mc"):
-            raise NotImplementedError("the rough-volatility simulator is outside this package's scope")
+            if "seed" not in kwargs:
+                raise AssertionError("use_rough_mc requires seed=")          # reference :391
+            if params.nodes is None or params.weights is None:
+                raise ValueError("rough MC needs params.nodes / params.weights (LogSvParams.approximate_kernel)")
+            common = dict(ttms=option_chain.ttms, forwards=option_chain.forwards, discfactors=option_chain.discfactors,
+                          strikes_ttms=option_chain.strikes_ttms, optiontypes_ttms=option_chain.optiontypes_ttms,
+                          sigma0=params.sigma0, theta=params.theta, kappa1=params.kappa1, kappa2=params.kappa2,
+                          beta=params.beta, orthog_vol=params.volvol, weights=params.weights, nodes=params.nodes,
+                          variable_type=variable_type, comm=kwargs.get("comm"),
+                          normalize_stderr=bool(kwargs.get("normalize_stderr", False)))
+            if kwargs.get("device_rng"):      # addition: no host randoms at all
+                return rough_logsv_mc_chain_pricer(nb_path=nb_path, nb_steps_per_year=nb_steps or 360,
+                                                   seed=kwargs["seed"], **common)
+            Z0, Z1, grid_ttms = get_randoms_for_rough_vol_chain_valuation(ttms=option_chain.ttms, nb_path=nb_path,
+                                                                          nb_steps_per_year=nb_steps or 360,
+                                                                          seed=kwargs["seed"])
+            return rough_logsv_mc_chain_pricer_fixed_randoms(Z0=Z0, Z1=Z1, timegrids=grid_ttms, **common)
         etas = params.get_vol_backbone_etas(ttms=option_chain.ttms)
         return logsv_mc_chain_pricer(v0=params.sigma0, theta=params.theta, kappa1=params.kappa1,
                                      kappa2=params.kappa2, beta=params.beta, volvol=params.volvol,
@@ -285,3 +301,111 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance)
+
+
+# ---------------------------------------------------------------------------------------------------
+# rough LogSV (Markovian lift of the fractional kernel), reference :1075-1232
+# ---------------------------------------------------------------------------------------------------
+def get_randoms_for_rough_vol_chain_valuation(ttms: np.ndarray, nb_path: int = 100000, nb_steps_per_year: int = 360,
+                                              seed: int = 10) -> Tuple[np.ndarray, np.ndarray, List[np.ndarray]]:
+    """host randoms and per-expiry time grids, identical to the reference (:1075-1097): every expiry has its own
+    grid from 0 to T_i with int(T_i*spy)+1 steps; Z0 then Z1 of shape [nb_steps_last, nb_path] from a local
+    RandomState(seed)."""
+    rng = np.random.RandomState(seed)
+    grids = [set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)[2] for ttm in ttms]
+    nb_last = grids[-1].size - 1
+    Z0 = rng.normal(0, 1, size=(nb_last, nb_path))
+    Z1 = rng.normal(0, 1, size=(nb_last, nb_path))
+    return Z0, Z1, grids
+
+
+def _rough_finalize(normalize_stderr: bool):
+    """The reference passes a [1, nb_path] log-spot to compute_mc_vars_payoff, whose "/ sqrt(x0.shape[0])"
+    (utils/mc_payoffs.py:88) then divides by 1: its second return is the payoff's standard deviation.  Reproduced
+    by default; normalize_stderr=True returns the standard error instead."""
+    if normalize_stderr:
+        return payoff_finalize
+
+    def finalize(sums, shifts, discfactor, n_path_total):
+        p, e = payoff_finalize(sums, shifts, discfactor, n_path_total)
+        return p, e * np.sqrt(n_path_total)
+    return finalize
+
+
+def _rough_coefficients(sigma0, beta, orthog_vol, weights, nodes):
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+    if not (weights.ndim == 1 and weights.shape == nodes.shape):
+        raise AssertionError("weights and nodes must be 1-d arrays of one shape")      # reference :1188
+    if not 1 <= nodes.size <= 3:
+        raise NotImplementedError("the Markovian lift is built for 1 to 3 factors (LogSvParams.approximate_kernel)")
+    v0 = np.full(nodes.size, sigma0 / np.sum(weights))
+    volvol = float(np.sqrt(beta ** 2 + orthog_vol ** 2))
+    return weights, nodes, v0, float(beta / volvol), volvol
+
+
+def rough_logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
+                                              strikes_ttms: Sequence[np.ndarray],
+                                              optiontypes_ttms: Sequence[np.ndarray], Z0: np.ndarray, Z1: np.ndarray,
+                                              sigma0: float, theta: float, kappa1: float, kappa2: float, beta: float,
+                                              orthog_vol: float, weights: np.ndarray, nodes: np.ndarray,
+                                              timegrids: Sequence[np.ndarray],
+                                              variable_type: VariableType = VariableType.LOG_RETURN,
+                                              debug: bool = False, comm=None, normalize_stderr: bool = False
+                                              ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """rough-LogSV chain on supplied N(0,1) draws (reference :1164-1232).  Z0/Z1 go to HBM once (this rank's path
+    columns); every expiry is then one kernel that re-simulates from time 0 over the first len(timegrid_i)-1 rows
+    with step timegrid_i[1]-timegrid_i[0], exactly as the reference does."""
+    variable_type_code(variable_type)
+    weights, nodes, v0, rho, volvol = _rough_coefficients(sigma0, beta, orthog_vol, weights, nodes)
+    comm = comm or svdist.get_default_comm()
+    Z0, Z1 = np.asarray(Z0), np.asarray(Z1)
+    if Z0.ndim != 2 or Z0.shape != Z1.shape:
+        raise ValueError("Z0 and Z1 must both have shape [nb_steps, nb_path]")
+    nb_path = Z0.shape[1]
+    nbs = [int(np.asarray(g).size) - 1 for g in timegrids]
+    if len(nbs) != len(ttms) or max(nbs) > Z0.shape[0] or min(nbs) < 1:
+        raise ValueError("one time grid per maturity, each with at most Z0.shape[0] steps")
+    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    eng = get_engine(n_local, path_offset=offset)
+    z0, z1 = eng.upload_randoms((Z0[:max(nbs)], Z1[:max(nbs)]), col0=offset)
+
+    def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
+        h = float(timegrids[i][1] - timegrids[i][0])
+        eng.rough_logsv(nbs[i], h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0, z1)
+        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+        if debug:
+            x, _, _ = eng.get_state()
+            vw = weights @ eng.get_factors(nodes.size)
+            print(f"Number of paths with negative vol: {np.sum(vw < 0.0)}, nan vol: {np.count_nonzero(np.isnan(vw))}")
+            print(f"Mean spot Strand: {np.mean(np.exp(x))}, nan spots: {np.count_nonzero(np.isnan(x))}")
+
+    return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr))
+
+
+def rough_logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
+                                strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray],
+                                sigma0: float, theta: float, kappa1: float, kappa2: float, beta: float,
+                                orthog_vol: float, weights: np.ndarray, nodes: np.ndarray, nb_path: int = 100000,
+                                nb_steps_per_year: int = 360, variable_type: VariableType = VariableType.LOG_RETURN,
+                                seed: Optional[int] = None, comm=None, normalize_stderr: bool = False
+                                ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """addition (no reference counterpart): the same chain with the N(0,1) draws generated in the kernel (stream 3 of
+    the counter-based generator), so nothing but the chain itself crosses PCIe.  Expiry i uses the draws of steps
+    0..nb_steps_i-1, i.e. the same nesting of randoms over expiries as the fixed-randoms pricer."""
+    variable_type_code(variable_type)
+    weights, nodes, v0, rho, volvol = _rough_coefficients(sigma0, beta, orthog_vol, weights, nodes)
+    comm = comm or svdist.get_default_comm()
+    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    eng = get_engine(n_local, path_offset=offset)
+    rng_seed, call_id = next_rng_call(seed)
+    grids = [set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)[:2] for ttm in ttms]
+
+    def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
+        nb, h = grids[i]
+        eng.rough_logsv(nb, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, seed=rng_seed, call_id=call_id)
+        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+
+    return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr))

@@ -422,6 +422,47 @@ def g_analytic_qvar():
     save("analytic_qvar", **out)
 
 
+# -- f.4: rough LogSV (pricers/rough_logsv/split_simulation.py, pricers/logsv_pricer.py:1164-1232) --------------
+def g_rough():
+    import stochvolmodels as svm
+    from stochvolmodels.pricers.rough_logsv.split_simulation import log_spot_full_combined
+    chain = svm.get_btc_test_chain_data()                     # data/sample_option_chains.py:79-134 (4 expiries)
+    out = dict(ttms=chain.ttms, forwards=chain.forwards, discfactors=chain.discfactors)
+    for i, (k, t) in enumerate(zip(chain.strikes_ttms, chain.optiontypes_ttms)):
+        out[f"strikes_{i}"], out[f"types_{i}"] = np.asarray(k), np.asarray(t)
+    # the reference's committed regression vector (tests/test_rough_logsv_pricer_regression/*.npz, rtol 1e-7)
+    reg = np.load("/root/reference/src/stochvolmodels/tests/test_rough_logsv_pricer_regression/"
+                  "test_rough_logsv_pricer_pricing_regression.npz")
+    for i in range(4):
+        out[f"reference_regression_prices_{i}"] = reg[f"option_prices_ttm_{i}"]
+    base = dict(sigma0=0.377, theta=0.347, kappa1=1.29, kappa2=1.93, beta=2.45, volvol=1.81)
+    out["params"] = np.array(list(base.values()))
+    for tag, H, nb_path in (("h010", 0.1, 10000), ("h045", 0.45, 2000), ("h050", 0.5, 2000)):
+        p = LogSvParams(**base)
+        p.H = H
+        p.approximate_kernel(T=chain.ttms[-1])
+        Z0, Z1, grids = lp.get_randoms_for_rough_vol_chain_valuation(ttms=chain.ttms, nb_path=nb_path,
+                                                                     nb_steps_per_year=360, seed=10)
+        pr, sd = lp.rough_logsv_mc_chain_pricer_fixed_randoms(
+            ttms=chain.ttms, forwards=chain.forwards, discfactors=chain.discfactors, strikes_ttms=chain.strikes_ttms,
+            optiontypes_ttms=chain.optiontypes_ttms, Z0=Z0, Z1=Z1, sigma0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+            kappa2=p.kappa2, beta=p.beta, orthog_vol=p.volvol, weights=p.weights, nodes=p.nodes, timegrids=grids)
+        out[f"{tag}_nodes"], out[f"{tag}_weights"], out[f"{tag}_nb_path"] = p.nodes, p.weights, nb_path
+        for i in range(4):
+            out[f"{tag}_prices_{i}"], out[f"{tag}_stderrs_{i}"] = np.asarray(pr[i]), np.asarray(sd[i])
+        # terminal state of the last expiry, first 128 paths
+        n = p.nodes.size
+        v0 = np.full((n,), p.sigma0 / np.sum(p.weights))
+        volvol = np.sqrt(p.beta ** 2 + p.volvol ** 2)
+        v0_vec = np.repeat(v0[:, None], nb_path, axis=1)
+        ls, vol, y = log_spot_full_combined(np.repeat(p.nodes[:, None], nb_path, axis=1),
+                                            np.repeat(p.weights[:, None], nb_path, axis=1), v0_vec, p.theta, p.kappa1,
+                                            p.kappa2, 0.0, v0_vec.copy(), p.beta / volvol, volvol, grids[-1], nb_path,
+                                            Z0[:grids[-1].size - 1], Z1[:grids[-1].size - 1])
+        out[f"{tag}_log_s_head"], out[f"{tag}_vol_head"], out[f"{tag}_y_head"] = ls[0, :128], vol[:, :128], y[0, :128]
+    save("rough", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
     g_time_grid()
@@ -435,3 +476,4 @@ if __name__ == "__main__":
     g_analytic()
     g_analytic_tight()
     g_analytic_qvar()
+    g_rough()

@@ -305,3 +305,38 @@ def test_analytic_qvar_vs_reference(oracle, golden):
     np.testing.assert_allclose(np.stack(pr), g["test_tight_prices"], rtol=0, atol=1e-9)
     with pytest.raises(ValueError):
         oracle.mgf_qvar_slice(oracle.psi_grid()[:5], np.zeros(5), 0.25, np.array([0.04]), np.array(["P"]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# rough LogSV: oracle/svmc_oracle_rough.c against the reference's split simulation
+# ---------------------------------------------------------------------------------------------------
+def _rough_chain(g):
+    m = len(g["ttms"])
+    return (g["ttms"], g["forwards"], g["discfactors"], [g[f"strikes_{i}"] for i in range(m)],
+            [g[f"types_{i}"] for i in range(m)])
+
+
+@pytest.mark.parametrize("tag", ["h010", "h045", "h050"])
+def test_rough_logsv_chain(oracle, golden, tag):
+    g = golden("rough")
+    ttms, fwd, df, K, ty = _rough_chain(g)
+    sigma0, theta, kappa1, kappa2, beta, orthog = (float(a) for a in g["params"])
+    nb_path = int(g[f"{tag}_nb_path"])
+    Z0, Z1, grids = oracle.rough_randoms(ttms, nb_path, 360, seed=10)
+    pr, sd, states = oracle.rough_logsv_chain_fixed_randoms(ttms, fwd, df, K, ty, Z0, Z1, sigma0, theta, kappa1, kappa2,
+                                                            beta, orthog, g[f"{tag}_weights"], g[f"{tag}_nodes"], grids,
+                                                            return_states=True)
+    # 1e-10: same arithmetic, but the RK4 stages of the fast factor (node ~ 108 at H = 0.1) amplify exp/sqrt
+    # rounding differences between libm and NumPy
+    for i in range(len(ttms)):
+        np.testing.assert_allclose(pr[i], g[f"{tag}_prices_{i}"], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(sd[i], g[f"{tag}_stderrs_{i}"], rtol=1e-10, atol=1e-14)
+    ls, vol, y = states[-1]
+    np.testing.assert_allclose(ls[:128], g[f"{tag}_log_s_head"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(vol[:, :128], g[f"{tag}_vol_head"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(y[:128], g[f"{tag}_y_head"], rtol=1e-9, atol=1e-12)
+    if tag == "h010":
+        # the reference's own committed regression vector (tests/test_rough_logsv_pricer_regression, rtol 1e-7;
+        # produced by its Numba fastmath build, hence not bit-equal to its NumPy-mode run either)
+        for i in range(len(ttms)):
+            np.testing.assert_allclose(pr[i], g[f"reference_regression_prices_{i}"], rtol=1e-7)
