@@ -35,6 +35,11 @@ _EXPORTS = {
     "get_randoms_for_rough_vol_chain_valuation": "pricers.logsv_pricer",
     "rough_logsv_mc_chain_pricer_fixed_randoms": "pricers.logsv_pricer",
     "rough_logsv_mc_chain_pricer": "pricers.logsv_pricer",
+    "upload_rough_randoms": "pricers.logsv_pricer",
+    "LogsvModelCalibrationType": "pricers.logsv_pricer",
+    "ConstraintsType": "pricers.logsv_pricer",
+    "CalibrationEngine": "pricers.logsv_pricer",
+    "CalibrationError": "utils.calibration",
     "logsv_chain_pricer": "pricers.logsv_pricer", "set_vol_scaler": "pricers.logsv_pricer",
     "ExpansionOrder": "pricers.logsv.affine_expansion", "compute_logsv_a_mgf_grid": "pricers.logsv.affine_expansion",
     "heston_chain_pricer": "pricers.heston_pricer", "compute_heston_mgf_grid": "pricers.heston_pricer",

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
 // ---------------------------------------------------------------------------------------------------
 struct RoughConsts {
     double nodes[3], w[3], v0[3], wlam[3];
-    double theta, kappa1, kappa2, rho, rho_comp, volvol, inv_volvol, h, sqrt_h, wsum, w_inv, volvol_w, w_lam_v0;
+    double theta, kappa1, kappa2, rho, rho_comp, volvol, inv_volvol, h, inv_h, sqrt_h, wsum, w_inv, volvol_w, w_lam_v0;
+    double ito, volvol_w_sqrt_h;   // -0.5 (volvol wsum)^2 h,  volvol wsum sqrt(h)
 };
 
 template <int N>
@@ -336,7 +337,7 @@ __device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N],
     double yw = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) yw += c.w[i] * d[i];
-    const double Yh = yw * exp(-0.5 * c.volvol_w * c.volvol_w * c.h + c.volvol_w * (z0 * c.sqrt_h));   // :238-239
+    const double Yh = yw * exp_fast(c.ito + c.volvol_w_sqrt_h * z0);   // :238-239
     const double Q = c.w_inv * (Yh - yw);
 #pragma unroll
     for (int i = 0; i < N; ++i) sn[i] = d[i] + Q;
@@ -360,11 +361,11 @@ __device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N],
         w_lam_vol_h += c.wlam[i] * vh[i];
     }
     const double sq_vw = vw * vw, sq_vhw = volw_h * volw_h;
-    const double term1 = c.inv_volvol * (((volw_h - vw) / c.h + 0.5 * w_lam_vol + 0.5 * w_lam_vol_h - c.w_lam_v0) * c.w_inv
+    const double term1 = c.inv_volvol * (((volw_h - vw) * c.inv_h + 0.5 * w_lam_vol + 0.5 * w_lam_vol_h - c.w_lam_v0) * c.w_inv
                                          - c.kappa1 * c.theta + (c.kappa1 - c.kappa2 * c.theta) * (0.5 * vw + 0.5 * volw_h)
                                          + c.kappa2 * (0.5 * sq_vw + 0.5 * sq_vhw)) * c.h;       // :319-321
     const double term2 = 0.5 * c.h * sq_vw + 0.5 * c.h * sq_vhw;
-    ls = ls - 0.5 * term2 + c.rho * term1 + c.rho_comp * sqrt(term2) * z1;                         // :324
+    ls = ls - 0.5 * term2 + c.rho * term1 + c.rho_comp * sqrt_pos(term2) * z1;                         // :324
     y = y + 0.5 * c.h * (vw * vw + volw_h * volw_h);                                               // :326
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = vh[i];
@@ -805,6 +806,9 @@ int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n
     c.theta = theta; c.kappa1 = kappa1; c.kappa2 = kappa2; c.rho = rho; c.rho_comp = sqrt(1.0 - rho * rho);
     c.volvol = volvol; c.inv_volvol = 1.0 / volvol; c.h = h; c.sqrt_h = sqrt(h); c.w_inv = 1.0 / c.wsum;
     c.volvol_w = volvol * c.wsum;
+    c.inv_h = 1.0 / h;
+    c.ito = -0.5 * c.volvol_w * c.volvol_w * h;
+    c.volvol_w_sqrt_h = c.volvol_w * c.sqrt_h;
     const dim3 g(grid_for(n_path)), b(BLOCK);
     const hipStream_t st = as_stream(stream);
     const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals

@@ -8,7 +8,7 @@ the un-vendored `vanilla_option_pricers` package, and the SwOptionChain / FutOpt
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import Tuple, List, Optional, Sequence
 
 import numpy as np
 
@@ -151,6 +151,25 @@ class OptionChain:
                    ask_ivs=[flat_vol * np.ones_like(strikes) for _ in ttms],
                    optiontypes_ttms=[np.where(strikes >= f, "C", "P") for f in forwards])
 
+    def get_chain_data_as_xy(self) -> Tuple[tuple, List[np.ndarray]]:
+        """(ttms, forwards, discfactors, strikes, types), mid vols: the calibration inputs (reference :318-325)"""
+        if self.bid_ivs is None or self.ask_ivs is None:
+            raise ValueError("calibration needs bid_ivs and ask_ivs on the chain")
+        return (self.ttms, self.forwards, self.discfactors, self.strikes_ttms, self.optiontypes_ttms), self.get_mid_vols()
+
+    def get_chain_vegas(self, is_unit_ttm_vega: bool = False) -> List[np.ndarray]:
+        """Black vegas at the mid vols, the calibration weights of Eq. (6.3) (reference :263-279; the reference
+        delegates to the third-party compute_bsm_vegas_ttms -- forward vega F*pdf(d1)*sqrt(T) here; the objective
+        normalises them per slice, so a constant factor is immaterial).  is_unit_ttm_vega evaluates them at T = 1."""
+        ttms = np.ones_like(self.ttms) if is_unit_ttm_vega else self.ttms
+        return [black_vega(float(f), np.asarray(k, dtype=float), float(t), np.asarray(v, dtype=float))
+                for t, f, k, v in zip(ttms, self.forwards, self.strikes_ttms, self.get_mid_vols())]
+
+    def get_chain_atm_vols(self) -> np.ndarray:
+        """mid vol of each slice linearly interpolated to the forward (reference :281-286)"""
+        return np.array([np.interp(x=f, xp=k, fp=v)
+                         for f, k, v in zip(self.forwards, self.strikes_ttms, self.get_mid_vols())])
+
     def compute_model_ivols_from_chain_data(self, model_prices, forwards=None) -> List[np.ndarray]:
         """model prices -> Black implied vols, slice by slice (reference data/option_chain.py:327-346).
 
@@ -173,6 +192,13 @@ def black_price(forward: float, strikes: np.ndarray, ttm: float, vol: np.ndarray
     d2 = d1 - sv
     call = discfactor * (forward * ndtr(d1) - strikes * ndtr(d2))
     return np.where(is_call, call, call - discfactor * (forward - strikes))
+
+
+def black_vega(forward: float, strikes: np.ndarray, ttm: float, vol: np.ndarray) -> np.ndarray:
+    """dPrice/dvol of an undiscounted Black-76 option"""
+    sv = np.maximum(vol, 1e-300) * np.sqrt(ttm)
+    d1 = np.log(forward / strikes) / sv + 0.5 * sv
+    return forward * np.exp(-0.5 * d1 * d1) / np.sqrt(2.0 * np.pi) * np.sqrt(ttm)
 
 
 def infer_black_ivols(prices: np.ndarray, ttm: float, forward: float, strikes: np.ndarray, optiontypes,

@@ -19,6 +19,7 @@ from .. import dist as svdist
 from ..data.option_chain import OptionChain
 from ..engine import HESTON_EULER_FLOOR, HESTON_QE, get_engine
 from ..mc_chain import price_chain_on_engine, variable_type_code
+from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
 from ..analytic import AnalyticGrid, vanilla_prices_from_capped
@@ -67,6 +68,30 @@ class HestonPricer(ModelPricer):
                                       variable_type=variable_type, scheme=kwargs.get("scheme", "euler"),
                                       nb_steps_per_year=kwargs.get("nb_steps_per_year", 360),
                                       seed=kwargs.get("seed"), comm=kwargs.get("comm"))
+
+    @timer
+    def calibrate_model_params_to_chain(self, option_chain: OptionChain, params0: HestonParams = None,
+                                        is_vega_weighted: bool = True, is_unit_ttm_vega: bool = False, **kwargs
+                                        ) -> HestonParams:
+        """fit (v0, theta, kappa, rho, volvol) to the chain's mid vols with the analytic pricer under the Feller
+        constraint 2 kappa theta >= volvol^2 (reference :110-181; same start point, bounds and SLSQP options)"""
+        p0 = np.array([0.1, 0.1, 2.0, -0.2, 1.0]) if params0 is None else \
+            np.array([params0.v0, params0.theta, params0.kappa, params0.rho, params0.volvol])
+        bounds = ((0.01, 2.0), (0.01, 2.0), (0.1, 30.0), (-0.99, 0.99), (0.1, 5.0))
+        _, market_vols_ttms = option_chain.get_chain_data_as_xy()
+        market_vols = np.concatenate(market_vols_ttms).ravel()
+        weights = chain_calibration_weights(option_chain, market_vols, is_vega_weighted, is_unit_ttm_vega)
+
+        def parse(pars: np.ndarray) -> HestonParams:
+            return HestonParams(v0=pars[0], theta=pars[1], kappa=pars[2], rho=pars[3], volvol=pars[4])
+
+        objective = ImpliedVolObjective(
+            lambda pars: self.compute_model_ivols_for_chain(option_chain=option_chain, params=parse(pars)),
+            market_vols, weights)
+        feller = {"type": "ineq", "fun": lambda pars: 2.0 * pars[2] * pars[1] - pars[4] * pars[4]}
+        fit = minimize_slsqp(objective, p0, bounds, feller, disp=bool(kwargs.get("disp", True)))
+        self.last_calibration = dict(n_eval=objective.n_eval, objective=objective(fit))
+        return parse(fit)
 
     @timer
     def simulate_terminal_values(self, params: HestonParams, ttm: float = 1.0, nb_path: int = 100000,

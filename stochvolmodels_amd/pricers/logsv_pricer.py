@@ -11,6 +11,7 @@ keywords: `seed=` (the reference exposes none; default = process seed / set_seed
 """
 from __future__ import annotations
 
+from enum import Enum
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -19,6 +20,7 @@ from .. import dist as svdist
 from ..data.option_chain import OptionChain
 from ..engine import DeviceRandoms, get_engine, payoff_finalize
 from ..mc_chain import price_chain_on_engine, variable_type_code
+from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
 from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
@@ -26,6 +28,75 @@ from ..utils import mgf_pricer as mgfp
 from .logsv.affine_expansion import ExpansionOrder, _order_code
 from .logsv.logsv_params import LogSvParams
 from .model_pricer import ModelPricer
+
+class LogsvModelCalibrationType(Enum):
+    """which parameters the calibration solves for (reference :56-68)"""
+    PARAMS4 = 1                     # sigma0, theta, beta, volvol; kappa1, kappa2 held at params0
+    PARAMS5 = 2                     # sigma0, theta, kappa1, beta, volvol; kappa2 = kappa1 / theta
+    PARAMS6 = 3
+    PARAMS_WITH_VARSWAP_FIT = 4     # beta, volvol + a vol backbone fitted to variance swaps
+
+
+class ConstraintsType(Enum):
+    """martingale / moment constraints of Theorem 3.7 (reference :70-88)"""
+    UNCONSTRAINT = 1
+    MMA_MARTINGALE = 2              # kappa2 >= beta
+    INVERSE_MARTINGALE = 3          # kappa2 >= 2 beta
+    MMA_MARTINGALE_MOMENT4 = 4      # ... and kappa1 + kappa2 theta >= 1.5 (beta^2 + volvol^2)
+    INVERSE_MARTINGALE_MOMENT4 = 5
+
+
+class CalibrationEngine(Enum):
+    """where the objective's model vols come from (reference :90-101)"""
+    ANALYTIC = 1
+    MC = 2
+    ROUGH_MC = 3
+
+
+_FREE_PARAMS = {LogsvModelCalibrationType.PARAMS4: ("sigma0", "theta", "beta", "volvol"),
+                LogsvModelCalibrationType.PARAMS5: ("sigma0", "theta", "kappa1", "beta", "volvol")}
+
+
+def _calibration_parser(calibration_type: LogsvModelCalibrationType, params0: LogSvParams):
+    """optimizer vector -> LogSvParams.  PARAMS4 keeps params0's kappas, PARAMS5 ties kappa2 = kappa1 / theta
+    (LogSvParams(kappa2=None)); H / nodes / weights always come from params0 (reference codec :106-160)."""
+    names = _FREE_PARAMS.get(calibration_type)
+    if names is None:
+        raise NotImplementedError(f"{calibration_type}")      # PARAMS6: as the reference; varswap fit: not built
+    tied = calibration_type == LogsvModelCalibrationType.PARAMS5
+
+    def parse(pars: np.ndarray) -> LogSvParams:
+        fields = dict(kappa1=params0.kappa1, kappa2=None if tied else params0.kappa2, H=params0.H,
+                      nodes=params0.nodes, weights=params0.weights)
+        fields.update(zip(names, pars))
+        return LogSvParams(**fields)
+    return names, parse
+
+
+def _calibration_constraints(parse, constraints_type: ConstraintsType):
+    """SLSQP inequality constraints g(pars) >= 0 (reference :297-332)"""
+    def mma(pars):
+        p = parse(pars)
+        return p.kappa2 - p.beta
+
+    def inverse(pars):
+        p = parse(pars)
+        return p.kappa2 - 2.0 * p.beta
+
+    def moment4(pars):
+        p = parse(pars)
+        return p.kappa1 + p.kappa2 * p.theta - 1.5 * (p.beta * p.beta + p.volvol * p.volvol)
+
+    ineq = lambda f: {"type": "ineq", "fun": f}    # noqa: E731
+    table = {ConstraintsType.UNCONSTRAINT: None,
+             ConstraintsType.MMA_MARTINGALE: ineq(mma),
+             ConstraintsType.INVERSE_MARTINGALE: ineq(inverse),
+             ConstraintsType.MMA_MARTINGALE_MOMENT4: (ineq(mma), ineq(moment4)),
+             ConstraintsType.INVERSE_MARTINGALE_MOMENT4: (ineq(inverse), ineq(moment4))}
+    if constraints_type not in table:
+        raise NotImplementedError(f"{constraints_type}")
+    return table[constraints_type]
+
 
 LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
 
@@ -74,6 +145,77 @@ class LogSVPricer(ModelPricer):
                                      variable_type=variable_type, nb_path=nb_path,
                                      nb_steps_per_year=nb_steps or int(360 * np.max(option_chain.ttms)) + 1,
                                      seed=kwargs.get("seed"), comm=kwargs.get("comm"))
+
+    def set_vol_scaler(self, option_chain: OptionChain) -> float:
+        """transform-grid scaler from the chain's first ATM vol, held fixed over a calibration (reference :429-438)"""
+        return set_vol_scaler(sigma0=option_chain.get_chain_atm_vols()[0], ttm=option_chain.ttms[0])
+
+    @timer
+    def calibrate_model_params_to_chain(self, option_chain: OptionChain, params0: LogSvParams,
+                                        params_min: LogSvParams = LogSvParams(sigma0=0.1, theta=0.1, kappa1=0.25,
+                                                                              kappa2=0.25, beta=-3.0, volvol=0.2),
+                                        params_max: LogSvParams = LogSvParams(sigma0=1.5, theta=1.5, kappa1=10.0,
+                                                                              kappa2=10.0, beta=3.0, volvol=3.0),
+                                        is_vega_weighted: bool = True, is_unit_ttm_vega: bool = False,
+                                        model_calibration_type: LogsvModelCalibrationType = LogsvModelCalibrationType.PARAMS5,
+                                        constraints_type: ConstraintsType = ConstraintsType.UNCONSTRAINT,
+                                        calibration_engine: CalibrationEngine = CalibrationEngine.ANALYTIC,
+                                        nb_path: int = 100000, nb_steps: int = 360, seed: int = 10, **kwargs
+                                        ) -> LogSvParams:
+        """fit the model to the chain's mid implied vols: SLSQP on the vega-weighted squared vol error of Eq. (6.3)
+        (reference :440-557).  The MC engines draw the reference's RandomState(seed) randoms once, upload this rank's
+        columns to HBM once, and every objective evaluation re-prices the chain from those resident randoms -- the
+        optimizer loop is kernel-bound, not PCIe-bound.  `kwargs`: comm=, disp= (SLSQP printing, default True as in
+        the reference).  `self.last_calibration` keeps {"n_eval", "objective"} of the run."""
+        vol_scaler = self.set_vol_scaler(option_chain=option_chain)
+        _, market_vols_ttms = option_chain.get_chain_data_as_xy()
+        market_vols = np.concatenate(market_vols_ttms).ravel()
+        weights = chain_calibration_weights(option_chain, market_vols, is_vega_weighted, is_unit_ttm_vega)
+        names, parse = _calibration_parser(model_calibration_type, params0)
+        p0 = np.array([getattr(params0, n) for n in names], dtype=float)
+        bounds = tuple((getattr(params_min, n), getattr(params_max, n)) for n in names)
+        comm = kwargs.get("comm")
+        chain_args = dict(ttms=option_chain.ttms, forwards=option_chain.forwards, discfactors=option_chain.discfactors,
+                          strikes_ttms=option_chain.strikes_ttms, optiontypes_ttms=option_chain.optiontypes_ttms)
+        resident = None
+        if calibration_engine == CalibrationEngine.ANALYTIC:
+            def model_vols(pars):
+                return self.compute_model_ivols_for_chain(option_chain=option_chain, params=parse(pars),
+                                                          vol_scaler=vol_scaler)
+        elif calibration_engine == CalibrationEngine.MC:
+            resident = upload_fixed_randoms(*get_randoms_for_chain_valuation(
+                ttms=option_chain.ttms, nb_path=nb_path, nb_steps_per_year=nb_steps, seed=seed), comm=comm)
+
+            def model_vols(pars):
+                p = parse(pars)
+                prices, _ = logsv_mc_chain_pricer_fixed_randoms(
+                    W0s=resident, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2,
+                    beta=p.beta, volvol=p.volvol, vol_backbone_etas=p.get_vol_backbone_etas(ttms=option_chain.ttms),
+                    comm=comm, **chain_args)
+                return option_chain.compute_model_ivols_from_chain_data(model_prices=prices)
+        elif calibration_engine == CalibrationEngine.ROUGH_MC:
+            Z0, Z1, grids = get_randoms_for_rough_vol_chain_valuation(ttms=option_chain.ttms, nb_path=nb_path,
+                                                                      nb_steps_per_year=nb_steps, seed=seed)
+            resident = upload_rough_randoms(Z0, Z1, comm=comm)
+
+            def model_vols(pars):
+                p = parse(pars)
+                prices, _ = rough_logsv_mc_chain_pricer_fixed_randoms(
+                    Z0=resident, Z1=None, sigma0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2,
+                    beta=p.beta, orthog_vol=p.volvol, weights=p.weights, nodes=p.nodes, timegrids=grids, comm=comm,
+                    **chain_args)
+                return option_chain.compute_model_ivols_from_chain_data(model_prices=prices)
+        else:
+            raise NotImplementedError(f"{calibration_engine}")
+        objective = ImpliedVolObjective(model_vols, market_vols, weights)
+        try:
+            fit = minimize_slsqp(objective, p0, bounds, _calibration_constraints(parse, constraints_type),
+                                 disp=bool(kwargs.get("disp", True)))
+        finally:
+            if resident is not None:
+                resident.free()
+        self.last_calibration = dict(n_eval=objective.n_eval, objective=objective(fit))
+        return parse(fit)
 
     @timer
     def simulate_vol_paths(self, params: LogSvParams, brownians: np.ndarray = None, ttm: float = 1.0,
@@ -319,6 +461,14 @@ def get_randoms_for_rough_vol_chain_valuation(ttms: np.ndarray, nb_path: int = 1
     return Z0, Z1, grids
 
 
+def upload_rough_randoms(Z0: np.ndarray, Z1: np.ndarray, comm=None) -> DeviceRandoms:
+    """copy the rough chain's Z0 / Z1 to HBM once (this rank's path columns); pass the result as `Z0` to
+    rough_logsv_mc_chain_pricer_fixed_randoms"""
+    comm = comm or svdist.get_default_comm()
+    offset, n_local = svdist.shard_range(np.asarray(Z0).shape[1], comm.rank, comm.world)
+    return DeviceRandoms([Z0], [Z1], [0.0], n_local, offset)
+
+
 def _rough_finalize(normalize_stderr: bool):
     """The reference passes a [1, nb_path] log-spot to compute_mc_vars_payoff, whose "/ sqrt(x0.shape[0])"
     (utils/mc_payoffs.py:88) then divides by 1: its second return is the payoff's standard deviation.  Reproduced
@@ -353,22 +503,30 @@ def rough_logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.nda
                                               variable_type: VariableType = VariableType.LOG_RETURN,
                                               debug: bool = False, comm=None, normalize_stderr: bool = False
                                               ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-    """rough-LogSV chain on supplied N(0,1) draws (reference :1164-1232).  Z0/Z1 go to HBM once (this rank's path
-    columns); every expiry is then one kernel that re-simulates from time 0 over the first len(timegrid_i)-1 rows
+    """rough-LogSV chain on supplied N(0,1) draws (reference :1164-1232).  Z0 may be the result of
+    upload_rough_randoms (Z1 is then ignored); otherwise Z0/Z1 go to HBM once per call (this rank's path columns); every expiry is then one kernel that re-simulates from time 0 over the first len(timegrid_i)-1 rows
     with step timegrid_i[1]-timegrid_i[0], exactly as the reference does."""
     variable_type_code(variable_type)
     weights, nodes, v0, rho, volvol = _rough_coefficients(sigma0, beta, orthog_vol, weights, nodes)
     comm = comm or svdist.get_default_comm()
-    Z0, Z1 = np.asarray(Z0), np.asarray(Z1)
-    if Z0.ndim != 2 or Z0.shape != Z1.shape:
-        raise ValueError("Z0 and Z1 must both have shape [nb_steps, nb_path]")
-    nb_path = Z0.shape[1]
+    resident = Z0 if isinstance(Z0, DeviceRandoms) else None
+    if resident is None:
+        Z0, Z1 = np.asarray(Z0), np.asarray(Z1)
+        if Z0.ndim != 2 or Z0.shape != Z1.shape:
+            raise ValueError("Z0 and Z1 must both have shape [nb_steps, nb_path]")
+    nb_path = resident.nb_path if resident else Z0.shape[1]
+    nb_rows = resident.nb_steps[0] if resident else Z0.shape[0]
     nbs = [int(np.asarray(g).size) - 1 for g in timegrids]
-    if len(nbs) != len(ttms) or max(nbs) > Z0.shape[0] or min(nbs) < 1:
+    if len(nbs) != len(ttms) or max(nbs) > nb_rows or min(nbs) < 1:
         raise ValueError("one time grid per maturity, each with at most Z0.shape[0] steps")
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    if resident and (resident.n_local, resident.col0) != (n_local, offset):
+        raise ValueError("DeviceRandoms were uploaded for a different path shard")
     eng = get_engine(n_local, path_offset=offset)
-    z0, z1 = eng.upload_randoms((Z0[:max(nbs)], Z1[:max(nbs)]), col0=offset)
+    if resident:
+        z0, z1 = resident.w0[0].ptr, resident.w1[0].ptr
+    else:
+        z0, z1 = eng.upload_randoms((Z0[:max(nbs)], Z1[:max(nbs)]), col0=offset)
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         h = float(timegrids[i][1] - timegrids[i][0])

@@ -2,9 +2,10 @@
 ModelParams / ModelPricer: the Monte Carlo part of the reference's pricer interface
 (pricers/model_pricer.py:28-41, :83-265).
 
-Kept: model_mc_price_chain, simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols,
-get_log_return_mc_pdf with the reference's signatures.  Out of scope: the
-analytic price_chain family, calibration, and the matplotlib plotting methods.
+Kept: price_chain, compute_chain_prices_with_vols, compute_model_ivols_for_chain, model_mc_price_chain,
+simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols, get_log_return_mc_pdf,
+calibrate_model_params_to_chain with the reference's signatures.  Out of scope: the
+matplotlib plotting methods and the slice / single-option conveniences built on them.
 """
 from __future__ import annotations
 
@@ -15,6 +16,7 @@ from typing import List, Tuple
 import numpy as np
 
 from ..data.option_chain import OptionChain
+from ..utils.calibration import CalibrationError, validate_optimization_result  # noqa: F401  (reference exports)
 from ..utils.config import VariableType
 
 
@@ -31,6 +33,20 @@ class ModelPricer(ABC):
 
     def price_chain(self, option_chain: OptionChain, params: ModelParams, **kwargs) -> List[np.ndarray]:
         raise NotImplementedError("analytic chain pricing is outside the Monte Carlo hot path of this package")
+
+    def compute_chain_prices_with_vols(self, option_chain: OptionChain, params: ModelParams,
+                                       variable_type: VariableType = VariableType.LOG_RETURN, **kwargs
+                                       ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """analytic chain prices and their Black implied vols (reference :109-120)"""
+        model_prices = self.price_chain(option_chain=option_chain, params=params, variable_type=variable_type, **kwargs)
+        return model_prices, option_chain.compute_model_ivols_from_chain_data(model_prices=model_prices)
+
+    def compute_model_ivols_for_chain(self, option_chain: OptionChain, params: ModelParams, **kwargs
+                                      ) -> List[np.ndarray]:
+        return self.compute_chain_prices_with_vols(option_chain=option_chain, params=params, **kwargs)[1]
+
+    def calibrate_model_params_to_chain(self, option_chain: OptionChain, **kwargs):
+        raise NotImplementedError("must be implemented in parent class")
 
     def model_mc_price_chain(self, option_chain: OptionChain, params: ModelParams,
                              variable_type: VariableType = VariableType.LOG_RETURN, **kwargs

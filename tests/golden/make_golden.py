@@ -463,7 +463,82 @@ def g_rough():
     save("rough", **out)
 
 
+# -- f.3: calibration loop -----------------------------------------------------------------------------
+def g_calibration():
+    """The reference's calibrate_model_params_to_chain run unmodified (codec, objective, constraints, SLSQP, its own
+    MC / rough / analytic pricers).  The Black vega and implied-vol routines it calls live in the third-party
+    `vanilla_option_pricers`, absent here: for this fixture they are bound to the host helpers of
+    stochvolmodels_amd.data.option_chain (textbook Black-76) -- so the fixture pins the calibration LOOP, not that
+    third-party inversion."""
+    import stochvolmodels as svm
+    import stochvolmodels.data.option_chain as roc
+    from stochvolmodels_amd.data import option_chain as host   # pure-host helpers, no GPU needed
+
+    def vegas_ttms(ttms, forwards, strikes_ttms, optiontypes_ttms, vols_ttms):
+        return [host.black_vega(float(f), np.asarray(k, float), float(t), np.asarray(v, float))
+                for t, f, k, v in zip(ttms, forwards, strikes_ttms, vols_ttms)]
+
+    def ivols_ttms(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, model_prices_ttms):
+        return [host.infer_black_ivols(np.asarray(p, float), float(t), float(f), np.asarray(k, float), ty, float(d))
+                for t, f, d, k, ty, p in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                             model_prices_ttms)]
+    roc.bsm.compute_bsm_vegas_ttms = vegas_ttms
+    roc.bsm.infer_bsm_ivols_from_model_chain_prices = ivols_ttms
+
+    ttms = np.array([0.1, 0.25])
+    forwards = np.array([1.0, 1.0])
+    strikes = np.linspace(0.8, 1.2, 9)
+    types = np.where(strikes >= 1.0, "C", "P")
+    true = LogSvParams(sigma0=0.5, theta=0.6, kappa1=2.0, kappa2=None, beta=-0.3, volvol=1.0)
+    base = svm.OptionChain(ttms=ttms, forwards=forwards, strikes_ttms=(strikes, strikes), optiontypes_ttms=(types, types),
+                           discfactors=np.ones(2), ids=np.array(["t0", "t1"]))
+    pricer = svm.LogSVPricer()
+    mids = pricer.compute_model_ivols_for_chain(option_chain=base, params=true)
+    chain = svm.OptionChain(ttms=ttms, forwards=forwards, strikes_ttms=(strikes, strikes),
+                            optiontypes_ttms=(types, types), discfactors=np.ones(2), ids=np.array(["t0", "t1"]),
+                            bid_ivs=tuple(m - 0.005 for m in mids), ask_ivs=tuple(m + 0.005 for m in mids))
+    out = dict(ttms=ttms, forwards=forwards, strikes=strikes, types=types, mid_0=mids[0], mid_1=mids[1],
+               true=params_vec(true))
+    start = LogSvParams(sigma0=0.4, theta=0.5, kappa1=3.0, kappa2=3.0, beta=0.0, volvol=1.4)
+    out["start"] = params_vec(start)
+    CT, CE, KT = lp.LogsvModelCalibrationType, lp.CalibrationEngine, lp.ConstraintsType
+
+    def run(tag, p0, **kw):
+        fit = pricer.calibrate_model_params_to_chain(option_chain=chain, params0=p0, **kw)
+        out[f"{tag}_fit"] = params_vec(fit)
+        print(tag, fit)
+        return fit
+
+    run("mc5", start, calibration_engine=CE.MC, model_calibration_type=CT.PARAMS5, nb_path=4000, nb_steps=360, seed=10)
+    run("mc4c", start, calibration_engine=CE.MC, model_calibration_type=CT.PARAMS4,
+        constraints_type=KT.INVERSE_MARTINGALE_MOMENT4, is_vega_weighted=False, nb_path=4000, nb_steps=360, seed=7)
+    rough0 = LogSvParams(sigma0=0.4, theta=0.5, kappa1=3.0, kappa2=3.0, beta=0.0, volvol=1.4, H=0.1,
+                         nodes=np.array([0.07724, 5.19, 108.46]), weights=np.array([0.777, 1.554, 8.516]))
+    out["rough_nodes"], out["rough_weights"] = rough0.nodes, rough0.weights
+    run("rough4", rough0, calibration_engine=CE.ROUGH_MC, model_calibration_type=CT.PARAMS4, nb_path=2000,
+        nb_steps=360, seed=10)
+    run("an4", start, calibration_engine=CE.ANALYTIC, model_calibration_type=CT.PARAMS4,
+        constraints_type=KT.MMA_MARTINGALE)
+    # Heston: analytic engine, Feller constraint
+    hpr = svm.HestonPricer()
+    htrue = hp.HestonParams(v0=0.2, theta=0.25, kappa=3.0, rho=-0.4, volvol=0.8)
+    hm = hpr.compute_model_ivols_for_chain(option_chain=base, params=htrue)
+    hchain = svm.OptionChain(ttms=ttms, forwards=forwards, strikes_ttms=(strikes, strikes),
+                             optiontypes_ttms=(types, types), discfactors=np.ones(2), ids=np.array(["t0", "t1"]),
+                             bid_ivs=tuple(m - 0.005 for m in hm), ask_ivs=tuple(m + 0.005 for m in hm))
+    hfit = hpr.calibrate_model_params_to_chain(option_chain=hchain, params0=None)
+    out["heston_mid_0"], out["heston_mid_1"] = hm[0], hm[1]
+    out["heston_true"] = np.array([htrue.v0, htrue.theta, htrue.kappa, htrue.rho, htrue.volvol])
+    out["heston_fit"] = np.array([hfit.v0, hfit.theta, hfit.kappa, hfit.rho, hfit.volvol])
+    save("calibration", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python make_golden.py g_rough g_calibration ...
+        oracle.build()
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     oracle.build()
     g_time_grid()
     g_logsv_zero_noise()
@@ -477,3 +552,4 @@ if __name__ == "__main__":
     g_analytic_tight()
     g_analytic_qvar()
     g_rough()
+    g_calibration()

@@ -814,3 +814,72 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
     p05 = sv.LogSvParams(H=0.5)
     p05.approximate_kernel(T=1.0)
     assert p05.nodes.tolist() == [1e-3] and p05.weights.tolist() == [1.0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# calibration loop: the optimizer runs on the host, every objective evaluation on the GPU
+# ---------------------------------------------------------------------------------------------------
+def _calibration_chain(sv, g, prefix=""):
+    k, ty = g["strikes"], g["types"]
+    mids = [g[f"{prefix}mid_0"], g[f"{prefix}mid_1"]]
+    return sv.OptionChain(ttms=g["ttms"], forwards=g["forwards"], strikes_ttms=(k, k), optiontypes_ttms=(ty, ty),
+                          discfactors=np.ones(2), ids=np.array(["t0", "t1"]),
+                          bid_ivs=tuple(m - 0.005 for m in mids), ask_ivs=tuple(m + 0.005 for m in mids))
+
+
+def _vec(p):
+    return np.array([p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol])
+
+
+@pytest.mark.parametrize("tag", ["mc5", "mc4c", "rough4", "an4"])
+def test_logsv_calibration_vs_reference(sv, golden, tag):
+    """same chain, start point, fixed randoms, SLSQP options as the reference's run.  The two objectives agree to
+    ~1e-9 per evaluation, so the optimizer paths coincide up to its own stopping tolerance (ftol 1e-8 on an
+    objective of order 1e-6..1e-4): fitted parameters within 2e-3 relative + 2e-3 absolute, and the objective
+    at our optimum no worse than at the reference's."""
+    g = golden("calibration")
+    chain = _calibration_chain(sv, g)
+    CT, CE, KT = sv.LogsvModelCalibrationType, sv.CalibrationEngine, sv.ConstraintsType
+    s = g["start"]
+    start = dict(sigma0=s[0], theta=s[1], kappa1=s[2], kappa2=s[3], beta=s[4], volvol=s[5])
+    kw = {"mc5": dict(calibration_engine=CE.MC, model_calibration_type=CT.PARAMS5, nb_path=4000, nb_steps=360, seed=10),
+          "mc4c": dict(calibration_engine=CE.MC, model_calibration_type=CT.PARAMS4,
+                       constraints_type=KT.INVERSE_MARTINGALE_MOMENT4, is_vega_weighted=False, nb_path=4000,
+                       nb_steps=360, seed=7),
+          "rough4": dict(calibration_engine=CE.ROUGH_MC, model_calibration_type=CT.PARAMS4, nb_path=2000, nb_steps=360,
+                         seed=10),
+          "an4": dict(calibration_engine=CE.ANALYTIC, model_calibration_type=CT.PARAMS4,
+                      constraints_type=KT.MMA_MARTINGALE)}[tag]
+    if tag == "rough4":
+        start.update(H=0.1, nodes=g["rough_nodes"], weights=g["rough_weights"])
+    pricer = sv.LogSVPricer()
+    fit = pricer.calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start), disp=False, **kw)
+    ref = g[f"{tag}_fit"]
+    tol = dict(rtol=2e-3, atol=2e-3) if tag != "an4" else dict(rtol=2e-2, atol=1e-2)   # an4: RK45 rtol 1e-3 in the reference
+    np.testing.assert_allclose(_vec(fit), ref, **tol)
+    assert pricer.last_calibration["n_eval"] > 5
+    if tag == "mc4c":       # the constraints hold at the optimum
+        assert fit.kappa2 - 2.0 * fit.beta >= -1e-8
+        assert fit.kappa1 + fit.kappa2 * fit.theta - 1.5 * (fit.beta ** 2 + fit.volvol ** 2) >= -1e-8
+
+
+def test_heston_calibration_vs_reference(sv, golden):
+    g = golden("calibration")
+    chain = _calibration_chain(sv, g, "heston_")
+    fit = sv.HestonPricer().calibrate_model_params_to_chain(option_chain=chain, params0=None, disp=False)
+    got = np.array([fit.v0, fit.theta, fit.kappa, fit.rho, fit.volvol])
+    np.testing.assert_allclose(got, g["heston_fit"], rtol=2e-3, atol=2e-3)
+    assert 2.0 * fit.kappa * fit.theta - fit.volvol ** 2 >= -1e-8
+
+
+def test_calibration_errors(sv, golden):
+    g = golden("calibration")
+    chain = _calibration_chain(sv, g)
+    p0 = sv.LogSvParams()
+    with pytest.raises(NotImplementedError):
+        sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=chain, params0=p0, disp=False,
+                                                         model_calibration_type=sv.LogsvModelCalibrationType.PARAMS6)
+    bare = sv.OptionChain(ttms=g["ttms"], forwards=g["forwards"], strikes_ttms=(g["strikes"],) * 2,
+                          optiontypes_ttms=(g["types"],) * 2, discfactors=np.ones(2), ids=np.array(["a", "b"]))
+    with pytest.raises((ValueError, TypeError)):
+        sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=bare, params0=p0, disp=False)

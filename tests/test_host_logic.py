@@ -139,3 +139,61 @@ def test_black_implied_vol_round_trip():
     assert np.isnan(infer_black_ivols(np.array([2.0]), 0.5, 1.0, np.array([1.0]), np.array(["C"]))[0])
     with pytest.raises(NotImplementedError):
         infer_black_ivols(pr[:1], 0.5, 1.0, k[:1], np.array(["IC"]))
+
+
+def test_validate_optimization_result():
+    """reference pricers/model_pricer.py:48-80 (tests/test_model_calibration_contracts.py covers the same cases)"""
+    from types import SimpleNamespace as NS
+    from stochvolmodels_amd.utils.calibration import CalibrationError, validate_optimization_result
+    b = ((0.0, 1.0), (None, 2.0))
+    assert validate_optimization_result(NS(success=True, x=[0.5, 1.0], message="ok"), b).tolist() == [0.5, 1.0]
+    assert validate_optimization_result(NS(success=True, x=[1.0 + 5e-11, -9.0], message="ok"), b)[0] > 1.0   # slack
+    for bad in (NS(success=False, x=[0.5, 1.0], message="boom"), NS(success=True, x=None, message="m"),
+                NS(success=True, x=["a", 1.0], message="m"), NS(success=True, x=[0.5], message="m"),
+                NS(success=True, x=[[0.5, 1.0]], message="m"), NS(success=True, x=[np.nan, 1.0], message="m"),
+                NS(success=True, x=[-1e-3, 1.0], message="m"), NS(success=True, x=[0.5, 2.1], message="m")):
+        with pytest.raises(CalibrationError):
+            validate_optimization_result(bad, b)
+
+
+def test_calibration_parser_and_constraints():
+    import stochvolmodels_amd as sv
+    from stochvolmodels_amd.pricers.logsv_pricer import _calibration_constraints, _calibration_parser
+    p0 = sv.LogSvParams(sigma0=0.3, theta=0.4, kappa1=2.0, kappa2=3.0, beta=0.1, volvol=1.0, H=0.3,
+                        nodes=np.array([1.0]), weights=np.array([2.0]))
+    names, parse = _calibration_parser(sv.LogsvModelCalibrationType.PARAMS4, p0)
+    assert names == ("sigma0", "theta", "beta", "volvol")
+    p = parse(np.array([0.5, 0.6, -0.2, 0.9]))
+    assert (p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, p.H) == (0.5, 0.6, 2.0, 3.0, -0.2, 0.9, 0.3)
+    assert p.nodes is p0.nodes and p.weights is p0.weights
+    names, parse = _calibration_parser(sv.LogsvModelCalibrationType.PARAMS5, p0)
+    p = parse(np.array([0.5, 0.5, 2.0, -0.2, 0.9]))
+    assert names == ("sigma0", "theta", "kappa1", "beta", "volvol") and p.kappa2 == 4.0     # kappa1 / theta
+    for ct in (sv.LogsvModelCalibrationType.PARAMS6, sv.LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT):
+        with pytest.raises(NotImplementedError):
+            _calibration_parser(ct, p0)
+    assert _calibration_constraints(parse, sv.ConstraintsType.UNCONSTRAINT) is None
+    c = _calibration_constraints(parse, sv.ConstraintsType.INVERSE_MARTINGALE_MOMENT4)
+    x = np.array([0.5, 0.5, 2.0, -0.2, 0.9])
+    assert c[0]["type"] == "ineq" and np.isclose(c[0]["fun"](x), 4.0 + 0.4)
+    assert np.isclose(c[1]["fun"](x), 2.0 + 4.0 * 0.5 - 1.5 * (0.04 + 0.81))
+    assert np.isclose(_calibration_constraints(parse, sv.ConstraintsType.MMA_MARTINGALE)["fun"](x), 4.2)
+
+
+def test_option_chain_calibration_helpers():
+    import stochvolmodels_amd as sv
+    from stochvolmodels_amd.data.option_chain import black_price, black_vega
+    k = np.array([0.9, 1.0, 1.1])
+    chain = sv.OptionChain(ttms=np.array([0.25, 1.0]), forwards=np.array([1.0, 1.05]), strikes_ttms=(k, k),
+                           optiontypes_ttms=(np.array(["P", "C", "C"]),) * 2, discfactors=np.ones(2),
+                           ids=np.array(["a", "b"]), bid_ivs=(np.array([0.3, 0.2, 0.25]),) * 2,
+                           ask_ivs=(np.array([0.32, 0.22, 0.27]),) * 2)
+    x, y = chain.get_chain_data_as_xy()
+    assert x[0] is chain.ttms and np.allclose(y[0], [0.31, 0.21, 0.26])
+    assert np.allclose(chain.get_chain_atm_vols(), [0.21, 0.235])
+    v = chain.get_chain_vegas()
+    h = 1e-5
+    fd = (black_price(1.05, k, 1.0, y[1] + h, np.array([False, True, True])) -
+          black_price(1.05, k, 1.0, y[1] - h, np.array([False, True, True]))) / (2 * h)
+    assert np.allclose(v[1], fd, rtol=1e-6)
+    assert np.allclose(chain.get_chain_vegas(is_unit_ttm_vega=True)[0], black_vega(1.0, k, 1.0, y[0]))
