@@ -211,10 +211,10 @@ class LogSVPricer(ModelPricer):
         try:
             fit = minimize_slsqp(objective, p0, bounds, _calibration_constraints(parse, constraints_type),
                                  disp=bool(kwargs.get("disp", True)))
+            self.last_calibration = dict(n_eval=objective.n_eval, objective=objective(fit))
         finally:
             if resident is not None:
                 resident.free()
-        self.last_calibration = dict(n_eval=objective.n_eval, objective=objective(fit))
         return parse(fit)
 
     @timer
