@@ -12,3 +12,8 @@ HESTON_CASE = dict(
     ttms=np.array([0.05, 0.1]), forwards=np.array([1.0, 1.01]), discfactors=np.array([0.999, 0.99]),
     strikes_ttms=(_KK, 1.01 * _KK), optiontypes_ttms=(np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"])),
     v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4, nb_path=1001, seed=78, scheme="qe", nb_steps_per_year=100)
+ROUGH_CASE = dict(
+    ttms=np.array([0.05, 0.1]), forwards=np.array([1.0, 1.01]), discfactors=np.array([0.999, 0.99]),
+    strikes_ttms=(_KK, 1.01 * _KK), optiontypes_ttms=(np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"])),
+    sigma0=0.377, theta=0.347, kappa1=1.29, kappa2=1.93, beta=2.45, orthog_vol=1.81,
+    weights=np.array([0.777, 1.554, 8.516]), nodes=np.array([0.0772, 5.19, 108.46]))

@@ -45,6 +45,14 @@ def main(out_path):
     kw = {k: v for k, v in LOGSV_CASE.items() if k not in ("nb_path", "nb_steps_per_year", "seed")}
     pr, sd = logsv_pricer.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=dts, **kw)
     res["fixed_prices"], res["fixed_stderrs"] = np.stack(pr), np.stack(sd)
+    # rough LogSV: fixed randoms (full host arrays on every rank) and device-side draws
+    from cases import ROUGH_CASE
+    Z0, Z1, grids = logsv_pricer.get_randoms_for_rough_vol_chain_valuation(ROUGH_CASE["ttms"], nb_path=1001,
+                                                                           nb_steps_per_year=120, seed=4)
+    pr, sd = logsv_pricer.rough_logsv_mc_chain_pricer_fixed_randoms(Z0=Z0, Z1=Z1, timegrids=grids, **ROUGH_CASE)
+    res["rough_prices"], res["rough_stderrs"] = np.stack(pr), np.stack(sd)
+    pr, sd = logsv_pricer.rough_logsv_mc_chain_pricer(nb_path=1001, nb_steps_per_year=120, seed=5, **ROUGH_CASE)
+    res["rough_rng_prices"], res["rough_rng_stderrs"] = np.stack(pr), np.stack(sd)
     res["rank_paths"] = np.array([e.n_path for e in engines.values()])
     res["rank_offsets"] = np.array([e.path_offset for e in engines.values()])
     np.savez(out_path + f".rank{comm.rank}.npz", **res)

@@ -95,6 +95,23 @@ class FakeEngine:
             self.x, self.vol, self.qvar, dt, theta, kappa1, kappa2, beta, volvol, self._rand[w0], self._rand[w1],
             eta=eta, is_spot_measure=is_spot_measure)
 
+    def rough_logsv(self, nb_steps, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0_ptr=None, z1_ptr=None,
+                    ldw=None, seed=0, call_id=0, step_offset=0, from_origin=True):
+        assert from_origin
+        if z0_ptr is None:
+            Z0, Z1 = oracle.fill_normals(seed, self.n_path, nb_steps, call_id=call_id, path_offset=self.path_offset,
+                                         step_offset=step_offset, stream=3)
+        else:
+            Z0, Z1 = self._rand[z0_ptr], self._rand[z1_ptr]
+        n = len(nodes)
+        ls, y = np.zeros(self.n_path), np.zeros(self.n_path)
+        vol = np.ascontiguousarray(np.repeat(np.asarray(v0, dtype=float)[:, None], self.n_path, axis=1))
+        L, p = oracle.lib(), oracle._p
+        nodes, weights, v0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (nodes, weights, v0))
+        L.svo_rough_logsv_terminal_w(self.n_path, nb_steps, h, n, p(nodes), p(weights), p(v0), theta, kappa1, kappa2, rho,
+                                     volvol, p(ls), p(vol), p(y), p(Z0), p(Z1), Z0.shape[1])
+        self.x, self.qvar, self.factors = ls, y, vol
+
     # the two reduction kernels, restated on host memory (utils/mc_payoffs.py:61-86)
     def spot_sums(self, x_ptr, forward, out_ptr):
         x = _view(x_ptr, self.n_path)

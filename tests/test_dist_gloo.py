@@ -54,6 +54,15 @@ def _expected(oracle):
                                             c["optiontypes_ttms"], W0s, W1s, dts, c["v0"], c["theta"], c["kappa1"],
                                             c["kappa2"], c["beta"], c["volvol"], c["vol_backbone_etas"])
     out["fixed_prices"], out["fixed_stderrs"] = np.stack(P), np.stack(E)
+    from cases import ROUGH_CASE as r
+    args = (r["ttms"], r["forwards"], r["discfactors"], r["strikes_ttms"], r["optiontypes_ttms"])
+    pars = (r["sigma0"], r["theta"], r["kappa1"], r["kappa2"], r["beta"], r["orthog_vol"], r["weights"], r["nodes"])
+    Z0, Z1, grids = oracle.rough_randoms(r["ttms"], 1001, 120, seed=4)
+    P, E = oracle.rough_logsv_chain_fixed_randoms(*args, Z0, Z1, *pars, grids)
+    out["rough_prices"], out["rough_stderrs"] = np.stack(P), np.stack(E)
+    Z0, Z1 = oracle.fill_normals(5, 1001, grids[-1].size - 1, call_id=0, stream=3)
+    P, E = oracle.rough_logsv_chain_fixed_randoms(*args, Z0, Z1, *pars, grids)
+    out["rough_rng_prices"], out["rough_rng_stderrs"] = np.stack(P), np.stack(E)
     return out
 
 
