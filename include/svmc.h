@@ -139,6 +139,15 @@ SVMC_API int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int
                                   int is_spot_measure, const double *brownians, size_t ldb, uint64_t seed,
                                   uint32_t call_id, uint64_t path_offset, svmc_stream_t stream);
 
+/* ---- Black-76 implied vols of one slice, HOST arrays in and out (no device work): the price -> vol step between a
+ * pricer and the calibration objective, OptionChain.compute_model_ivols_from_chain_data data/option_chain.py:327-346
+ * (which delegates to the third-party vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices; parity with it
+ * is unpinned).  optiontypes: SVMC_CALL / SVMC_PUT only (else SVMC_ERR_UNSUPPORTED_VARIABLE).  A quote whose price is
+ * not strictly inside (price(vol_lo), price(vol_hi)) -- or is NaN -- gets NaN. */
+SVMC_API int svmc_black_implied_vols(const double *prices, const double *strikes, const int8_t *optiontypes,
+                                     size_t n_strikes, double forward, double ttm, double discfactor, double vol_lo,
+                                     double vol_hi, double *ivols);
+
 /* ---- rough LogSV (Markovian lift, n_factors <= 3): log_spot_full_combined_f64, pricers/rough_logsv/
  * split_simulation.py:335-356 (Strang splitting :249-278 over drift_ode_solve2 :86-128 and diffus_sde_solve_f64
  * :228-246; log-spot update :281-332).  In-place advance of (log_s[n], vol[n_factors][n], qvar[n]) over nb_steps of

@@ -174,13 +174,34 @@ class OptionChain:
         """model prices -> Black implied vols, slice by slice (reference data/option_chain.py:327-346).
 
         The reference delegates to the third-party `vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices`,
-        which is not available here: this is a textbook Black-76 inversion on the host (a few dozen numbers per
-        chain; not on the GPU path), for 'C' and 'P'.  Parity with the third-party routine is UNPINNED
-        (SURVEY.md 8c); prices outside the no-arbitrage band give NaN."""
+        which is not available here: this is a textbook Black-76 inversion for 'C' and 'P' done by libsvmc's host
+        routine svmc_black_implied_vols (safeguarded Newton; a few dozen numbers per chain, so deliberately not a
+        kernel).  Parity with the third-party routine is UNPINNED; prices outside the band
+        attainable for vols in [1e-6, 10] give NaN."""
         forwards = self.forwards if forwards is None else forwards
-        return [infer_black_ivols(np.asarray(p, dtype=float), float(t), float(f), np.asarray(k, dtype=float), ty, float(d))
+        return [black_ivols_native(np.asarray(p, dtype=float), float(t), float(f), np.asarray(k, dtype=float), ty, float(d))
                 for p, t, f, k, ty, d in zip(model_prices, self.ttms, forwards, self.strikes_ttms,
                                              self.optiontypes_ttms, self.discfactors)]
+
+
+def black_ivols_native(prices: np.ndarray, ttm: float, forward: float, strikes: np.ndarray, optiontypes,
+                       discfactor: float = 1.0, lo: float = 1e-6, hi: float = 10.0) -> np.ndarray:
+    """svmc_black_implied_vols through ctypes; same contract as infer_black_ivols below (the NumPy bisection kept as
+    the independent check)"""
+    import ctypes as C
+    from .. import _lib
+    types = np.asarray(optiontypes).astype(str)
+    if not np.all(np.isin(types, ("C", "P"))):
+        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
+    prices = np.ascontiguousarray(prices, dtype=np.float64)
+    strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+    codes = np.ascontiguousarray(types != "C", dtype=np.int8)            # SVMC_CALL = 0, SVMC_PUT = 1
+    out = np.empty(strikes.shape, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _lib.check(_lib.load().svmc_black_implied_vols(prices.ctypes.data_as(dp), strikes.ctypes.data_as(dp),
+                                                   codes.ctypes.data_as(C.POINTER(C.c_int8)), strikes.size,
+                                                   forward, ttm, discfactor, lo, hi, out.ctypes.data_as(dp)))
+    return out
 
 
 def black_price(forward: float, strikes: np.ndarray, ttm: float, vol: np.ndarray, is_call: np.ndarray,

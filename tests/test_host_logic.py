@@ -197,3 +197,33 @@ def test_option_chain_calibration_helpers():
           black_price(1.05, k, 1.0, y[1] - h, np.array([False, True, True]))) / (2 * h)
     assert np.allclose(v[1], fd, rtol=1e-6)
     assert np.allclose(chain.get_chain_vegas(is_unit_ttm_vega=True)[0], black_vega(1.0, k, 1.0, y[0]))
+
+
+def test_native_black_implied_vols_vs_bisection():
+    """svmc_black_implied_vols (host routine of libsvmc, no GPU involved) against the NumPy bisection and the truth"""
+    from stochvolmodels_amd.data.option_chain import black_ivols_native, black_price, infer_black_ivols
+    rng = np.random.default_rng(0)
+    n_checked = 0
+    for _ in range(200):
+        F, T, df = rng.uniform(0.5, 100), rng.uniform(0.01, 3), rng.uniform(0.9, 1)
+        k = F * np.exp(rng.normal(0, 0.4, 25))
+        ty = rng.choice(["C", "P"], 25)
+        vol = rng.uniform(0.02, 3, 25)
+        pr = black_price(F, k, T, vol, ty == "C", df)
+        a, b = black_ivols_native(pr, T, F, k, ty, df), infer_black_ivols(pr, T, F, k, ty, df)
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        otm = (k >= F) == (ty == "C")
+        tv = np.where(otm, pr / df, pr / df - np.abs(F - k)) / F       # time value per unit forward
+        m = ~np.isnan(a) & (tv > 1e-7)                                  # below that the INPUT price is rounding noise
+        np.testing.assert_allclose(a[m], b[m], rtol=1e-8)
+        np.testing.assert_allclose(a[m], vol[m], rtol=1e-7)
+        n_checked += int(m.sum())
+    assert n_checked > 4000
+    # far tail: prices down to 1e-300 are still inverted on the log scale
+    a = black_ivols_native(np.array([1.3377398071023282e-297 * 50.0]), 1.0, 50.0, np.array([50.0 * np.exp(1.1555)]), ["C"])
+    assert np.isfinite(a[0]) and 0.02 < a[0] < 0.05
+    # contract: NaN outside the attainable band / for NaN prices; error for inverse payoffs
+    out = black_ivols_native(np.array([0.0, np.nan, 2.0, 0.05]), 1.0, 1.0, np.array([1.0, 1.0, 1.0, 1.0]), ["C"] * 4)
+    assert np.isnan(out[:3]).all() and abs(out[3] - 0.12538) < 1e-4
+    with pytest.raises(NotImplementedError):
+        black_ivols_native(np.array([0.1]), 1.0, 1.0, np.array([1.0]), ["IC"])

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""
+Where one calibration objective evaluation spends its time: BTC-style 4-expiry chain, MC engine on
+resident fixed randoms.  Prints one JSON object per line.
+
+    python tools/bench_calibration.py [nb_path]
+"""
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import stochvolmodels_amd as sv  # noqa: E402
+from stochvolmodels_amd.pricers import logsv_pricer as lp  # noqa: E402
+
+
+def main():
+    nb_path = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
+    k = np.linspace(0.7, 1.3, 13)
+    ty = np.where(k >= 1.0, "C", "P")
+    chain0 = sv.OptionChain(ttms=ttms, forwards=np.ones(4), strikes_ttms=(k,) * 4, optiontypes_ttms=(ty,) * 4,
+                            discfactors=np.ones(4), ids=np.array(list("abcd")))
+    p = sv.LOGSV_BTC_PARAMS
+    t0 = time.perf_counter()
+    W = lp.get_randoms_for_chain_valuation(ttms, nb_path=nb_path, nb_steps_per_year=360, seed=10)
+    t_draw = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = lp.upload_fixed_randoms(*W)
+    t_up = time.perf_counter() - t0
+    kw = dict(ttms=ttms, forwards=chain0.forwards, discfactors=chain0.discfactors, strikes_ttms=chain0.strikes_ttms,
+              optiontypes_ttms=chain0.optiontypes_ttms, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2,
+              beta=p.beta, volvol=p.volvol, vol_backbone_etas=np.ones(4))
+
+    def price():
+        return lp.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **kw)[0]
+
+    def ivols(prices):
+        return chain0.compute_model_ivols_from_chain_data(model_prices=prices)
+
+    pr = price()
+    ivols(pr)
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pr = price()
+    t_price = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ivols(pr)
+    t_iv = (time.perf_counter() - t0) / n
+    steps = sum(res.nb_steps)
+    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price,
+                          ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
+    prof = cProfile.Profile()
+    prof.enable()
+    for _ in range(20):
+        ivols(price())
+    prof.disable()
+    s = io.StringIO()
+    pstats.Stats(prof, stream=s).sort_stats("cumulative").print_stats(18)
+    print(s.getvalue()[:3500])
+
+
+if __name__ == "__main__":
+    main()
