@@ -117,6 +117,11 @@ int svmc_memcpy_d2d(void *dst, const void *src, size_t bytes, svmc_stream_t stre
 int svmc_memcpy2d_h2d(void *dst, size_t dst_pitch_bytes, const void *src_host, size_t src_pitch_bytes,
                       size_t width_bytes, size_t height, svmc_stream_t stream)
 {
+    if (width_bytes == 0 || height == 0) return SVMC_OK;
+    if (dst_pitch_bytes == width_bytes && src_pitch_bytes == width_bytes) {      // whole rows: one linear copy
+        SVMC_HIP_TRY(hipMemcpyAsync(dst, src_host, width_bytes * height, hipMemcpyHostToDevice, as_stream(stream)));
+        return SVMC_OK;
+    }
     SVMC_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch_bytes, src_host, src_pitch_bytes, width_bytes, height,
                                   hipMemcpyHostToDevice, as_stream(stream)));
     return SVMC_OK;
