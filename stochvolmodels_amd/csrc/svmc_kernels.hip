@@ -76,16 +76,51 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// One halving level of the multi-value butterfly: lanes with (lane & MASK) set keep the upper half of v[0..2H),
+// the others the lower half, and add the partner lane's copy of the half they keep.
+template <int H, int MASK>
+__device__ __forceinline__ void butterfly_halve(const double *v, double *w, int lane)
+{
+    const bool hi = (lane & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const double mine = hi ? v[H + j] : v[j];
+        const double other = hi ? v[j] : v[H + j];
+        w[j] = mine + __shfl_xor(other, MASK, 64);
+    }
+}
+
 // every thread of the block calls; thread j < NV ends up writing the block total of v[j] to out[j]
 template <int NV>
 __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * NV] */, double *out, int n_out)
 {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    if (lane == 0) {
+    if constexpr (NV % 8 == 0) {
+        // NV values over 64 lanes in NV/2 + NV/4 + NV/8 + 3*NV/8 shuffles instead of 6*NV: three halving levels
+        // (xor 32, 16, 8) leave every lane with NV/8 partial sums of the index block its bits 5..3 select, three
+        // plain levels (xor 4, 2, 1) finish them.  Fixed tree, hence deterministic.
+        double a[NV / 2], b[NV / 4], c[NV / 8];
+        butterfly_halve<NV / 2, 32>(v, a, lane);
+        butterfly_halve<NV / 4, 16>(a, b, lane);
+        butterfly_halve<NV / 8, 8>(b, c, lane);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) lds[wave * NV + j] = v[j];
+        for (int j = 0; j < NV / 8; ++j) {
+            c[j] += __shfl_xor(c[j], 4, 64);
+            c[j] += __shfl_xor(c[j], 2, 64);
+            c[j] += __shfl_xor(c[j], 1, 64);
+        }
+        if ((lane & 7) == 0) {
+            const int off = ((lane & 32) ? NV / 2 : 0) + ((lane & 16) ? NV / 4 : 0) + ((lane & 8) ? NV / 8 : 0);
+#pragma unroll
+            for (int j = 0; j < NV / 8; ++j) lds[wave * NV + off + j] = c[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) lds[wave * NV + j] = v[j];
+        }
     }
     __syncthreads();
     if (static_cast<int>(threadIdx.x) < n_out) {
@@ -514,7 +549,10 @@ struct PayoffArgs {
 };
 
 // grid = (path blocks, strike chunks of KC): every block owns KC strikes of a path range, so the per-strike
-// accumulators stay in 48 VGPRs (8 waves/SIMD) and all strikes of a slice run in ONE launch.
+// accumulators stay in 48 VGPRs (8 waves/SIMD) and all strikes of a slice run in ONE launch.  The block's strikes,
+// types and shifts are read from the kernel arguments ONCE, before the path loop (left to the compiler they were
+// re-fetched with a scalar load + wait per strike per path).  HAS_INV = false drops the per-strike division.
+template <bool HAS_INV>
 __global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__restrict__ x,
                                                             const double *__restrict__ qvar, size_t n,
                                                             double forward, double ttm,
@@ -526,23 +564,33 @@ __global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__rest
     const int k0 = blockIdx.y * KC;
     const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
-    double acc[3 * KC];
+    double acc[3 * KC], K[KC], shift[KC];
+    bool is_call[KC], is_inv[KC], live[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        live[k] = k0 + k < pa.k;
+        const int kk = live[k] ? k0 + k : 0;
+        K[k] = pa.strikes[kk];
+        shift[k] = pa.shifts[kk];
+        const int ty = pa.types[kk];
+        is_call[k] = ty == SVMC_CALL || ty == SVMC_INV_CALL;
+        is_inv[k] = ty == SVMC_INV_CALL || ty == SVMC_INV_PUT;
+    }
 #pragma unroll
     for (int j = 0; j < 3 * KC; ++j) acc[j] = 0.0;
+    const bool need_q = variable_type != SVMC_LOG_RETURN;
 
     for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
         const double spot = forward * exp(x[i]) - corr;                                         // :61-63
-        const double u = (variable_type == SVMC_LOG_RETURN) ? spot : qvar[i] / ttm;             // :65-68
+        const double u = need_q ? qvar[i] / ttm : spot;                                         // :65-68
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
-            if (k0 + k < pa.k) {
-                const double K = pa.strikes[k0 + k];
-                const int ty = pa.types[k0 + k];
-                double pay = (ty == SVMC_CALL || ty == SVMC_INV_CALL) ? ((u > K) ? (u - K) : 0.0)   // :75-78
-                                                                      : ((u < K) ? (K - u) : 0.0);  // :79-82
-                if (ty == SVMC_INV_CALL || ty == SVMC_INV_PUT) pay = pay / spot;
+            if (live[k]) {                                                                      // block-uniform
+                double pay = is_call[k] ? ((u > K[k]) ? (u - K[k]) : 0.0)                       // :75-78
+                                        : ((u < K[k]) ? (K[k] - u) : 0.0);                      // :79-82
+                if (HAS_INV && is_inv[k]) pay = pay / spot;
                 if (pay == pay) {                                                               // nanmean/nanstd
-                    const double d = pay - pa.shifts[k0 + k];
+                    const double d = pay - shift[k];
                     acc[3 * k + 0] += d;
                     acc[3 * k + 1] = fma(d, d, acc[3 * k + 1]);
                     acc[3 * k + 2] += 1.0;
@@ -912,8 +960,14 @@ int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double 
             pa.types[k] = (k < pa.k) ? types_host[k0 + k] : 0;
         }
         const unsigned chunks = static_cast<unsigned>((pa.k + KC - 1) / KC);
-        hipLaunchKernelGGL(payoff_sums_kernel, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar, n_path,
-                           forward, ttm, spot_sums, pa, variable_type, partials);
+        bool has_inv = false;
+        for (int k = 0; k < pa.k; ++k) has_inv = has_inv || pa.types[k] == SVMC_INV_CALL || pa.types[k] == SVMC_INV_PUT;
+        if (has_inv)
+            hipLaunchKernelGGL(payoff_sums_kernel<true>, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar,
+                               n_path, forward, ttm, spot_sums, pa, variable_type, partials);
+        else
+            hipLaunchKernelGGL(payoff_sums_kernel<false>, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar,
+                               n_path, forward, ttm, spot_sums, pa, variable_type, partials);
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * pa.k), dim3(BLOCK), 0, as_stream(stream), partials,
                            static_cast<int>(g), 3 * KMAX, sums + 3 * k0);
     }
