@@ -7,46 +7,49 @@
 using namespace svmc;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(double *x, double *sigma, double *qvar, size_t n, int nb_steps, LogsvConsts c,
-                                         uint64_t seed)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k(double *x, double *sigma,
+                                                                                    double *qvar, size_t n,
+                                                                                    int nb_steps, LogsvFast c,
+                                                                                    uint64_t seed)
 {
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    double xv = x[p], s = sigma[p], q = qvar[p], L = log(s);
+    double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;
     for (int t = 0; t < nb_steps; ++t) {
         double w0, w1;
-        if (MODE == 0) {  // full
-            draw_normals(seed, 0, p, t, w0, w1);
-            logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);
+        uint32_t r[4];
+        if (MODE == 0) {  // the shipped step: draw + logsv_step_fast
+            draw_normals(seed, 0, p, t, tab, w0, w1);
+            logsv_step_fast(c, xv, L, s, s2, q, w0, w1);
         } else if (MODE == 1) {  // step only
             w0 = 1e-3 * (double)(t & 7); w1 = -w0;
-            logsv_step(c, xv, L, s, q, c.sdt * w0, c.sdt * w1);
-        } else if (MODE == 2) {  // philox only
-            uint32_t r[4];
-            philox4x32_10((uint32_t)p, 0, t, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            xv += u52(r[0], r[1]); q += u52(r[2], r[3]);
+            logsv_step_fast(c, xv, L, s, s2, q, w0, w1);
+        } else if (MODE == 2) {  // philox + mantissa conversion only
+            philox_draw(seed, 0, p, t, r);
+            xv += mantissa_1_2(r[0], r[1]); q += mantissa_1_2(r[2], r[3]);
         } else if (MODE == 3) {  // philox + box-muller
-            draw_normals(seed, 0, p, t, w0, w1);
+            draw_normals(seed, 0, p, t, tab, w0, w1);
             xv += w0; q += w1;
-        } else if (MODE == 4) {  // philox + log + sqrt
-            uint32_t r[4];
-            philox4x32_10((uint32_t)p, 0, t, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            xv += sqrt(-2.0 * log(u52(r[0], r[1]))); q += u52(r[2], r[3]);
-        } else if (MODE == 5) {  // philox + sincospi
-            uint32_t r[4];
-            philox4x32_10((uint32_t)p, 0, t, 0, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            double sn, cs; sincospi(2.0 * u52(r[2], r[3]), &sn, &cs);
-            xv += sn + u52(r[0], r[1]); q += cs;
+        } else if (MODE == 4) {  // philox + table log + sqrt
+            philox_draw(seed, 0, p, t, r);
+            const double e = neg_log_tab(mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53), tab);
+            xv += sqrt_pos(e + e); q += mantissa_1_2(r[2], r[3]);
+        } else if (MODE == 5) {  // philox + quarter-turn sincos
+            philox_draw(seed, 0, p, t, r);
+            double sn, cs; sincos_quarter(r[2] & 3u, mantissa_1_2(r[2], r[3]) - 1.5, sn, cs);
+            xv += sn + mantissa_1_2(r[0], r[1]); q += cs;
         } else if (MODE == 6) {  // exp only
-            L += 1e-3; s = exp(L); xv += s;
-        } else if (MODE == 7) {  // div only
-            s = c.k1theta / (s + 1.0); xv += s;
+            L += 1e-3; s = exp_fast(L); xv += s;
+        } else if (MODE == 7) {  // reciprocal only
+            s = rcp_fast(s + 1.0); xv += s;
         }
     }
     x[p] = xv; sigma[p] = s; qvar[p] = q;
 }
 
-template <int MODE> float run(double *x, double *s, double *q, size_t n, int nb, LogsvConsts c)
+template <int MODE> float run(double *x, double *s, double *q, size_t n, int nb, LogsvFast c)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<MODE>, dim3(n / 256), dim3(256), 0, 0, x, s, q, n, nb, c, 42ull);
@@ -66,8 +69,8 @@ int main()
     hipMemset(x, 0, n * 8); hipMemset(q, 0, n * 8);
     double *h = (double *)malloc(n * 8); for (size_t i = 0; i < n; ++i) h[i] = 0.8376;
     hipMemcpy(s, h, n * 8, hipMemcpyHostToDevice);
-    LogsvConsts c = make_logsv_consts(1.0 / 1024, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1.0, 1);
-    const char *names[] = {"full", "step only", "philox only", "philox+boxmuller", "philox+log+sqrt", "philox+sincospi", "exp only", "div only"};
+    const LogsvFast c = make_logsv_fast(make_logsv_consts(1.0 / 1024, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1.0, 1));
+    const char *names[] = {"full", "step only", "philox only", "philox+boxmuller", "philox+log+sqrt", "philox+sincos", "exp only", "rcp only"};
     float t[8];
     t[0] = run<0>(x, s, q, n, nb, c); hipMemcpy(s, h, n * 8, hipMemcpyHostToDevice);
     t[1] = run<1>(x, s, q, n, nb, c); hipMemcpy(s, h, n * 8, hipMemcpyHostToDevice);
