@@ -98,6 +98,8 @@ def init_from_env(backend: Optional[str] = None):
     if world <= 1:
         set_default_comm(None)
         return get_default_comm()
+    # the host driver of these boxes only supports dmabuf IPC; RCCL's cross-process handles need this before HIP starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
