@@ -127,6 +127,13 @@ SVMC_API int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_
                           double theta, double kappa1, double kappa2, double beta, double volvol,
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
                           size_t ldw, svmc_stream_t stream);
+/* svmc_logsv_terminal_w + the slice epilogue of svmc_logsv_slice_rng (snapshots, spot sums) in the same launch:
+ * one expiry of logsv_mc_chain_pricer_fixed_randoms (pricers/logsv_pricer.py:1140-1160) */
+SVMC_API int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                                double theta, double kappa1, double kappa2, double beta, double volvol,
+                                double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
+                                size_t ldw, double forward, double *x_snapshot, double *qvar_snapshot,
+                                double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 
 /* ---- LogSV volatility paths on the full time grid: simulate_vol_paths, pricers/logsv_pricer.py:870-947 ---
  * sigma_t[(t+1)*ld + p] for t = 0..nb_steps-1, row 0 = v0 (written too): an explicit Euler scheme on L = ln sigma
@@ -162,6 +169,15 @@ SVMC_API int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar,
                                        double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
                                        uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
                                        svmc_stream_t stream);
+/* the same with the slice epilogue (x_snapshot <- log_s, qvar_snapshot <- qvar, spot sums): one expiry of
+ * rough_logsv_mc_chain_pricer_fixed_randoms (pricers/logsv_pricer.py:1206-1230) in one stepping launch */
+SVMC_API int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
+                                    int n_factors, const double *nodes_host, const double *weights_host,
+                                    const double *v0_host, double theta, double kappa1, double kappa2, double rho,
+                                    double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
+                                    uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
+                                    double forward, double *x_snapshot, double *qvar_snapshot, double *spot_sums,
+                                    void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 
 /* ---- Heston generator: simulate_heston_x_vol_terminal, pricers/heston_pricer.py:334-381 ----------
  * `var` is the variance (the reference returns variance, not vol).  scheme = SVMC_HESTON_EULER_FLOOR

@@ -264,19 +264,25 @@ __device__ __forceinline__ void streamed_time_loop(const double *const (&w)[NARR
 __global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                         double *__restrict__ qvar, size_t n, int nb_steps,
                                                         LogsvConsts c, const double *__restrict__ W0,
-                                                        const double *__restrict__ W1, size_t ldw)
+                                                        const double *__restrict__ W1, size_t ldw, SliceOut so)
 {
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    if (p >= n) return;
-    double xv = x[p], s = sigma[p], q = qvar[p];
-    double L = log(s);
-    const double *const w[2] = {W0 + p, W1 + p};
-    streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&v)[2]) {
-        logsv_step(c, xv, L, s, q, c.sdt * v[0], c.sdt * v[1]);                                   // :1028-1030
-    });
-    x[p] = xv;
-    sigma[p] = s;
-    qvar[p] = q;
+    const bool active = p < n;
+    double xv = 0.0, q = 0.0;
+    if (active) {
+        xv = x[p];
+        q = qvar[p];
+        double s = sigma[p];
+        double L = log(s);
+        const double *const w[2] = {W0 + p, W1 + p};
+        streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&v)[2]) {
+            logsv_step(c, xv, L, s, q, c.sdt * v[0], c.sdt * v[1]);                               // :1028-1030
+        });
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
+    }
+    slice_epilogue(so, p, active, xv, q);
 }
 
 // Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
@@ -413,37 +419,41 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
                                                             RoughConsts c, const double *__restrict__ Z0,
                                                             const double *__restrict__ Z1, size_t ldw, uint64_t seed,
                                                             uint32_t c3, uint64_t path_offset, uint32_t step_offset,
-                                                            int from_origin)
+                                                            int from_origin, SliceOut so)
 {
     __shared__ LogTabEntry s_tab[256];
     const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    if (p >= n) return;
-    double v[N], ls = 0.0, y = 0.0;
-    if (from_origin) {                       // (log_s, v, y) = (0, v0, 0): the chain pricer restarts every expiry here
+    const bool active = p < n;
+    double ls = 0.0, y = 0.0;
+    if (active) {
+        double v[N];
+        if (from_origin) {                   // (log_s, v, y) = (0, v0, 0): the chain pricer restarts every expiry here
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = c.v0[i];
-    } else {
-        ls = log_s[p];
-        y = yq[p];
+            for (int i = 0; i < N; ++i) v[i] = c.v0[i];
+        } else {
+            ls = log_s[p];
+            y = yq[p];
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = vol[static_cast<size_t>(i) * n + p];
-    }
-    if (RNG) {
-        const uint64_t gp = path_offset + p;
-        for (int t = 0; t < nb_steps; ++t) {
-            double z0, z1;
-            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-            rough_step<N>(c, v, ls, y, z0, z1);
+            for (int i = 0; i < N; ++i) v[i] = vol[static_cast<size_t>(i) * n + p];
         }
-    } else {
-        const double *const w[2] = {Z0 + p, Z1 + p};
-        streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1]); });
-    }
+        if (RNG) {
+            const uint64_t gp = path_offset + p;
+            for (int t = 0; t < nb_steps; ++t) {
+                double z0, z1;
+                draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
+                rough_step<N>(c, v, ls, y, z0, z1);
+            }
+        } else {
+            const double *const w[2] = {Z0 + p, Z1 + p};
+            streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1]); });
+        }
 #pragma unroll
-    for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];
-    log_s[p] = ls;
-    yq[p] = y;
+        for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];
+        log_s[p] = ls;
+        yq[p] = y;
+    }
+    slice_epilogue(so, p, active, ls, y);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -738,19 +748,45 @@ int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
+static int logsv_w_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
+                          double theta, double kappa1, double kappa2, double beta, double volvol,
+                          double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1, size_t ldw,
+                          const SliceOut &so, svmc_stream_t stream)
+{
+    if (int rc = check_state(fn, x, sigma, qvar, nb_steps, dt)) return rc;
+    if (W0 == nullptr || W1 == nullptr) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null W0/W1");
+    if (ldw < n_path) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": ldw < n_path");
+    if (n_path == 0 || (nb_steps == 0 && so.partials == nullptr)) return SVMC_OK;
+    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure);
+    hipLaunchKernelGGL(logsv_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
+                       n_path, nb_steps, c, W0, W1, ldw, so);
+    return check_launch(fn);
+}
+
 int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
                           double theta, double kappa1, double kappa2, double beta, double volvol,
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,
                           size_t ldw, svmc_stream_t stream)
 {
-    if (int rc = check_state("svmc_logsv_terminal_w", x, sigma, qvar, nb_steps, dt)) return rc;
-    SVMC_REQUIRE(W0 && W1, "svmc_logsv_terminal_w: null W0/W1");
-    SVMC_REQUIRE(ldw >= n_path, "svmc_logsv_terminal_w: ldw < n_path");
-    if (n_path == 0 || nb_steps == 0) return SVMC_OK;
-    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure);
-    hipLaunchKernelGGL(logsv_w_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, W0, W1, ldw);
-    return check_launch("svmc_logsv_terminal_w");
+    const SliceOut none = {nullptr, nullptr, nullptr, 0.0};
+    return logsv_w_launch("svmc_logsv_terminal_w", x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta,
+                          volvol, vol_backbone_eta, is_spot_measure, W0, W1, ldw, none, stream);
+}
+
+int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
+                       double kappa1, double kappa2, double beta, double volvol, double vol_backbone_eta,
+                       int is_spot_measure, const double *W0, const double *W1, size_t ldw, double forward,
+                       double *x_snapshot, double *qvar_snapshot, double *spot_sums, void *workspace,
+                       size_t workspace_bytes, svmc_stream_t stream)
+{
+    const char *fn = "svmc_logsv_slice_w";
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_logsv_slice_w: n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = logsv_w_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
+                                vol_backbone_eta, is_spot_measure, W0, W1, ldw, so, stream))
+        return rc;
+    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0, double theta,
@@ -824,22 +860,22 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
-int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
-                              int n_factors, const double *nodes_host, const double *weights_host,
+static int rough_logsv_launch(const char *name, double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps,
+                              double h, int n_factors, const double *nodes_host, const double *weights_host,
                               const double *v0_host, double theta, double kappa1, double kappa2, double rho,
                               double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
                               uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
-                              svmc_stream_t stream)
+                              const SliceOut &so, svmc_stream_t stream)
 {
-    const char *fn = "svmc_rough_logsv_terminal";
-    if (int rc = check_state(fn, log_s, vol, qvar, nb_steps, h)) return rc;
-    SVMC_REQUIRE(n_factors >= 1 && n_factors <= 3, "svmc_rough_logsv_terminal: 1 <= n_factors <= 3");
-    SVMC_REQUIRE(nodes_host && weights_host && v0_host, "svmc_rough_logsv_terminal: null nodes/weights/v0");
-    SVMC_REQUIRE((Z0 == nullptr) == (Z1 == nullptr), "svmc_rough_logsv_terminal: Z0 and Z1 go together");
-    SVMC_REQUIRE(Z0 == nullptr || ldw >= n_path, "svmc_rough_logsv_terminal: ldw < n_path");
-    SVMC_REQUIRE(call_id < (1u << 24), "svmc_rough_logsv_terminal: call_id must fit 24 bits");
-    SVMC_REQUIRE(volvol > 0.0 && rho * rho <= 1.0, "svmc_rough_logsv_terminal: volvol > 0 and |rho| <= 1");
-    if (n_path == 0 || (nb_steps == 0 && !from_origin)) return SVMC_OK;
+    const std::string fn(name);
+    if (int rc = check_state(name, log_s, vol, qvar, nb_steps, h)) return rc;
+    SVMC_REQUIRE(n_factors >= 1 && n_factors <= 3, fn + ": 1 <= n_factors <= 3");
+    SVMC_REQUIRE(nodes_host && weights_host && v0_host, fn + ": null nodes/weights/v0");
+    SVMC_REQUIRE((Z0 == nullptr) == (Z1 == nullptr), fn + ": Z0 and Z1 go together");
+    SVMC_REQUIRE(Z0 == nullptr || ldw >= n_path, fn + ": ldw < n_path");
+    SVMC_REQUIRE(call_id < (1u << 24), fn + ": call_id must fit 24 bits");
+    SVMC_REQUIRE(volvol > 0.0 && rho * rho <= 1.0, fn + ": volvol > 0 and |rho| <= 1");
+    if (n_path == 0 || (nb_steps == 0 && !from_origin && so.partials == nullptr)) return SVMC_OK;
     RoughConsts c{};
     c.wsum = 0.0;
     c.w_lam_v0 = 0.0;
@@ -864,16 +900,48 @@ int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n
     do {                                                                                                               \
         if (Z0 != nullptr)                                                                                             \
             hipLaunchKernelGGL((rough_logsv_kernel<NF, false>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0, \
-                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin);                              \
+                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin, so);                          \
         else                                                                                                           \
             hipLaunchKernelGGL((rough_logsv_kernel<NF, true>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0,  \
-                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin);                              \
+                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin, so);                          \
     } while (0)
     if (n_factors == 1) SVMC_ROUGH_LAUNCH(1);
     else if (n_factors == 2) SVMC_ROUGH_LAUNCH(2);
     else SVMC_ROUGH_LAUNCH(3);
 #undef SVMC_ROUGH_LAUNCH
-    return check_launch(fn);
+    return check_launch(name);
+}
+
+int svmc_rough_logsv_terminal(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
+                              int n_factors, const double *nodes_host, const double *weights_host,
+                              const double *v0_host, double theta, double kappa1, double kappa2, double rho,
+                              double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
+                              uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
+                              svmc_stream_t stream)
+{
+    const SliceOut none = {nullptr, nullptr, nullptr, 0.0};
+    return rough_logsv_launch("svmc_rough_logsv_terminal", log_s, vol, qvar, n_path, nb_steps, h, n_factors, nodes_host,
+                              weights_host, v0_host, theta, kappa1, kappa2, rho, volvol, Z0, Z1, ldw, seed, call_id,
+                              path_offset, step_offset, from_origin, none, stream);
+}
+
+int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps, double h,
+                           int n_factors, const double *nodes_host, const double *weights_host, const double *v0_host,
+                           double theta, double kappa1, double kappa2, double rho, double volvol, const double *Z0,
+                           const double *Z1, size_t ldw, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                           uint32_t step_offset, int from_origin, double forward, double *x_snapshot,
+                           double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
+                           svmc_stream_t stream)
+{
+    const char *fn = "svmc_rough_logsv_slice";
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_rough_logsv_slice: n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = rough_logsv_launch(fn, log_s, vol, qvar, n_path, nb_steps, h, n_factors, nodes_host, weights_host,
+                                    v0_host, theta, kappa1, kappa2, rho, volvol, Z0, Z1, ldw, seed, call_id,
+                                    path_offset, step_offset, from_origin, so, stream))
+        return rc;
+    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,

@@ -260,24 +260,40 @@ class HipEngine:
             w0_ptr, w1_ptr, self.n_path if ldw is None else int(ldw), self.stream)))
 
     def rough_logsv(self, nb_steps, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0_ptr=None,
-                    z1_ptr=None, ldw=None, seed=0, call_id=0, step_offset=0, from_origin=True) -> None:
-        """rough LogSV terminal state in (x, factor buffer, qvar); randoms streamed from z0/z1 or drawn on device"""
+                    z1_ptr=None, ldw=None, seed=0, call_id=0, step_offset=0, from_origin=True, slice_out=None) -> None:
+        """rough LogSV terminal state in (x, factor buffer, qvar); randoms streamed from z0/z1 or drawn on device.
+        slice_out = (forward, snap_row, qvar_row | None, spot_ptr) adds the slice epilogue (svmc_rough_logsv_slice)."""
         nodes, weights, v0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (nodes, weights, v0))
         if not (nodes.ndim == 1 and nodes.shape == weights.shape == v0.shape):
             raise ValueError("nodes, weights and v0 must be 1-d arrays of one length")
-        if self._factors is None or self._factors.n < nodes.size * self.n_path:
-            if self._factors is not None:
-                self._factors.free()
+        if self._factors is None:
             self._factors = DeviceBuffer(3 * self.n_path)
         dp = C.POINTER(C.c_double)
-        self._timed("rough_logsv_kernel", lambda: _lib.check(self.lib.svmc_rough_logsv_terminal(
-            self.x.ptr, self._factors.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(h), int(nodes.size),
-            nodes.ctypes.data_as(dp), weights.ctypes.data_as(dp), v0.ctypes.data_as(dp), float(theta), float(kappa1),
-            float(kappa2), float(rho), float(volvol), z0_ptr, z1_ptr, self.n_path if ldw is None else int(ldw),
-            int(seed), int(call_id), self.path_offset, int(step_offset), int(bool(from_origin)), self.stream)))
+        args = (self.x.ptr, self._factors.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(h), int(nodes.size),
+                nodes.ctypes.data_as(dp), weights.ctypes.data_as(dp), v0.ctypes.data_as(dp), float(theta), float(kappa1),
+                float(kappa2), float(rho), float(volvol), z0_ptr, z1_ptr, self.n_path if ldw is None else int(ldw),
+                int(seed), int(call_id), self.path_offset, int(step_offset), int(bool(from_origin)))
+        if slice_out is None:
+            self._timed("rough_logsv_kernel",
+                        lambda: _lib.check(self.lib.svmc_rough_logsv_terminal(*args, self.stream)))
+            return
+        forward, snap_row, qvar_row, spot_ptr = slice_out
+        self._timed("rough_logsv_kernel", lambda: _lib.check(self.lib.svmc_rough_logsv_slice(
+            *args, float(forward), self.snapshot_ptr(snap_row), None if qvar_row is None else self.snapshot_ptr(qvar_row),
+            spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
 
     def get_factors(self, n_factors: int) -> np.ndarray:
         return self.download(self._factors.ptr, n_factors * self.n_path).reshape(n_factors, self.n_path)
+
+    def logsv_slice_w(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0_ptr, w1_ptr,
+                      forward, snap_row, qvar_row, spot_ptr, ldw=None) -> None:
+        """streamed-randoms advance + snapshot + spot sums of one expiry in one stepping launch (svmc_logsv_slice_w)"""
+        self._timed("logsv_w_kernel", lambda: _lib.check(self.lib.svmc_logsv_slice_w(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
+            float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
+            w0_ptr, w1_ptr, self.n_path if ldw is None else int(ldw), float(forward), self.snapshot_ptr(snap_row),
+            None if qvar_row is None else self.snapshot_ptr(qvar_row), spot_ptr, self.ws.ptr, self.ws_bytes,
+            self.stream)))
 
     def logsv_vol_paths(self, nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
                         brownians: Optional[np.ndarray] = None) -> np.ndarray:

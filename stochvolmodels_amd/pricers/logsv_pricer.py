@@ -429,17 +429,16 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         if resident:
-            eng.logsv_w(resident.nb_steps[i], resident.dts[i], theta, kappa1, kappa2, beta, volvol,
-                        float(vol_backbone_etas[i]), is_spot_measure, resident.w0[i].ptr, resident.w1[i].ptr)
-            eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+            eng.logsv_slice_w(resident.nb_steps[i], resident.dts[i], theta, kappa1, kappa2, beta, volvol,
+                              float(vol_backbone_etas[i]), is_spot_measure, resident.w0[i].ptr, resident.w1[i].ptr,
+                              forward, snap_row, qvar_row, spot_ptr)
             return
         W0, W1 = np.asarray(W0s[i]), np.asarray(W1s[i])
         if W0.shape != W1.shape or W0.shape[1] != nb_path:
             raise ValueError("every W0/W1 must have shape [nb_steps_i, nb_path]")
         w0, w1 = eng.upload_randoms((W0, W1), col0=offset)
-        eng.logsv_w(W0.shape[0], float(dts[i]), theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]),
-                    is_spot_measure, w0, w1)
-        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+        eng.logsv_slice_w(W0.shape[0], float(dts[i]), theta, kappa1, kappa2, beta, volvol,
+                          float(vol_backbone_etas[i]), is_spot_measure, w0, w1, forward, snap_row, qvar_row, spot_ptr)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance)
@@ -530,8 +529,8 @@ def rough_logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.nda
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         h = float(timegrids[i][1] - timegrids[i][0])
-        eng.rough_logsv(nbs[i], h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0, z1)
-        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+        eng.rough_logsv(nbs[i], h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0, z1,
+                        slice_out=(forward, snap_row, qvar_row, spot_ptr))
         if debug:
             x, _, _ = eng.get_state()
             vw = weights @ eng.get_factors(nodes.size)
@@ -562,8 +561,8 @@ def rough_logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfact
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         nb, h = grids[i]
-        eng.rough_logsv(nb, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, seed=rng_seed, call_id=call_id)
-        eng.finish_slice(forward, snap_row, qvar_row, spot_ptr)
+        eng.rough_logsv(nb, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, seed=rng_seed, call_id=call_id,
+                        slice_out=(forward, snap_row, qvar_row, spot_ptr))
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance, finalize=_rough_finalize(normalize_stderr))

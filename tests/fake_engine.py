@@ -96,7 +96,7 @@ class FakeEngine:
             eta=eta, is_spot_measure=is_spot_measure)
 
     def rough_logsv(self, nb_steps, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0_ptr=None, z1_ptr=None,
-                    ldw=None, seed=0, call_id=0, step_offset=0, from_origin=True):
+                    ldw=None, seed=0, call_id=0, step_offset=0, from_origin=True, slice_out=None):
         assert from_origin
         if z0_ptr is None:
             Z0, Z1 = oracle.fill_normals(seed, self.n_path, nb_steps, call_id=call_id, path_offset=self.path_offset,
@@ -111,6 +111,13 @@ class FakeEngine:
         L.svo_rough_logsv_terminal_w(self.n_path, nb_steps, h, n, p(nodes), p(weights), p(v0), theta, kappa1, kappa2, rho,
                                      volvol, p(ls), p(vol), p(y), p(Z0), p(Z1), Z0.shape[1])
         self.x, self.qvar, self.factors = ls, y, vol
+        if slice_out is not None:
+            self.finish_slice(*slice_out)
+
+    def logsv_slice_w(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0, w1, forward,
+                      snap_row, qvar_row, spot_ptr, ldw=None):
+        self.logsv_w(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0, w1, ldw)
+        self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
 
     # the two reduction kernels, restated on host memory (utils/mc_payoffs.py:61-86)
     def spot_sums(self, x_ptr, forward, out_ptr):
