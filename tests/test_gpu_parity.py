@@ -795,6 +795,12 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
                                            **{**kw, "strikes_ttms": [np.array([0.3, 0.5])] * 4,
                                               "optiontypes_ttms": [np.array(["C", "P"])] * 4})
     assert all(np.all(np.isfinite(p)) and np.all(p >= 0) for p in pq)
+    pqo, _ = oracle.rough_logsv_chain_fixed_randoms(kw["ttms"], kw["forwards"], kw["discfactors"],
+                                                    [np.array([0.3, 0.5])] * 4, [np.array(["C", "P"])] * 4, Z0, Z1,
+                                                    kw["sigma0"], kw["theta"], kw["kappa1"], kw["kappa2"], kw["beta"],
+                                                    kw["orthog_vol"], kw["weights"], kw["nodes"], grids, variable_type=2)
+    for i in range(len(grids)):
+        np.testing.assert_allclose(pq[i], pqo[i], rtol=1e-9, atol=1e-13)
     for i in range(len(grids)):
         err = np.sqrt(sd[i] ** 2 / n + g[f"h010_stderrs_{i}"] ** 2 / 10000)    # second return = payoff std here
         assert np.all(np.abs(pr[i] - g[f"h010_prices_{i}"]) <= 4.5 * err + 1e-12)
@@ -883,3 +889,63 @@ def test_calibration_errors(sv, golden):
                           optiontypes_ttms=(g["types"],) * 2, discfactors=np.ones(2), ids=np.array(["a", "b"]))
     with pytest.raises((ValueError, TypeError)):
         sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=bare, params0=p0, disp=False)
+
+
+def test_rough_cabi_continuation_and_errors(sv, oracle, golden):
+    """svmc_rough_logsv_terminal called directly: two half-range calls continuing from the resident state equal one
+    full-range call bit for bit (device RNG: the step offset carries the counter), and argument errors map to
+    ValueError"""
+    g = golden("rough")
+    nodes, weights = g["h010_nodes"], g["h010_weights"]
+    v0 = np.full(3, 0.377 / weights.sum())
+    n, nb, h = 4097, 40, 1.0 / 360
+    args = (nodes, weights, v0, 0.347, 1.29, 1.93, 0.8, 3.0)
+    eng = _engine(n, offset=77)
+    eng.rough_logsv(nb, h, *args, seed=9, call_id=2, from_origin=True)
+    full = (*eng.get_state(), eng.get_factors(3).copy())
+    eng.rough_logsv(nb // 2, h, *args, seed=9, call_id=2, from_origin=True)
+    eng.rough_logsv(nb - nb // 2, h, *args, seed=9, call_id=2, step_offset=nb // 2, from_origin=False)
+    two = (*eng.get_state(), eng.get_factors(3))
+    assert np.array_equal(full[0], two[0]) and np.array_equal(full[2], two[2]) and np.array_equal(full[3], two[3])
+    # the same numbers from the CPU twin
+    Z0, Z1 = oracle.fill_normals(9, n, nb, call_id=2, path_offset=77, stream=3)
+    ls, y = np.zeros(n), np.zeros(n)
+    vol = np.ascontiguousarray(np.repeat(v0[:, None], n, axis=1))
+    P = oracle._p
+    oracle.lib().svo_rough_logsv_terminal_w(n, nb, h, 3, P(np.ascontiguousarray(nodes)), P(np.ascontiguousarray(weights)),
+                                            P(v0), 0.347, 1.29, 1.93, 0.8, 3.0, P(ls), P(vol), P(y), P(Z0), P(Z1), n)
+    np.testing.assert_allclose(full[0], ls, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(full[3], vol, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(full[2], y, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        eng.rough_logsv(nb, h, np.ones(4), np.ones(4), np.ones(4), 0.3, 1.0, 1.0, 0.5, 1.0)        # 4 factors
+    with pytest.raises(ValueError):
+        eng.rough_logsv(nb, h, *args[:-2], 1.5, 3.0)                                                 # |rho| > 1
+    with pytest.raises(ValueError):
+        eng.rough_logsv(nb, h, *args, z0_ptr=eng.x.ptr, z1_ptr=None)                                 # Z0 without Z1
+    with pytest.raises(NotImplementedError):
+        sv.rough_logsv_mc_chain_pricer_fixed_randoms(
+            ttms=np.array([0.1]), forwards=np.ones(1), discfactors=np.ones(1), strikes_ttms=(np.ones(1),),
+            optiontypes_ttms=(np.array(["C"]),), Z0=np.zeros((40, 8)), Z1=np.zeros((40, 8)), sigma0=0.3, theta=0.3,
+            kappa1=1.0, kappa2=1.0, beta=0.1, orthog_vol=1.0, weights=np.ones(4), nodes=np.ones(4),
+            timegrids=[np.linspace(0, 0.1, 37)])
+
+
+def test_logsv_slice_w_equals_terminal_w_plus_reductions(sv):
+    """the fused streamed slice (svmc_logsv_slice_w) against svmc_logsv_terminal_w + snapshot + svmc_spot_sums"""
+    n, nb = 5000, 33
+    p = sv.LOGSV_BTC_PARAMS
+    a, b = _engine(n), _engine(n)
+    for e in (a, b):
+        e.fill_state(0.0, p.sigma0, 0.0)
+        e.reserve_snapshots(2)
+    wa, wb = a.fill_normals(nb, 5), b.fill_normals(nb, 5)
+    sa, _ = a.alloc_sums(2, "spot")
+    sb, _ = b.alloc_sums(2, "spot")
+    a.logsv_slice_w(nb, 1 / 360, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, 0.9, False, *wa, 1.02, 0, 1, sa)
+    b.logsv_w(nb, 1 / 360, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, 0.9, False, *wb)
+    b.finish_slice(1.02, 0, 1, sb)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.download(a.snapshot_ptr(0), 2 * n), b.download(b.snapshot_ptr(0), 2 * n))
+    np.testing.assert_allclose(a.download(sa, 2), b.download(sb, 2), rtol=1e-14)      # different reduction trees
