@@ -23,28 +23,33 @@ class CalibrationError(RuntimeError):
 
 
 def validate_optimization_result(result, bounds) -> np.ndarray:
-    """finite, in-bounds (1e-10 slack) 1-d vector of len(bounds) from a successful optimizer result, else
-    CalibrationError carrying the optimizer's message"""
+    """the optimizer's vector if the run succeeded and the vector is numeric, 1-d, of len(bounds), finite and inside
+    the box (1e-10 slack); CalibrationError with the optimizer's message otherwise (same contract and wording as the
+    reference's pricers/model_pricer.py:48-80)"""
     message = str(getattr(result, "message", "no optimizer message"))
-    if not bool(getattr(result, "success", False)):
-        raise CalibrationError(f"Calibration failed: {message}")
-    raw = getattr(result, "x", None)
-    if raw is None:
-        raise CalibrationError(f"Calibration returned no parameter vector: {message}")
+
+    def reject(what: str, cause=None):
+        raise CalibrationError(f"{what}: {message}") from cause
+
+    if not getattr(result, "success", False):
+        reject("Calibration failed")
+    if getattr(result, "x", None) is None:
+        reject("Calibration returned no parameter vector")
     try:
-        values = np.asarray(raw, dtype=float)
+        values = np.array(result.x, dtype=float)
     except (TypeError, ValueError) as error:
-        raise CalibrationError(f"Calibration returned a non-numeric parameter vector: {message}") from error
-    if values.ndim != 1 or values.size != len(bounds):
-        raise CalibrationError(f"Calibration returned a parameter vector with the wrong shape: {message}")
-    if not np.all(np.isfinite(values)):
-        raise CalibrationError(f"Calibration returned non-finite parameters: {message}")
+        reject("Calibration returned a non-numeric parameter vector", error)
+    if values.shape != (len(bounds),):
+        reject("Calibration returned a parameter vector with the wrong shape")
+    if not np.isfinite(values).all():
+        reject("Calibration returned non-finite parameters")
     slack = 1.0e-10
-    for value, (lower, upper) in zip(values, bounds):
-        if lower is not None and value < lower - slack:
-            raise CalibrationError(f"Calibration returned parameters below bounds: {message}")
-        if upper is not None and value > upper + slack:
-            raise CalibrationError(f"Calibration returned parameters above bounds: {message}")
+    lower = np.array([-np.inf if lo is None else lo for lo, _ in bounds], dtype=float)
+    upper = np.array([np.inf if hi is None else hi for _, hi in bounds], dtype=float)
+    if (values < lower - slack).any():
+        reject("Calibration returned parameters below bounds")
+    if (values > upper + slack).any():
+        reject("Calibration returned parameters above bounds")
     return values
 
 
