@@ -949,3 +949,41 @@ def test_logsv_slice_w_equals_terminal_w_plus_reductions(sv):
         assert np.array_equal(x, y)
     assert np.array_equal(a.download(a.snapshot_ptr(0), 2 * n), b.download(b.snapshot_ptr(0), 2 * n))
     np.testing.assert_allclose(a.download(sa, 2), b.download(sb, 2), rtol=1e-14)      # different reduction trees
+
+
+def test_two_engines_on_their_own_streams(sv):
+    """the ABI takes one HIP stream per call: two engines driven on two non-blocking streams, launches interleaved
+    from the host, give exactly what each gives alone on the default stream"""
+    import ctypes as C
+    from stochvolmodels_amd import _lib
+    from stochvolmodels_amd.engine import HipEngine
+    L = _lib.load()
+    p = sv.LOGSV_BTC_PARAMS
+    n, nb = 1 << 16, 200
+
+    def run(eng, seed):
+        eng.fill_state(0.0, p.sigma0, 0.0)
+        for k in range(4):                                  # four back-to-back slices of 50 steps
+            eng.logsv_rng(nb // 4, 1 / 360, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, 1.0, True, seed, 0, k * (nb // 4))
+
+    ref = []
+    for seed in (1, 2):
+        e = HipEngine(n)
+        run(e, seed)
+        ref.append(e.get_state())
+        e.close()
+    streams = [C.c_void_p(), C.c_void_p()]
+    for s in streams:
+        assert L.svmc_stream_create(C.byref(s)) == 0
+    engines = [HipEngine(n, stream=s) for s in streams]
+    for e in engines:
+        e.fill_state(0.0, p.sigma0, 0.0)
+    for k in range(4):                                      # interleave the two streams' launches
+        for e, seed in zip(engines, (1, 2)):
+            e.logsv_rng(nb // 4, 1 / 360, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, 1.0, True, seed, 0, k * (nb // 4))
+    for e, r in zip(engines, ref):
+        for a, b in zip(e.get_state(), r):
+            assert np.array_equal(a, b)
+        e.close()
+    for s in streams:
+        assert L.svmc_stream_destroy(s) == 0
