@@ -353,6 +353,26 @@ static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, 
     }
 }
 
+/* stream 4 (Heston QE): pair and uniform from one Philox call -- device twin draw_qe, csrc/svmc_rng.h */
+void svo_draw_qe(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, double *w0, double *w1, double *u)
+{
+    static const double HALF_PI = 1.57079632679489661923;
+    uint32_t r[4];
+    philox_draw(seed, call_id, path, step, 4u, r);
+    double u1 = m52(r[0] & 0xFFC00000u, r[1]) + 0x1.0p-53;
+    double rr = m52(r[2] & 0xFFC00000u, r[3]) - 0.5;
+    uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
+    *u = (double)k * 0x1.0p-32 + 0x1.0p-33;
+    double R = sqrt(-2.0 * log(u1));
+    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);
+    switch (r[2] & 3u) {
+    case 0: *w0 = R * c;  *w1 = R * s;  break;
+    case 1: *w0 = R * -s; *w1 = R * c;  break;
+    case 2: *w0 = R * -c; *w1 = R * -s; break;
+    default: *w0 = R * s; *w1 = R * -c; break;
+    }
+}
+
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step)
 {
     uint32_t r[4];
@@ -419,11 +439,12 @@ void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
         double xp = x[p], vp = var[p], qp = qvar[p];
         for (int t = 0; t < nb_steps; ++t) {
             uint32_t step = step_offset + (uint32_t)t;
-            svo_draw_normals(seed, call_id, path_offset + p, step, &w0, &w1);
             if (scheme == SVO_HESTON_QE) {
-                double u = svo_draw_uniform(seed, call_id, path_offset + p, step);
+                double u;
+                svo_draw_qe(seed, call_id, path_offset + p, step, &w0, &w1, &u);
                 heston_qe_step(&c, &xp, &vp, &qp, w0, w1, u);
             } else {
+                svo_draw_normals(seed, call_id, path_offset + p, step, &w0, &w1);
                 heston_euler_step(dt, theta, kappa, rho, rho_1, volvol, &xp, &vp, &qp, sdt * w0, sdt * w1);
             }
         }

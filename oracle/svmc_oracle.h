@@ -77,6 +77,7 @@ double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t
 
 /* Materialise the streams the kernels consume: W0/W1[t*ldw + p] for global path ids
  * path_offset + p, global step ids step_offset + t. */
+void svo_draw_qe(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, double *w0, double *w1, double *u);
 void svo_fill_normals_stream(uint64_t seed, uint32_t call_id, uint32_t stream, uint64_t path_offset,
                              uint32_t step_offset, size_t n_path, int nb_steps, double *W0, double *W1, size_t ldw);
 void svo_fill_normals(uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,

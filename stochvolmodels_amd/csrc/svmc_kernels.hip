@@ -479,10 +479,12 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         for (int t = 0; t < nb_steps; ++t) {
             const uint32_t step = step_offset + static_cast<uint32_t>(t);
             double w0, w1;
-            draw_normals(seed, c3, gp, step, tab, w0, w1);
             if (SCHEME == SVMC_HESTON_QE) {
-                heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return draw_uniform(seed, c3, gp, step); });
+                double u;
+                draw_qe(seed, c3, gp, step, tab, w0, w1, u);
+                heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
             } else {
+                draw_normals(seed, c3, gp, step, tab, w0, w1);
                 heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
             }
         }

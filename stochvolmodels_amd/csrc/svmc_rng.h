@@ -83,6 +83,27 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_
     w1 = R * sn;
 }
 
+// stream 4 (Heston QE): the Box-Muller pair AND the uniform of the exponential branch from ONE Philox call.
+// u1 and the angle keep 42 mantissa bits each (r1 / r3 + the top 10 bits of r0 / r2), the quadrant is r2 & 3, and
+// the 32 bits left over (r0[21:0] : r2[11:2]) make u = (k + 0.5) 2^-32 -- exact in fp64, so the CPU twin gets the
+// same bits.  42-bit radii reach 7.6 sigma; a 32-bit uniform truncates the exponential branch at e^-22.
+__device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
+                                        const LogTabEntry *tab, double &w0, double &w1, double &u)
+{
+    uint32_t r[4];
+    philox_draw(seed, c3 | 4u, path, step, r);
+    const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
+    const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
+    const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
+    u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
+    const double e = neg_log_tab(u1, tab);
+    const double R = sqrt_pos(e + e);
+    double sn, cs;
+    sincos_quarter(r[2] & 3u, rr, sn, cs);
+    w0 = R * cs;
+    w1 = R * sn;
+}
+
 // stream 1: one uniform in (0,1)
 __device__ __forceinline__ double draw_uniform(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step)
 {
