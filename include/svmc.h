@@ -242,6 +242,18 @@ SVMC_API int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_h
                                     double kappa2, double beta, double volvol, int is_spot_measure,
                                     int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
                                     double *prices_host, double *stderrs_host);
+/* the same chain on supplied randoms resident in HBM: logsv_mc_chain_pricer_fixed_randoms, pricers/logsv_pricer.py:
+ * 1100-1162.  W0s[i] / W1s[i] are DEVICE pointers to the UNSCALED N(0,1) of expiry i, [nb_steps_host[i]][ldw]; the
+ * arrays of pointers, step counts and dts are host arrays of n_expiries entries.  This is the inner loop of an MC
+ * calibration (:244-265): one call per optimizer iterate, nothing but the chain and the prices crosses PCIe. */
+SVMC_API int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                          const double *discfactors_host, const double *vol_backbone_etas_host,
+                                          int n_expiries, const double *strikes_host, const int8_t *types_host,
+                                          const size_t *strike_offsets_host, double v0, double theta, double kappa1,
+                                          double kappa2, double beta, double volvol, int is_spot_measure,
+                                          int variable_type, const double *const *W0s, const double *const *W1s,
+                                          const int *nb_steps_host, const double *dts_host, size_t ldw,
+                                          double *prices_host, double *stderrs_host);
 SVMC_API int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
                                      const double *discfactors_host, int n_expiries, const double *strikes_host,
                                      const int8_t *types_host, const size_t *strike_offsets_host, double v0,

@@ -180,6 +180,33 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
 }
 
+int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                 const double *discfactors_host, const double *vol_backbone_etas_host, int n_expiries,
+                                 const double *strikes_host, const int8_t *types_host, const size_t *strike_offsets_host,
+                                 double v0, double theta, double kappa1, double kappa2, double beta, double volvol,
+                                 int is_spot_measure, int variable_type, const double *const *W0s, const double *const *W1s,
+                                 const int *nb_steps_host, const double *dts_host, size_t ldw, double *prices_host,
+                                 double *stderrs_host)
+{
+    const char *fn = "svmc_logsv_chain_price_fixed";
+    Session *s = reinterpret_cast<Session *>(session);
+    const ChainView c = {n_expiries, ttms_host, forwards_host, discfactors_host, strikes_host, types_host, strike_offsets_host};
+    if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
+    SVMC_REQUIRE(W0s && W1s && nb_steps_host && dts_host, "svmc_logsv_chain_price_fixed: null randoms / grids");
+    const size_t n = s->n_path;
+    if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :1128-1130
+    for (int i = 0; i < c.m; ++i) {                                                                       // :1136-1160
+        const double eta = vol_backbone_etas_host ? vol_backbone_etas_host[i] : 1.0;
+        double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
+        if (int rc = svmc_logsv_slice_w(s->x, s->vol, s->qvar, n, nb_steps_host[i], dts_host[i], theta, kappa1, kappa2,
+                                        beta, volvol, eta, is_spot_measure, W0s[i], W1s[i], ldw, c.forwards[i],
+                                        s->snap + static_cast<size_t>(i) * n, qsnap, s->spot + 2 * i, s->ws, s->ws_bytes,
+                                        s->stream))
+            return rc;
+    }
+    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+}
+
 int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
                             const double *discfactors_host, int n_expiries, const double *strikes_host,
                             const int8_t *types_host, const size_t *strike_offsets_host, double v0, double theta,

@@ -13,7 +13,7 @@ class and fails loudly when libsvmc.so or a GPU is missing.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -360,6 +360,7 @@ class DeviceRandoms:
         self.n_local, self.col0 = int(n_local), int(col0)
         self.dts = [float(d) for d in dts]
         self.nb_steps, self.w0, self.w1 = [], [], []
+        self._session, self._session_strikes = None, 0
         for W0, W1 in zip(W0s, W1s):
             W0 = np.ascontiguousarray(W0, dtype=np.float64)
             W1 = np.ascontiguousarray(W1, dtype=np.float64)
@@ -383,6 +384,44 @@ class DeviceRandoms:
     def free(self) -> None:
         for b in self.w0 + self.w1:
             b.free()
+        if self._session is not None:
+            _lib.check(_lib.load().svmc_session_destroy(self._session))
+            self._session = None
+
+    def price_logsv_chain(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
+                          v0, theta, kappa1, kappa2, beta, volvol, etas, is_spot_measure: bool, variable_type: int
+                          ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """one call of the fused single-GPU driver svmc_logsv_chain_price_fixed on these randoms: every launch of
+        the chain queued back to back in C++, one synchronisation, prices and stderrs back (the inner loop of an MC
+        calibration).  Same kernels in the same order as mc_chain.price_chain_on_engine, hence the same bits."""
+        lib = _lib.load()
+        m = len(self)
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
+        total = int(offs[-1])
+        if self._session is None or self._session_strikes < total:
+            if self._session is not None:
+                _lib.check(lib.svmc_session_destroy(self._session))
+            sess = C.c_void_p()
+            _lib.check(lib.svmc_session_create(C.byref(sess), self.n_local, m, max(total, 1)))
+            self._session, self._session_strikes = sess, max(total, 1)
+        dp = C.POINTER(C.c_double)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)      # noqa: E731
+        ttms, forwards, discfactors, etas = f64(ttms), f64(forwards), f64(discfactors), f64(etas)
+        k_all = f64(np.concatenate(strikes)) if total else np.zeros(1)
+        c_all = np.ascontiguousarray(np.concatenate(codes), dtype=np.int8) if total else np.zeros(1, dtype=np.int8)
+        w0 = (C.c_void_p * m)(*[b.ptr for b in self.w0])
+        w1 = (C.c_void_p * m)(*[b.ptr for b in self.w1])
+        nbs = (C.c_int * m)(*self.nb_steps)
+        dts = f64(self.dts)
+        prices, stderrs = np.empty(max(total, 1)), np.empty(max(total, 1))
+        _lib.check(lib.svmc_logsv_chain_price_fixed(
+            self._session, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp),
+            etas.ctypes.data_as(dp), m, k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)),
+            offs.ctypes.data_as(C.POINTER(C.c_size_t)), float(v0), float(theta), float(kappa1), float(kappa2),
+            float(beta), float(volvol), int(bool(is_spot_measure)), int(variable_type), w0, w1, nbs,
+            dts.ctypes.data_as(dp), self.n_local, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp)))
+        return ([prices[offs[i]:offs[i + 1]].copy() for i in range(m)],
+                [stderrs[offs[i]:offs[i + 1]].copy() for i in range(m)])
 
 
 def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float

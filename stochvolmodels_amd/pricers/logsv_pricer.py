@@ -18,7 +18,7 @@ import numpy as np
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
-from ..engine import DeviceRandoms, get_engine, payoff_finalize
+from ..engine import DeviceRandoms, get_engine, option_type_codes, payoff_finalize
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
@@ -97,6 +97,9 @@ def _calibration_constraints(parse, constraints_type: ConstraintsType):
         raise NotImplementedError(f"{constraints_type}")
     return table[constraints_type]
 
+
+# single-GPU chains on resident randoms go through svmc_logsv_chain_price_fixed (one C++ call per chain) when True
+FUSED_FIXED_RANDOMS_DRIVER = True
 
 LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
 
@@ -424,6 +427,16 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     if resident and (resident.n_local, resident.col0) != (n_local, offset):
         raise ValueError("DeviceRandoms were uploaded for a different path shard")
+    if FUSED_FIXED_RANDOMS_DRIVER and resident and comm.world == 1 and len(resident) == len(ttms):
+        # single GPU, randoms resident: the whole chain in one call of the fused C++ driver
+        strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
+        codes = [option_type_codes(t) for t in optiontypes_ttms]
+        prices, stderrs = resident.price_logsv_chain(ttms, forwards, discfactors, [k.ravel() for k in strikes],
+                                                     [c.ravel() for c in codes], v0, theta, kappa1, kappa2, beta,
+                                                     volvol, vol_backbone_etas, is_spot_measure,
+                                                     variable_type_code(variable_type))
+        return ([p.reshape(np.shape(k)) for p, k in zip(prices, strikes_ttms)],
+                [e.reshape(np.shape(k)) for e, k in zip(stderrs, strikes_ttms)])
     eng = get_engine(n_local, path_offset=offset)
     eng.fill_state(0.0, v0, 0.0)
 

@@ -554,6 +554,16 @@ def test_resident_fixed_randoms(sv, golden):
     a, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **p2)
     b, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=g["dts"], **common, **p2)
     np.testing.assert_array_equal(np.stack(a), np.stack(b))
+    # the fused C++ driver behind the resident path, on quadratic-variance payoffs, against the Python chain driver
+    qv = dict(common, strikes_ttms=(np.array([0.2, 0.6, 1.0]),) * 2, optiontypes_ttms=(np.array(["C", "P", "C"]),) * 2,
+              variable_type=sv.VariableType.Q_VAR)
+    a, ea = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **qv, **p2)
+    b, eb = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=g["dts"], **qv, **p2)
+    np.testing.assert_array_equal(np.stack(a), np.stack(b))
+    np.testing.assert_array_equal(np.stack(ea), np.stack(eb))
+    with pytest.raises(ValueError):
+        sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **dict(qv, optiontypes_ttms=(
+            np.array(["C", "X", "C"]),) * 2), **p2)
     res.free()
 
 

@@ -57,7 +57,14 @@ def main():
         ivols(pr)
     t_iv = (time.perf_counter() - t0) / n
     steps = sum(res.nb_steps)
-    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price,
+    lp.FUSED_FIXED_RANDOMS_DRIVER = False
+    price()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        price()
+    t_price_py = (time.perf_counter() - t0) / n
+    lp.FUSED_FIXED_RANDOMS_DRIVER = True
+    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_python_driver_ms=1e3 * t_price_py,
                           ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
     prof = cProfile.Profile()
     prof.enable()
