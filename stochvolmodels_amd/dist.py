@@ -116,5 +116,11 @@ def init_from_env(backend: Optional[str] = None):
             dist.init_process_group(backend=backend, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
+        # RCCL builds its communicator (rings over xGMI) lazily at the first collective: do that here, once, not
+        # inside the first chain that is priced
+        warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", device) if backend == "nccl" else "cpu")
+        dist.all_reduce(warm)
+        if warm.is_cuda:
+            torch.cuda.synchronize(warm.device)
     set_default_comm(TorchComm())
     return get_default_comm()
