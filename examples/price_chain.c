@@ -1,6 +1,7 @@
 /*
  * price_chain.c -- a plain-C host of libsvmc.so: prices a two-expiry LogSV chain and a one-expiry Heston chain by
- * Monte Carlo on the GPU through the fused chain drivers of include/svmc.h and prints the results as JSON.
+ * Monte Carlo on the GPU through the fused chain drivers of include/svmc.h, re-prices one expiry on fixed randoms
+ * resident in HBM (the calibration inner loop) and prints the results as JSON.
  *
  *   gcc -O2 -Iinclude examples/price_chain.c -o price_chain -Lstochvolmodels_amd -lsvmc \
  *       -Wl,-rpath,$PWD/stochvolmodels_amd -lm
@@ -61,8 +62,33 @@ int main(int argc, char **argv)
     CHECK(svmc_heston_chain_price(session, ttms, forwards, discfactors, 1, strikes, types, offsets, 0.04, 0.04, 4.0, -0.5,
                                   0.4, SVMC_HESTON_EULER_FLOOR, 360, SVMC_LOG_RETURN, seed, 0, prices, stderrs));
     print_array("heston_prices", prices, 3, 0);
-    print_array("heston_stderrs", stderrs, 3, 1);
+    print_array("heston_stderrs", stderrs, 3, 0);
+
+    /* The inner loop of an MC calibration: fixed N(0,1) randoms resident in HBM (here drawn on the device; a
+     * calibration uploads its own with svmc_memcpy2d_h2d), the first expiry re-priced on them for two parameter
+     * sets with svmc_logsv_chain_price_fixed, and the call's price inverted to a Black vol on the host. */
+    const int nb_steps[1] = {12};
+    const double dts[1] = {0.1 / 12};
+    double *w0 = NULL, *w1 = NULL;
+    CHECK(svmc_malloc((void **)&w0, sizeof(double) * n_path * 12));
+    CHECK(svmc_malloc((void **)&w1, sizeof(double) * n_path * 12));
+    CHECK(svmc_fill_normals(w0, w1, n_path, n_path, 12, seed, 1, 0, 0, NULL));
+    CHECK(svmc_stream_synchronize(NULL));
+    const double *w0s[1] = {w0}, *w1s[1] = {w1};
+    double fixed_prices[6], ivol[1];
+    for (int it = 0; it < 2; ++it) {
+        const double volvol = it ? 1.2 : 1.8458;
+        CHECK(svmc_logsv_chain_price_fixed(session, ttms, forwards, discfactors, NULL, 1, strikes, types, offsets, 0.8376,
+                                           1.0413, 3.1844, 3.058, 0.1514, volvol, 1, SVMC_LOG_RETURN, w0s, w1s, nb_steps,
+                                           dts, n_path, fixed_prices + 3 * it, stderrs));
+    }
+    print_array("fixed_prices", fixed_prices, 6, 0);
+    CHECK(svmc_black_implied_vols(fixed_prices + 1, strikes + 1, types + 1, 1, forwards[0], ttms[0], discfactors[0], 1e-6,
+                                  10.0, ivol));
+    print_array("atm_call_ivol", ivol, 1, 1);
     printf("}\n");
+    CHECK(svmc_free(w0));
+    CHECK(svmc_free(w1));
 
     CHECK(svmc_session_destroy(session));
     return 0;

@@ -693,6 +693,19 @@ def test_c_host_example(sv, tmp_path):
                                        nb_path=65536, seed=123)
     np.testing.assert_array_equal(pr[0], out["heston_prices"])
     np.testing.assert_array_equal(sd[0], out["heston_stderrs"])
+    # the calibration inner loop from C: the same device-drawn randoms (call id 1) through the Python fixed-randoms API
+    eng = _engine(65536)
+    w0p, w1p = eng.fill_normals(12, 123, call_id=1)
+    W0, W1 = eng.download(w0p, 12 * 65536).reshape(12, -1), eng.download(w1p, 12 * 65536).reshape(12, -1)
+    for it, volvol in enumerate((P_.volvol, 1.2)):
+        pf, _ = sv.logsv_mc_chain_pricer_fixed_randoms(
+            ttms=ttms[:1], forwards=fw[:1], discfactors=df[:1], strikes_ttms=strikes[:1], optiontypes_ttms=types[:1],
+            W0s=[W0], W1s=[W1], dts=[0.1 / 12], v0=P_.sigma0, theta=P_.theta, kappa1=P_.kappa1, kappa2=P_.kappa2,
+            beta=P_.beta, volvol=volvol, vol_backbone_etas=np.ones(1))
+        np.testing.assert_array_equal(pf[0], out["fixed_prices"][3 * it:3 * it + 3])
+    from stochvolmodels_amd.data.option_chain import infer_black_ivols
+    iv = infer_black_ivols(np.array(out["fixed_prices"][1:2]), 0.1, 1.0, np.array([1.0]), ["C"], 0.99)
+    np.testing.assert_allclose(out["atm_call_ivol"], iv, rtol=1e-10)
 
 
 def test_reference_heston_and_logsv_mc_ci_tests(sv):
