@@ -344,7 +344,7 @@ class HipEngine:
             self.ws_bytes, self.stream))
 
     def close(self) -> None:
-        for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, *self._sums.values()):
+        for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values()):
             if b is not None:
                 b.free()
 

@@ -22,7 +22,6 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 from .engine import LOG_RETURN, Q_VAR, option_type_codes, payoff_finalize, payoff_shifts
-from .utils.config import VariableType
 
 
 def variable_type_code(variable_type) -> int:
