@@ -251,7 +251,7 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
         if (types[k] < SVO_CALL || types[k] > SVO_INV_PUT) return -1;
 
     double *spots = (double *)malloc(n_path * sizeof(double));
-    double *buf = (double *)malloc(n_path * sizeof(double));
+    double *buf = (double *)calloc(n_path ? n_path : 1, sizeof(double));
     size_t cnt = 0;
     for (size_t p = 0; p < n_path; ++p) {
         spots[p] = forward * exp(x[p]);
