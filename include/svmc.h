@@ -254,6 +254,12 @@ SVMC_API int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *
                                           int variable_type, const double *const *W0s, const double *const *W1s,
                                           const int *nb_steps_host, const double *dts_host, size_t ldw,
                                           double *prices_host, double *stderrs_host);
+/* svmc_logsv_chain_price_fixed captures its launches (state init, per-expiry stepping + spot sums, payoff sums, D2H)
+ * into a hipGraph the first time it sees a (chain, randoms) combination and replays it afterwards -- the model
+ * constants travel in a small device block the graph's first node refreshes.  On by default; results are identical
+ * either way.  svmc_session_graph_launches counts the replays (diagnostics). */
+SVMC_API int svmc_session_use_graphs(svmc_session_t session, int enable);
+SVMC_API int svmc_session_graph_launches(svmc_session_t session, size_t *count);
 SVMC_API int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
                                      const double *discfactors_host, int n_expiries, const double *strikes_host,
                                      const int8_t *types_host, const size_t *strike_offsets_host, double v0,

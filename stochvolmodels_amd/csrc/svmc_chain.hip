@@ -16,7 +16,21 @@
 
 namespace svmc {
 
+// A captured chain on fixed randoms (svmc_logsv_chain_price_fixed): everything that shapes the launches -- chain,
+// randoms, step counts -- is frozen in `key`; the model constants live in `params_dev`, refreshed from the pinned
+// `params_host` by the graph's first node, so one hipGraphLaunch re-prices the chain for a new parameter set.
+struct FixedGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<unsigned char> key;
+    double *params_host = nullptr, *params_dev = nullptr, *sums_host = nullptr;   // pinned / device / pinned
+    size_t params_doubles = 0, sums_doubles = 0;
+};
+
 struct Session {
+    bool use_graphs = true;
+    size_t graph_launches = 0;
+    FixedGraph fixed;
     size_t n_path = 0;
     int max_expiries = 0;
     size_t max_strikes = 0;
@@ -26,9 +40,20 @@ struct Session {
     hipStream_t stream = nullptr;
 };
 
+static void fixed_graph_release(FixedGraph &g)
+{
+    if (g.exec != nullptr) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph != nullptr) (void)hipGraphDestroy(g.graph);
+    if (g.params_host != nullptr) (void)hipHostFree(g.params_host);
+    if (g.sums_host != nullptr) (void)hipHostFree(g.sums_host);
+    if (g.params_dev != nullptr) (void)hipFree(g.params_dev);
+    g = FixedGraph();
+}
+
 static void session_release(Session *s)
 {
     if (s == nullptr) return;
+    fixed_graph_release(s->fixed);
     for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar),
                     static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
         if (p != nullptr) (void)hipFree(p);
@@ -80,11 +105,11 @@ static int check_chain(const char *fn, const Session *s, const ChainView &c, int
     return SVMC_OK;
 }
 
-// phases 3-4 of mc_chain.py: per-strike sums of every slice, one D2H, host finalisation
-static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type, double *prices, double *stderrs)
+// phase 3 of mc_chain.py: per-strike sums of every slice, queued on the session's stream
+static int enqueue_payoff_sums(Session *s, const ChainView &c, int variable_type, std::vector<double> &shifts)
 {
     const size_t n = s->n_path;
-    std::vector<double> shifts(c.offsets[c.m]);
+    shifts.resize(c.offsets[c.m]);
     for (int i = 0; i < c.m; ++i) {
         const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
         for (size_t j = 0; j < k; ++j) shifts[k0 + j] = payoff_shift(c.strikes[k0 + j], c.types[k0 + j], c.forwards[i], variable_type);
@@ -94,16 +119,37 @@ static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type
                                       s->sums + 3 * k0, s->ws, s->ws_bytes, s->stream))
             return rc;
     }
-    std::vector<double> sums(3 * c.offsets[c.m]);
-    SVMC_HIP_TRY(hipMemcpyAsync(sums.data(), s->sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+    return SVMC_OK;
+}
+
+// phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88)
+static int finalize_prices(const Session *s, const ChainView &c, const double *sums, const std::vector<double> &shifts,
+                           double *prices, double *stderrs)
+{
     for (int i = 0; i < c.m; ++i) {
         const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
-        if (int rc = svmc_payoff_finalize(sums.data() + 3 * k0, shifts.data() + k0, k, c.discfactors[i],
-                                          static_cast<double>(n), prices + k0, stderrs + k0))
+        if (int rc = svmc_payoff_finalize(sums + 3 * k0, shifts.data() + k0, k, c.discfactors[i],
+                                          static_cast<double>(s->n_path), prices + k0, stderrs + k0))
             return rc;
     }
     return SVMC_OK;
+}
+
+static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type, double *prices, double *stderrs)
+{
+    std::vector<double> shifts;
+    if (int rc = enqueue_payoff_sums(s, c, variable_type, shifts)) return rc;
+    std::vector<double> sums(3 * c.offsets[c.m]);
+    SVMC_HIP_TRY(hipMemcpyAsync(sums.data(), s->sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+    return finalize_prices(s, c, sums.data(), shifts, prices, stderrs);
+}
+
+template <class T>
+static void key_append(std::vector<unsigned char> &key, const T *p, size_t count)
+{
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
+    key.insert(key.end(), b, b + count * sizeof(T));
 }
 
 }  // namespace svmc
@@ -194,6 +240,70 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
     if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
     SVMC_REQUIRE(W0s && W1s && nb_steps_host && dts_host, "svmc_logsv_chain_price_fixed: null randoms / grids");
     const size_t n = s->n_path;
+    if (s->use_graphs) {
+        // ---- replay path: the launch structure is captured once per (chain, randoms) and replayed per parameter set
+        std::vector<unsigned char> key;
+        key_append(key, &c.m, 1);
+        key_append(key, &variable_type, 1);
+        key_append(key, &ldw, 1);
+        key_append(key, c.ttms, c.m);
+        key_append(key, c.forwards, c.m);
+        key_append(key, c.offsets, c.m + 1);
+        key_append(key, c.strikes, c.offsets[c.m]);
+        key_append(key, c.types, c.offsets[c.m]);
+        key_append(key, W0s, c.m);
+        key_append(key, W1s, c.m);
+        key_append(key, nb_steps_host, c.m);
+        FixedGraph &g = s->fixed;
+        const size_t n_params = 1 + static_cast<size_t>(c.m) * LOGSV_CONSTS_DOUBLES, n_sums = 3 * c.offsets[c.m];
+        std::vector<double> shifts(c.offsets[c.m]);
+        for (int i = 0; i < c.m; ++i)
+            for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k)
+                shifts[k] = payoff_shift(c.strikes[k], c.types[k], c.forwards[i], variable_type);
+        if (g.exec == nullptr || g.key != key) {
+            fixed_graph_release(g);
+            g.params_doubles = n_params;
+            g.sums_doubles = n_sums;
+            SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.params_host), n_params * sizeof(double), hipHostMallocDefault));
+            SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.sums_host), (n_sums ? n_sums : 1) * sizeof(double), hipHostMallocDefault));
+            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.params_dev), n_params * sizeof(double)));
+            SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+            int rc = SVMC_OK;
+            hipError_t e = hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess) rc = fill_state_indirect(s->x, s->vol, s->qvar, n, g.params_dev, s->stream);   // :1128-1130
+            for (int i = 0; i < c.m && e == hipSuccess && rc == SVMC_OK; ++i) {                                    // :1136-1160
+                double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
+                rc = logsv_slice_w_indirect(s->x, s->vol, s->qvar, n, nb_steps_host[i],
+                                            g.params_dev + 1 + static_cast<size_t>(i) * LOGSV_CONSTS_DOUBLES, W0s[i], W1s[i],
+                                            ldw, c.forwards[i], s->snap + static_cast<size_t>(i) * n, qsnap, s->spot + 2 * i,
+                                            s->ws, s->ws_bytes, s->stream);
+            }
+            std::vector<double> unused;
+            if (e == hipSuccess && rc == SVMC_OK) rc = enqueue_payoff_sums(s, c, variable_type, unused);
+            if (e == hipSuccess && rc == SVMC_OK && n_sums)
+                e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+            const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
+            if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
+            if (e != hipSuccess || e_end != hipSuccess) {
+                fixed_graph_release(g);
+                return fail(SVMC_ERR_HIP, std::string("svmc_logsv_chain_price_fixed: graph capture: ") +
+                                              hipGetErrorString(e != hipSuccess ? e : e_end));
+            }
+            SVMC_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            g.key = key;
+        }
+        g.params_host[0] = v0;
+        for (int i = 0; i < c.m; ++i)
+            logsv_consts_to_doubles(dts_host[i], theta, kappa1, kappa2, beta, volvol,
+                                    vol_backbone_etas_host ? vol_backbone_etas_host[i] : 1.0, is_spot_measure,
+                                    g.params_host + 1 + static_cast<size_t>(i) * LOGSV_CONSTS_DOUBLES);
+        for (int i = 0; i < c.m; ++i)
+            SVMC_REQUIRE(dts_host[i] > 0.0 && nb_steps_host[i] > 0, "svmc_logsv_chain_price_fixed: dt and nb_steps must be positive");
+        SVMC_HIP_TRY(hipGraphLaunch(g.exec, s->stream));
+        SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+        ++s->graph_launches;
+        return finalize_prices(s, c, g.sums_host, shifts, prices_host, stderrs_host);
+    }
     if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :1128-1130
     for (int i = 0; i < c.m; ++i) {                                                                       // :1136-1160
         const double eta = vol_backbone_etas_host ? vol_backbone_etas_host[i] : 1.0;
@@ -205,6 +315,22 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
             return rc;
     }
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+}
+
+int svmc_session_use_graphs(svmc_session_t session, int enable)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr, "svmc_session_use_graphs: null session");
+    s->use_graphs = enable != 0;
+    return SVMC_OK;
+}
+
+int svmc_session_graph_launches(svmc_session_t session, size_t *count)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr && count != nullptr, "svmc_session_graph_launches: null pointer");
+    *count = s->graph_launches;
+    return SVMC_OK;
 }
 
 int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,

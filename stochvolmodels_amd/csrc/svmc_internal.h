@@ -26,4 +26,14 @@ int fail(int code, const std::string &msg);
 
 inline hipStream_t as_stream(svmc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// svmc_kernels.hip: launches whose model constants live in device memory (graph replay, svmc_chain.hip)
+constexpr int LOGSV_CONSTS_DOUBLES = 13;
+int fill_state_indirect(double *x, double *vol, double *qvar, size_t n_path, const double *vol0_dev, hipStream_t stream);
+int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, const double *consts_dev,
+                           const double *W0, const double *W1, size_t ldw, double forward, double *x_snapshot,
+                           double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
+                           hipStream_t stream);
+void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
+                             int is_spot_measure, double *out);
+
 }  // namespace svmc

@@ -6,6 +6,8 @@
 // per load) in the streamed-randoms kernels.  No MFMA: the work is elementwise fp64 VALU +
 // transcendentals (DESIGN.md "Rooflines").
 #include "svmc_internal.h"
+
+#include <cstring>
 #include "svmc_models.h"
 #include "svmc_rng.h"
 
@@ -261,10 +263,10 @@ __device__ __forceinline__ void streamed_time_loop(const double *const (&w)[NARR
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, double *__restrict__ sigma,
-                                                        double *__restrict__ qvar, size_t n, int nb_steps,
-                                                        LogsvConsts c, const double *__restrict__ W0,
-                                                        const double *__restrict__ W1, size_t ldw, SliceOut so)
+__device__ __forceinline__ void logsv_w_body(double *__restrict__ x, double *__restrict__ sigma,
+                                             double *__restrict__ qvar, size_t n, int nb_steps, const LogsvConsts &c,
+                                             const double *__restrict__ W0, const double *__restrict__ W1, size_t ldw,
+                                             const SliceOut &so)
 {
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
@@ -283,6 +285,39 @@ __global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, 
         qvar[p] = q;
     }
     slice_epilogue(so, p, active, xv, q);
+}
+
+__global__ __launch_bounds__(BLOCK) void logsv_w_kernel(double *__restrict__ x, double *__restrict__ sigma,
+                                                        double *__restrict__ qvar, size_t n, int nb_steps,
+                                                        LogsvConsts c, const double *__restrict__ W0,
+                                                        const double *__restrict__ W1, size_t ldw, SliceOut so)
+{
+    logsv_w_body(x, sigma, qvar, n, nb_steps, c, W0, W1, ldw, so);
+}
+
+// The same kernel with its model constants read from device memory: every launch argument is then fixed for a given
+// chain and set of randoms, so the launch can sit in a captured hipGraph that is replayed for each new parameter set
+// (svmc_chain.hip) -- only the small constants block is rewritten between replays.
+__global__ __launch_bounds__(BLOCK) void logsv_w_indirect_kernel(double *__restrict__ x, double *__restrict__ sigma,
+                                                                 double *__restrict__ qvar, size_t n, int nb_steps,
+                                                                 const LogsvConsts *__restrict__ consts,
+                                                                 const double *__restrict__ W0,
+                                                                 const double *__restrict__ W1, size_t ldw, SliceOut so)
+{
+    const LogsvConsts c = *consts;                      // wave-uniform: scalar loads
+    logsv_w_body(x, sigma, qvar, n, nb_steps, c, W0, W1, ldw, so);
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__restrict__ x, double *__restrict__ vol,
+                                                                    double *__restrict__ qvar, size_t n,
+                                                                    const double *__restrict__ vol0)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p < n) {
+        x[p] = 0.0;
+        vol[p] = *vol0;
+        qvar[p] = 0.0;
+    }
 }
 
 // Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
@@ -790,6 +825,47 @@ int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, in
         return rc;
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
+
+}  // extern "C"
+
+namespace svmc {
+
+// internal entry points of the graph-replayed chain driver (svmc_chain.hip); same checks as their C-ABI twins
+int fill_state_indirect(double *x, double *vol, double *qvar, size_t n_path, const double *vol0_dev, hipStream_t stream)
+{
+    if (n_path == 0) return SVMC_OK;
+    hipLaunchKernelGGL(fill_state_indirect_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, stream, x, vol, qvar, n_path,
+                       vol0_dev);
+    return check_launch("fill_state_indirect");
+}
+
+int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps,
+                           const double *consts_dev, const double *W0, const double *W1, size_t ldw, double forward,
+                           double *x_snapshot, double *qvar_snapshot, double *spot_sums, void *workspace,
+                           size_t workspace_bytes, hipStream_t stream)
+{
+    const char *fn = "logsv_slice_w_indirect";
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    if (W0 == nullptr || W1 == nullptr || ldw < n_path || nb_steps <= 0 || n_path == 0)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad randoms / sizes");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    hipLaunchKernelGGL(logsv_w_indirect_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, stream, x, sigma, qvar, n_path,
+                       nb_steps, reinterpret_cast<const LogsvConsts *>(consts_dev), W0, W1, ldw, so);
+    if (int rc = check_launch(fn)) return rc;
+    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, reinterpret_cast<svmc_stream_t>(stream));
+}
+
+void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
+                             int is_spot_measure, double *out)
+{
+    const LogsvConsts c = make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure);
+    static_assert(sizeof(LogsvConsts) == LOGSV_CONSTS_DOUBLES * sizeof(double), "LogsvConsts layout");
+    memcpy(out, &c, sizeof(c));
+}
+
+}  // namespace svmc
+
+extern "C" {
 
 int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps, double dt, double v0, double theta,
                          double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,

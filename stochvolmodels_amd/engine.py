@@ -388,12 +388,21 @@ class DeviceRandoms:
             _lib.check(_lib.load().svmc_session_destroy(self._session))
             self._session = None
 
+    def graph_launches(self) -> int:
+        """how many chain pricings of this object were hipGraph replays (diagnostics)"""
+        if self._session is None:
+            return 0
+        n = C.c_size_t()
+        _lib.check(_lib.load().svmc_session_graph_launches(self._session, C.byref(n)))
+        return int(n.value)
+
     def price_logsv_chain(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
-                          v0, theta, kappa1, kappa2, beta, volvol, etas, is_spot_measure: bool, variable_type: int
-                          ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-        """one call of the fused single-GPU driver svmc_logsv_chain_price_fixed on these randoms: every launch of
-        the chain queued back to back in C++, one synchronisation, prices and stderrs back (the inner loop of an MC
-        calibration).  Same kernels in the same order as mc_chain.price_chain_on_engine, hence the same bits."""
+                          v0, theta, kappa1, kappa2, beta, volvol, etas, is_spot_measure: bool, variable_type: int,
+                          use_graph: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """one call of the fused single-GPU driver svmc_logsv_chain_price_fixed on these randoms: the chain's launches
+        captured once into a hipGraph and replayed per parameter set (use_graph=False: queued back to back instead),
+        one synchronisation, prices and stderrs back -- the inner loop of an MC calibration.  Same kernels in the
+        same order as mc_chain.price_chain_on_engine, hence the same bits."""
         lib = _lib.load()
         m = len(self)
         offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
@@ -404,6 +413,7 @@ class DeviceRandoms:
             sess = C.c_void_p()
             _lib.check(lib.svmc_session_create(C.byref(sess), self.n_local, m, max(total, 1)))
             self._session, self._session_strikes = sess, max(total, 1)
+        _lib.check(lib.svmc_session_use_graphs(self._session, int(bool(use_graph))))
         dp = C.POINTER(C.c_double)
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)      # noqa: E731
         ttms, forwards, discfactors, etas = f64(ttms), f64(forwards), f64(discfactors), f64(etas)

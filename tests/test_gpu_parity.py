@@ -561,6 +561,21 @@ def test_resident_fixed_randoms(sv, golden):
     b, eb = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W0s, W1s=W1s, dts=g["dts"], **qv, **p2)
     np.testing.assert_array_equal(np.stack(a), np.stack(b))
     np.testing.assert_array_equal(np.stack(ea), np.stack(eb))
+    # hipGraph replay of the fused driver: on by default, identical bits with it off, re-captured when the chain changes
+    from stochvolmodels_amd.engine import option_type_codes
+    assert res.graph_launches() >= 4
+    args = lambda c, pp, vt: (c["ttms"], c["forwards"], c["discfactors"], [np.asarray(k, float) for k in c["strikes_ttms"]],   # noqa: E731
+                              [option_type_codes(t) for t in c["optiontypes_ttms"]], pp["v0"], pp["theta"], pp["kappa1"],
+                              pp["kappa2"], pp["beta"], pp["volvol"], np.ones(2), True, vt)
+    for c, vt in ((common, 1), (qv, 2), (common, 1)):
+        for pp in (p, p2):
+            before = res.graph_launches()
+            g_on = res.price_logsv_chain(*args(c, pp, vt), use_graph=True)
+            assert res.graph_launches() == before + 1
+            g_off = res.price_logsv_chain(*args(c, pp, vt), use_graph=False)
+            assert res.graph_launches() == before + 1
+            for a_, b_ in zip(g_on[0] + g_on[1], g_off[0] + g_off[1]):
+                np.testing.assert_array_equal(a_, b_)
     with pytest.raises(ValueError):
         sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **dict(qv, optiontypes_ttms=(
             np.array(["C", "X", "C"]),) * 2), **p2)

@@ -64,7 +64,19 @@ def main():
         price()
     t_price_py = (time.perf_counter() - t0) / n
     lp.FUSED_FIXED_RANDOMS_DRIVER = True
-    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_python_driver_ms=1e3 * t_price_py,
+    from stochvolmodels_amd.engine import option_type_codes
+    direct = lambda g: res.price_logsv_chain(ttms, chain0.forwards, chain0.discfactors, [k] * 4,       # noqa: E731
+                                             [option_type_codes(ty)] * 4, p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta,
+                                             p.volvol, np.ones(4), True, 1, use_graph=g)
+    t_direct = {}
+    for g in (False, True):
+        direct(g)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            direct(g)
+        t_direct[g] = (time.perf_counter() - t0) / n
+    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
+                          fused_graph_ms=1e3 * t_direct[True],
                           ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
     prof = cProfile.Profile()
     prof.enable()
