@@ -218,6 +218,17 @@ SVMC_API int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path
                      const double *spot_sums, const double *strikes_host, const int8_t *types_host,
                      const double *shifts_host, size_t n_strikes, int variable_type, double *sums,
                      void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+/* svmc_payoff_sums for ALL expiries of a chain in one pair of launches (per 20 strike-chunks of 8): expiry i reads
+ * the snapshots x_snapshots_host[i] (and qvar_snapshots_host[i] for Q_VAR; HOST arrays of DEVICE pointers), its
+ * recentring sums spot_sums[2i..2i+1], forwards_host[i], ttms_host[i] and the strikes
+ * [strike_offsets_host[i], strike_offsets_host[i+1]) of the concatenated strikes / types / shifts; sums gets the
+ * 3 * strike_offsets_host[n_expiries] doubles in chain order.  Bit-identical to per-expiry svmc_payoff_sums. */
+SVMC_API int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host,
+                                    size_t n_path, const double *forwards_host, const double *ttms_host,
+                                    const double *spot_sums, int n_expiries, const double *strikes_host,
+                                    const int8_t *types_host, const double *shifts_host,
+                                    const size_t *strike_offsets_host, int variable_type, double *sums, void *workspace,
+                                    size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes,
                          double discfactor, double n_path_total, double *prices_host, double *stderrs_host);
 

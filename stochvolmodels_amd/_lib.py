@@ -72,6 +72,8 @@ def _declare(L: C.CDLL) -> None:
         "svmc_payoff_workspace_bytes": ([psz], i32),
         "svmc_slice_workspace_bytes": ([sz, psz], i32),
         "svmc_spot_sums": ([vp, sz, f64, vp, vp, sz, vp], i32),
+        "svmc_payoff_sums_chain": ([C.POINTER(vp), C.POINTER(vp), sz, pf64, pf64, vp, i32, pf64, pi8, pf64, psz, i32, vp, vp,
+                                    sz, vp], i32),
         "svmc_payoff_sums": ([vp, vp, sz, f64, f64, vp, pf64, pi8, pf64, sz, i32, vp, vp, sz, vp], i32),
         "svmc_logsv_mgf_grid": ([vp, vp, sz, f64, f64, f64, f64, f64, f64, f64, i32, i32, f64, vp, vp, f64, f64, vp], i32),
         "svmc_heston_mgf_grid": ([vp, vp, sz, f64, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp], i32),

@@ -110,16 +110,16 @@ static int enqueue_payoff_sums(Session *s, const ChainView &c, int variable_type
 {
     const size_t n = s->n_path;
     shifts.resize(c.offsets[c.m]);
+    std::vector<const double *> xs(c.m), qs(c.m);
     for (int i = 0; i < c.m; ++i) {
-        const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
-        for (size_t j = 0; j < k; ++j) shifts[k0 + j] = payoff_shift(c.strikes[k0 + j], c.types[k0 + j], c.forwards[i], variable_type);
-        const double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
-        if (int rc = svmc_payoff_sums(s->snap + static_cast<size_t>(i) * n, qsnap, n, c.forwards[i], c.ttms[i],
-                                      s->spot + 2 * i, c.strikes + k0, c.types + k0, shifts.data() + k0, k, variable_type,
-                                      s->sums + 3 * k0, s->ws, s->ws_bytes, s->stream))
-            return rc;
+        for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k)
+            shifts[k] = payoff_shift(c.strikes[k], c.types[k], c.forwards[i], variable_type);
+        xs[i] = s->snap + static_cast<size_t>(i) * n;
+        qs[i] = s->snap + static_cast<size_t>(c.m + i) * n;
     }
-    return SVMC_OK;
+    return svmc_payoff_sums_chain(xs.data(), variable_type == SVMC_Q_VAR ? qs.data() : nullptr, n, c.forwards, c.ttms,
+                                  s->spot, c.m, c.strikes, c.types, shifts.data(), c.offsets, variable_type, s->sums,
+                                  s->ws, s->ws_bytes, s->stream);
 }
 
 // phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88)

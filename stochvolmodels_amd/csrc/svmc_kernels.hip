@@ -17,6 +17,7 @@ constexpr int BLOCK = 256;             // 4 waves of 64 lanes
 constexpr int MAX_REDUCE_GRID = 1024;  // 256 CUs x 4 blocks: cap for grid-stride reductions
 constexpr int KC = 8;                  // strikes per payoff block (register accumulators: 3 doubles per strike)
 constexpr int KMAX = 32;               // strikes per payoff launch (grid.y = ceil(k / KC) chunks)
+constexpr int CHAIN_CHUNKS = 20;       // strike chunks (of any expiries) per chain-wide payoff launch: 20 x 192 B of kernarg
 
 // block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
 // 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
@@ -649,6 +650,70 @@ __global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__rest
     block_sum_store<3 * KC>(acc, lds, partials + static_cast<size_t>(blockIdx.x) * (3 * KMAX) + 3 * k0, n_out);
 }
 
+// ---- all expiries of a chain in one launch ----------------------------------------------------------------------
+// One block column (blockIdx.y) = one chunk of <= KC strikes of ONE expiry; the chunk descriptor carries that expiry's
+// snapshot pointers, forward and recentring sums.  Same per-lane path order, block reduction and column reduce as
+// payoff_sums_kernel, hence the same bits -- but 2 launches per chain instead of 2 per expiry.
+struct PayoffChunk {
+    const double *x, *qvar, *spot_sums;
+    double forward, ttm;
+    double strikes[KC], shifts[KC];
+    int8_t types[KC];
+    int k;      // live strikes in this chunk
+    int col;    // first output column of the chunk within this launch (in strikes)
+};
+struct PayoffChunkPack {
+    PayoffChunk c[CHAIN_CHUNKS];
+};
+
+template <bool HAS_INV>
+__global__ __launch_bounds__(BLOCK) void payoff_chain_kernel(PayoffChunkPack pack, size_t n, int variable_type,
+                                                             double *__restrict__ partials, int ld)
+{
+    __shared__ double lds[4 * 3 * KC];
+    const PayoffChunk &d = pack.c[blockIdx.y];
+    const double *__restrict__ x = d.x;
+    const double *__restrict__ qvar = d.qvar;
+    const double forward = d.forward, ttm = d.ttm;
+    const double corr = d.spot_sums[0] / d.spot_sums[1] - forward;                              // :62
+    const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
+    const int nk = d.k;
+    double acc[3 * KC], K[KC], shift[KC];
+    bool is_call[KC], is_inv[KC], live[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        live[k] = k < nk;
+        K[k] = d.strikes[k];
+        shift[k] = d.shifts[k];
+        const int ty = d.types[k];
+        is_call[k] = ty == SVMC_CALL || ty == SVMC_INV_CALL;
+        is_inv[k] = ty == SVMC_INV_CALL || ty == SVMC_INV_PUT;
+    }
+#pragma unroll
+    for (int j = 0; j < 3 * KC; ++j) acc[j] = 0.0;
+    const bool need_q = variable_type != SVMC_LOG_RETURN;
+
+    for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
+        const double spot = forward * exp(x[i]) - corr;                                         // :61-63
+        const double u = need_q ? qvar[i] / ttm : spot;                                         // :65-68
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (live[k]) {
+                double pay = is_call[k] ? ((u > K[k]) ? (u - K[k]) : 0.0)                       // :75-78
+                                        : ((u < K[k]) ? (K[k] - u) : 0.0);                      // :79-82
+                if (HAS_INV && is_inv[k]) pay = pay / spot;
+                if (pay == pay) {                                                               // nanmean/nanstd
+                    const double dd = pay - shift[k];
+                    acc[3 * k + 0] += dd;
+                    acc[3 * k + 1] = fma(dd, dd, acc[3 * k + 1]);
+                    acc[3 * k + 2] += 1.0;
+                }
+            }
+        }
+    }
+    block_sum_store<3 * KC>(acc, lds, partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col, 3 * nk);
+}
+
 // out[j] = sum_r partials[r * ld + j]; one block per column j
 __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials, int n_rows,
                                                                int ld, double *__restrict__ out)
@@ -1053,7 +1118,7 @@ int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_pat
 int svmc_payoff_workspace_bytes(size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_payoff_workspace_bytes: null output");
-    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KMAX * sizeof(double);
+    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * CHAIN_CHUNKS * sizeof(double);   // >= 3 * KMAX columns too
     return SVMC_OK;
 }
 
@@ -1061,7 +1126,7 @@ int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
     const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * sizeof(double);
-    const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KMAX * sizeof(double);
+    const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * CHAIN_CHUNKS * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;
 }
@@ -1118,6 +1183,76 @@ int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double 
                            static_cast<int>(g), 3 * KMAX, sums + 3 * k0);
     }
     return check_launch("svmc_payoff_sums");
+}
+
+int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
+                           const double *forwards_host, const double *ttms_host, const double *spot_sums,
+                           int n_expiries, const double *strikes_host, const int8_t *types_host,
+                           const double *shifts_host, const size_t *strike_offsets_host, int variable_type,
+                           double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    const char *fn = "svmc_payoff_sums_chain";
+    if (variable_type != SVMC_LOG_RETURN && variable_type != SVMC_Q_VAR)
+        return fail(SVMC_ERR_UNSUPPORTED_VARIABLE, "svmc_payoff_sums_chain: variable_type must be LOG_RETURN or Q_VAR");
+    SVMC_REQUIRE(x_snapshots_host && forwards_host && ttms_host && spot_sums && strike_offsets_host && sums && workspace,
+                 "svmc_payoff_sums_chain: null pointer");
+    SVMC_REQUIRE(n_expiries >= 1, "svmc_payoff_sums_chain: n_expiries < 1");
+    SVMC_REQUIRE(variable_type != SVMC_Q_VAR || qvar_snapshots_host != nullptr, "svmc_payoff_sums_chain: Q_VAR needs qvar");
+    const size_t total = strike_offsets_host[n_expiries];
+    SVMC_REQUIRE(total == 0 || (strikes_host && types_host), "svmc_payoff_sums_chain: null strikes/types");
+    for (size_t k = 0; k < total; ++k)
+        if (types_host[k] < SVMC_CALL || types_host[k] > SVMC_INV_PUT)
+            return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
+    const unsigned g = reduce_grid(n_path);
+    if (workspace_bytes < static_cast<size_t>(g) * 3 * KC * CHAIN_CHUNKS * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, "svmc_payoff_sums_chain: workspace too small (svmc_payoff_workspace_bytes)");
+    if (n_path == 0 || total == 0) return SVMC_OK;
+    double *partials = static_cast<double *>(workspace);
+    PayoffChunkPack pack;
+    int n_chunks = 0, cols = 0;                 // chunks and strike columns gathered for the pending launch
+    size_t first_strike = 0;                    // global index of the pending launch's first strike
+    bool has_inv = false;
+    auto flush = [&]() -> int {
+        if (n_chunks == 0) return SVMC_OK;
+        const dim3 grid(g, static_cast<unsigned>(n_chunks));
+        if (has_inv)
+            hipLaunchKernelGGL(payoff_chain_kernel<true>, grid, dim3(BLOCK), 0, as_stream(stream), pack, n_path,
+                               variable_type, partials, 3 * cols);
+        else
+            hipLaunchKernelGGL(payoff_chain_kernel<false>, grid, dim3(BLOCK), 0, as_stream(stream), pack, n_path,
+                               variable_type, partials, 3 * cols);
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
+                           static_cast<int>(g), 3 * cols, sums + 3 * first_strike);
+        first_strike += static_cast<size_t>(cols);
+        n_chunks = cols = 0;
+        has_inv = false;
+        return check_launch(fn);
+    };
+    for (int i = 0; i < n_expiries; ++i) {
+        SVMC_REQUIRE(x_snapshots_host[i] != nullptr, "svmc_payoff_sums_chain: null snapshot");
+        for (size_t k0 = strike_offsets_host[i]; k0 < strike_offsets_host[i + 1]; k0 += KC) {
+            PayoffChunk &d = pack.c[n_chunks];
+            d.x = x_snapshots_host[i];
+            d.qvar = (variable_type == SVMC_Q_VAR) ? qvar_snapshots_host[i] : nullptr;
+            d.spot_sums = spot_sums + 2 * i;
+            d.forward = forwards_host[i];
+            d.ttm = ttms_host[i];
+            const size_t left = strike_offsets_host[i + 1] - k0;
+            d.k = static_cast<int>(left < static_cast<size_t>(KC) ? left : KC);
+            d.col = cols;
+            for (int k = 0; k < KC; ++k) {
+                const bool on = k < d.k;
+                d.strikes[k] = on ? strikes_host[k0 + k] : 0.0;
+                d.shifts[k] = (on && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
+                d.types[k] = on ? types_host[k0 + k] : 0;
+                has_inv = has_inv || (on && (d.types[k] == SVMC_INV_CALL || d.types[k] == SVMC_INV_PUT));
+            }
+            cols += d.k;
+            if (++n_chunks == CHAIN_CHUNKS)
+                if (int rc = flush()) return rc;
+        }
+    }
+    return flush();
 }
 
 int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes, double discfactor,

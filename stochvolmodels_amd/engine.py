@@ -343,6 +343,28 @@ class HipEngine:
             shifts.ctypes.data_as(C.POINTER(C.c_double)), k, int(variable_type), out_ptr, self.ws.ptr,
             self.ws_bytes, self.stream))
 
+    def payoff_sums_chain(self, snap_rows: Sequence[int], qvar_rows: Optional[Sequence[int]], forwards, ttms,
+                          spot_sums_ptr: int, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
+                          shifts: Sequence[np.ndarray], variable_type: int, out_ptr: int) -> None:
+        """per-strike payoff sums of ALL expiries in one pair of launches (svmc_payoff_sums_chain); expiry i reads
+        snapshot row snap_rows[i] (and qvar_rows[i]) and the recentring sums at spot_sums_ptr + 16 i"""
+        m = len(strikes)
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
+        if int(offs[-1]) == 0:
+            return
+        dp = C.POINTER(C.c_double)
+        k_all = np.ascontiguousarray(np.concatenate(strikes), dtype=np.float64)
+        c_all = np.ascontiguousarray(np.concatenate(codes), dtype=np.int8)
+        s_all = np.ascontiguousarray(np.concatenate(shifts), dtype=np.float64)
+        fw = np.ascontiguousarray(forwards, dtype=np.float64)
+        tt = np.ascontiguousarray(ttms, dtype=np.float64)
+        xs = (C.c_void_p * m)(*[self.snapshot_ptr(r) for r in snap_rows])
+        qs = None if qvar_rows is None else (C.c_void_p * m)(*[self.snapshot_ptr(r) for r in qvar_rows])
+        _lib.check(self.lib.svmc_payoff_sums_chain(
+            xs, qs, self.n_path, fw.ctypes.data_as(dp), tt.ctypes.data_as(dp), spot_sums_ptr, m, k_all.ctypes.data_as(dp),
+            c_all.ctypes.data_as(C.POINTER(C.c_int8)), s_all.ctypes.data_as(dp), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
+            int(variable_type), out_ptr, self.ws.ptr, self.ws_bytes, self.stream))
+
     def close(self) -> None:
         for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values()):
             if b is not None:

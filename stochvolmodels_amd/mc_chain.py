@@ -9,7 +9,7 @@ per slice.  Re-ordered for the GPU / multi-GPU case:
   phase 1  for every expiry ONE kernel: advance the resident state, snapshot the terminal x (and qvar for Q_VAR
            chains) in HBM and reduce the block partials of [sum F*exp(x), count]  -- no host round trip
   phase 2  per-expiry [sum F*exp(x), count]              -> ONE all-reduce over ranks (2*M doubles)
-  phase 3  per-strike [sum d, sum d^2, count]            -> ONE all-reduce over ranks (3*sum K doubles)
+  phase 3  per-strike [sum d, sum d^2, count] of ALL expiries in one launch pair -> ONE all-reduce (3*sum K doubles)
   phase 4  D2H of the sums, host finalisation (utils/mc_payoffs.py:85-88)
 
 The driver is engine-agnostic: `engine` is a HipEngine in the product (GPU only, no fallback); tests may
@@ -59,10 +59,9 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     # phase 3: per-strike payoff sums
     offs = np.concatenate([[0], np.cumsum([3 * len(k) for k in strikes])]).astype(int)
     sums_ptr, sums_handle = comm.alloc(engine, int(offs[-1]) + 1, "payoff")
-    for i in range(m):
-        engine.payoff_sums(engine.snapshot_ptr(i), engine.snapshot_ptr(m + i) if need_q else None,
-                           float(forwards[i]), float(ttms[i]), spot_ptr + 16 * i, strikes[i], codes[i], shifts[i],
-                           vt, sums_ptr + 8 * int(offs[i]))
+    engine.payoff_sums_chain(range(m), range(m, 2 * m) if need_q else None, forwards, ttms, spot_ptr,
+                             [k.ravel() for k in strikes], [c.ravel() for c in codes], [s.ravel() for s in shifts], vt,
+                             sums_ptr)
     comm.all_reduce_sum(engine, sums_handle)
 
     # phase 4

@@ -127,6 +127,15 @@ class FakeEngine:
         out = _view(out_ptr, 2)
         out[0], out[1] = spots[ok].sum(), ok.sum()
 
+    def payoff_sums_chain(self, snap_rows, qvar_rows, forwards, ttms, spot_sums_ptr, strikes, codes, shifts, variable_type,
+                          out_ptr):
+        off = 0
+        for i, (k, c, s) in enumerate(zip(strikes, codes, shifts)):
+            self.payoff_sums(self.snapshot_ptr(list(snap_rows)[i]),
+                             None if qvar_rows is None else self.snapshot_ptr(list(qvar_rows)[i]), float(forwards[i]),
+                             float(ttms[i]), spot_sums_ptr + 16 * i, k, c, s, variable_type, out_ptr + 8 * off)
+            off += 3 * len(k)
+
     def payoff_sums(self, x_ptr, qvar_ptr, forward, ttm, spot_sums_ptr, strikes, codes, shifts, variable_type, out_ptr):
         x = _view(x_ptr, self.n_path)
         ss = _view(spot_sums_ptr, 2)

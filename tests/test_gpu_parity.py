@@ -1025,3 +1025,44 @@ def test_two_engines_on_their_own_streams(sv):
         e.close()
     for s in streams:
         assert L.svmc_stream_destroy(s) == 0
+
+
+@pytest.mark.parametrize("vt", [1, 2])
+def test_payoff_sums_chain_equals_per_expiry(sv, vt):
+    """svmc_payoff_sums_chain (all expiries in one launch pair, 20 chunks of 8 strikes per launch) gives the bits of
+    per-expiry svmc_payoff_sums: 9 expiries with ragged strike counts (0, 1, 8, 9, 21, 33, ...: 26 chunks -> two
+    launches), all four payoff codes"""
+    from stochvolmodels_amd.engine import option_type_codes, payoff_shifts
+    rng = np.random.default_rng(5)
+    n, m = 20001, 9
+    counts = [21, 0, 1, 8, 9, 33, 21, 16, 40]
+    eng = _engine(n)
+    eng.reserve_snapshots(2 * m)
+    p = sv.LOGSV_BTC_PARAMS
+    eng.fill_state(0.0, p.sigma0, 0.0)
+    forwards = 1.0 + 0.01 * np.arange(m)
+    ttms = 0.05 * (1 + np.arange(m))
+    spot_ptr, _ = eng.alloc_sums(2 * m, "spot")
+    for i in range(m):
+        eng.logsv_slice_rng(7, 0.05 / 7, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, 1.0, True, 3, 0, 7 * i,
+                            float(forwards[i]), i, m + i, spot_ptr + 16 * i)
+    strikes = [np.sort(rng.uniform(0.02, 0.3, c)) if vt == 2 else f * np.sort(rng.uniform(0.6, 1.5, c))
+               for c, f in zip(counts, forwards)]
+    types = [rng.choice(["C", "P"] if vt == 2 else ["C", "P", "IC", "IP"], c) for c in counts]
+    codes = [option_type_codes(t) if len(t) else np.zeros(0, dtype=np.int8) for t in types]
+    shifts = [payoff_shifts(k, c, float(f), vt) for k, c, f in zip(strikes, codes, forwards)]
+    total = sum(counts)
+    a_ptr, _ = eng.alloc_sums(3 * total + 1, "a")
+    b_ptr, _ = eng.alloc_sums(3 * total + 1, "b")
+    off = 0
+    for i in range(m):
+        if counts[i]:
+            eng.payoff_sums(eng.snapshot_ptr(i), eng.snapshot_ptr(m + i) if vt == 2 else None, float(forwards[i]),
+                            float(ttms[i]), spot_ptr + 16 * i, strikes[i], codes[i], shifts[i], vt, a_ptr + 8 * off)
+        off += 3 * counts[i]
+    eng.payoff_sums_chain(range(m), range(m, 2 * m) if vt == 2 else None, forwards, ttms, spot_ptr, strikes, codes, shifts,
+                          vt, b_ptr)
+    a, b = eng.download(a_ptr, 3 * total), eng.download(b_ptr, 3 * total)
+    assert np.array_equal(a, b)
+    assert np.all(a[2::3] == n)                       # every path counted for every strike
+    eng.close()
