@@ -123,6 +123,17 @@ SVMC_API int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t
                                   uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
                                   double *qvar_snapshot, double *spot_sums, void *workspace,
                                   size_t workspace_bytes, svmc_stream_t stream);
+/* ALL expiries of a chain in one stepping launch (per 16 slices): slice i advances nb_steps_host[i] steps of
+ * dts_host[i] with vol backbone etas_host[i] (NULL = 1), then writes x_snapshots[i][n_path] (and qvar_snapshots[i]
+ * when non-NULL) and spot_sums[2i..2i+1] for forwards_host[i] -- the expiry loop of logsv_mc_chain_pricer
+ * (pricers/logsv_pricer.py:840-865) without a launch boundary, and its tail, per expiry.  Same bits as calling
+ * svmc_logsv_slice_rng slice by slice with step_offset advanced by the steps done. */
+SVMC_API int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices,
+                                  const int *nb_steps_host, const double *dts_host, const double *etas_host,
+                                  const double *forwards_host, double theta, double kappa1, double kappa2, double beta,
+                                  double volvol, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                                  uint64_t path_offset, uint32_t step_offset, double *x_snapshots, double *qvar_snapshots,
+                                  double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_logsv_terminal_w(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
                           double theta, double kappa1, double kappa2, double beta, double volvol,
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1,

@@ -208,21 +208,26 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
     const size_t n = s->n_path;
     if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :832-834
     double t0 = 0.0;
-    uint32_t step0 = 0;
+    std::vector<int> nbs(c.m);
+    std::vector<double> dts(c.m);
     for (int i = 0; i < c.m; ++i) {                                                                       // :840-865
-        int nb;
-        double dt;
-        time_grid(c.ttms[i] - t0, nb_steps_per_year, nb, dt);
-        const double eta = vol_backbone_etas_host ? vol_backbone_etas_host[i] : 1.0;
-        double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
-        if (int rc = svmc_logsv_slice_rng(s->x, s->vol, s->qvar, n, nb, dt, theta, kappa1, kappa2, beta, volvol, eta,
-                                          is_spot_measure, seed, call_id, 0, step0, c.forwards[i],
-                                          s->snap + static_cast<size_t>(i) * n, qsnap, s->spot + 2 * i, s->ws, s->ws_bytes,
-                                          s->stream))
-            return rc;
-        step0 += static_cast<uint32_t>(nb);
+        time_grid(c.ttms[i] - t0, nb_steps_per_year, nbs[i], dts[i]);
         t0 = c.ttms[i];
     }
+    if (c.m == 1) {       // a single expiry: the plain slice kernel (same bits, and the one bench.py profiles)
+        if (int rc = svmc_logsv_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
+                                          vol_backbone_etas_host ? vol_backbone_etas_host[0] : 1.0, is_spot_measure, seed,
+                                          call_id, 0, 0, c.forwards[0], s->snap,
+                                          (variable_type == SVMC_Q_VAR) ? s->snap + n : nullptr, s->spot, s->ws, s->ws_bytes,
+                                          s->stream))
+            return rc;
+        return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+    }
+    if (int rc = svmc_logsv_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
+                                      c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id, 0, 0,
+                                      s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
+                                      s->spot, s->ws, s->ws_bytes, s->stream))
+        return rc;
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
 }
 

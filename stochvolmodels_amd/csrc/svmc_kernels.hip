@@ -158,8 +158,9 @@ __device__ __forceinline__ void progress_priority(int stage)
 struct SliceOut {
     double *x_snap;     // nullable
     double *q_snap;     // nullable
-    double *partials;   // nullable: [gridDim.x][2]
+    double *partials;   // nullable: [gridDim.x][ld], this slice's pair at the row start
     double forward;
+    int ld = 2;         // doubles per block row of `partials` (2 * slices for the whole-chain kernel)
 };
 
 __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, bool active, double xv, double q)
@@ -173,7 +174,7 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
         const double sp = so.forward * exp(xv);            // full-range exp: x = +-inf must give inf / 0   :61
         const bool ok = active && (sp == sp);                                                   // nanmean :62
         double v[2] = {ok ? sp : 0.0, ok ? 1.0 : 0.0};
-        block_sum_store<2>(v, lds, so.partials + 2 * static_cast<size_t>(blockIdx.x), 2);
+        block_sum_store<2>(v, lds, so.partials + static_cast<size_t>(so.ld) * blockIdx.x, 2);
     }
 }
 
@@ -210,6 +211,66 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         qvar[p] = q;
     }
     slice_epilogue(so, p, active, xv, q);
+}
+
+// All expiries of a chain in ONE stepping launch: the slice loop runs inside the kernel, each slice with its own
+// constants (dt, vol backbone) and its own epilogue (snapshot row i, spot partials column pair i).  Eight 128-step
+// launches each pay their own ramp-up and ramp-down (C4: 8 x 1.03 ms against 7.44 ms for one 1024-step launch);
+// here the chain pays one.  L and sigma^2 are re-derived from sigma at every slice start exactly as a fresh launch
+// would, so the results are the bits of the slice-by-slice path.
+constexpr int MAX_CHAIN_SLICES = 16;
+struct ChainSlices {
+    LogsvFast c[MAX_CHAIN_SLICES];
+    double forward[MAX_CHAIN_SLICES];
+    int nb_steps[MAX_CHAIN_SLICES];
+    int m, total_steps;
+};
+
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72))) void logsv_chain_rng_kernel(
+    double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
+    uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
+    double *__restrict__ partials)
+{
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool active = p < n;
+    double xv = 0.0, s = 1.0, q = 0.0;
+    if (active) {
+        xv = x[p];
+        s = sigma[p];
+        q = qvar[p];
+    }
+    const uint64_t gp = path_offset + p;
+    const int quarter = (cs.total_steps + 3) >> 2;
+    int stage = 0, next_stage_t = 0, tg = 0;
+    for (int i = 0; i < cs.m; ++i) {
+        const int nb = cs.nb_steps[i];
+        if (active) {
+            const LogsvFast c = cs.c[i];
+            double L = log(s);                                                                  // :1039
+            double s2 = s * s;
+            for (int t = 0; t < nb; ++t) {
+                if (tg + t == next_stage_t) {              // wave-uniform
+                    progress_priority(stage++);
+                    next_stage_t += quarter;
+                }
+                double z0, z1;
+                draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
+                logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
+            }
+        }
+        tg += nb;
+        const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
+                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+        slice_epilogue(so, p, active, xv, q);
+        __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
+    }
+    if (active) {
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
+    }
 }
 
 // Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
@@ -850,6 +911,47 @@ int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
 }
 
+int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                         const double *dts_host, const double *etas_host, const double *forwards_host, double theta,
+                         double kappa1, double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed,
+                         uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
+                         double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
+                         svmc_stream_t stream)
+{
+    const char *fn = "svmc_logsv_chain_rng";
+    SVMC_REQUIRE(x && sigma && qvar && x_snapshots && spot_sums && workspace, "svmc_logsv_chain_rng: null pointer");
+    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, "svmc_logsv_chain_rng: null grids / no slices");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_chain_rng: call_id must fit 24 bits");
+    SVMC_REQUIRE(n_path > 0, "svmc_logsv_chain_rng: n_path must be positive");
+    for (int i = 0; i < n_slices; ++i)
+        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, "svmc_logsv_chain_rng: nb_steps and dt must be positive");
+    const unsigned g = rng_grid(n_path);
+    for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
+        ChainSlices cs;
+        cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
+        if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
+            return fail(SVMC_ERR_WORKSPACE, "svmc_logsv_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
+        cs.total_steps = 0;
+        for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+            const int j = (i < cs.m) ? i0 + i : i0;        // unused entries repeat a valid one
+            cs.c[i] = make_logsv_fast(make_logsv_consts(dts_host[j], theta, kappa1, kappa2, beta, volvol,
+                                                        etas_host ? etas_host[j] : 1.0, is_spot_measure));
+            cs.forward[i] = forwards_host[j];
+            cs.nb_steps[i] = (i < cs.m) ? nb_steps_host[j] : 0;
+            cs.total_steps += cs.nb_steps[i];
+        }
+        hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar, n_path,
+                           cs, seed, make_c3(call_id), path_offset, step_offset, x_snapshots + static_cast<size_t>(i0) * n_path,
+                           qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr,
+                           static_cast<double *>(workspace));
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
+                           static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
+        if (int rc = check_launch(fn)) return rc;
+        step_offset += static_cast<uint32_t>(cs.total_steps);
+    }
+    return SVMC_OK;
+}
+
 static int logsv_w_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
                           double theta, double kappa1, double kappa2, double beta, double volvol,
                           double vol_backbone_eta, int is_spot_measure, const double *W0, const double *W1, size_t ldw,
@@ -1125,7 +1227,7 @@ int svmc_payoff_workspace_bytes(size_t *bytes)
 int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
-    const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * sizeof(double);
+    const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
     const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * CHAIN_CHUNKS * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;

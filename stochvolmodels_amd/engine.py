@@ -236,6 +236,21 @@ class HipEngine:
             None if qvar_row is None else self.snapshot_ptr(qvar_row), spot_ptr, self.ws.ptr, self.ws_bytes,
             self.stream)))
 
+    def logsv_chain_rng(self, nb_steps: Sequence[int], dts: Sequence[float], etas: Sequence[float],
+                        forwards: Sequence[float], theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                        step_offset, need_qvar: bool, spot_ptr: int) -> None:
+        """every expiry of a chain in one stepping launch (svmc_logsv_chain_rng): snapshot rows 0..m-1 get the
+        terminal x of each expiry, rows m..2m-1 the quadratic variance (need_qvar), spot_ptr the 2m spot sums"""
+        m = len(nb_steps)
+        dp = C.POINTER(C.c_double)
+        nbs = (C.c_int * m)(*[int(v) for v in nb_steps])
+        d, e, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (dts, etas, forwards))
+        self._timed("logsv_chain_rng_kernel", lambda: _lib.check(self.lib.svmc_logsv_chain_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, m, nbs, d.ctypes.data_as(dp), e.ctypes.data_as(dp),
+            f.ctypes.data_as(dp), float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
+            int(bool(is_spot_measure)), int(seed), int(call_id), self.path_offset, int(step_offset), self.snapshot_ptr(0),
+            self.snapshot_ptr(m) if need_qvar else None, spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
+
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
                          snap_row, qvar_row, spot_ptr) -> None:
         self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_slice_rng(

@@ -35,9 +35,12 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
                           discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
                           optiontypes_ttms: Sequence[np.ndarray], variable_type,
                           advance_slice: Callable[[int, float, int, object, int], None],
-                          finalize: Callable = payoff_finalize) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+                          finalize: Callable = payoff_finalize, advance_chain: Callable[[bool, int], None] = None
+                          ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """advance_slice(i, forward_i, snap_row, qvar_row | None, spot_ptr) must leave the state advanced over slice i,
-    the terminal x (qvar) in snapshot row snap_row (qvar_row) and [sum F*exp(x), count] at spot_ptr."""
+    the terminal x (qvar) in snapshot row snap_row (qvar_row) and [sum F*exp(x), count] at spot_ptr.  A generator that
+    can step the whole chain in one launch passes advance_chain(need_qvar, spot_ptr) instead: it must fill snapshot
+    rows 0..m-1 (x), m..2m-1 (qvar, when need_qvar) and the 2m spot sums."""
     vt = variable_type_code(variable_type)
     m = len(ttms)
     if not (len(forwards) == len(discfactors) == len(strikes_ttms) == len(optiontypes_ttms) == m):
@@ -50,8 +53,11 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     # phase 1: stepping + snapshot + local spot sums, state resident
     engine.reserve_snapshots(m * (2 if need_q else 1))
     spot_ptr, spot_handle = comm.alloc(engine, 2 * m, "spot")
-    for i in range(m):
-        advance_slice(i, float(forwards[i]), i, (m + i) if need_q else None, spot_ptr + 16 * i)
+    if advance_chain is not None:
+        advance_chain(need_q, spot_ptr)
+    else:
+        for i in range(m):
+            advance_slice(i, float(forwards[i]), i, (m + i) if need_q else None, spot_ptr + 16 * i)
 
     # phase 2: forward recentring needs the GLOBAL mean of the terminal spots
     comm.all_reduce_sum(engine, spot_handle)

@@ -98,6 +98,9 @@ def _calibration_constraints(parse, constraints_type: ConstraintsType):
     return table[constraints_type]
 
 
+# logsv_mc_chain_pricer steps all expiries of a multi-expiry chain in one launch (svmc_logsv_chain_rng) when True,
+# slice by slice otherwise (same bits)
+WHOLE_CHAIN_STEPPING = True
 # single-GPU chains on resident randoms go through svmc_logsv_chain_price_fixed (one C++ call per chain) when True
 FUSED_FIXED_RANDOMS_DRIVER = True
 
@@ -381,8 +384,13 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
         eng.logsv_slice_rng(nb, dt, theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]), is_spot_measure,
                             rng_seed, call_id, int(step0[i]), forward, snap_row, qvar_row, spot_ptr)
 
+    def advance_chain(need_qvar: bool, spot_ptr: int) -> None:
+        eng.logsv_chain_rng([g[0] for g in grids], [g[1] for g in grids], vol_backbone_etas, forwards, theta, kappa1,
+                            kappa2, beta, volvol, is_spot_measure, rng_seed, call_id, 0, need_qvar, spot_ptr)
+
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
-                                 variable_type, advance)
+                                 variable_type, advance,
+                                 advance_chain=advance_chain if (WHOLE_CHAIN_STEPPING and len(grids) > 1) else None)
 
 
 def get_randoms_for_chain_valuation(ttms: np.ndarray, nb_path: int = 100000, nb_steps_per_year: int = 360,

@@ -81,6 +81,15 @@ class FakeEngine:
                        step_offset)
         self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
 
+    def logsv_chain_rng(self, nb_steps, dts, etas, forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed,
+                        call_id, step_offset, need_qvar, spot_ptr):
+        m, step = len(nb_steps), step_offset
+        for i in range(m):
+            self.logsv_slice_rng(nb_steps[i], dts[i], theta, kappa1, kappa2, beta, volvol, float(etas[i]), is_spot_measure,
+                                 seed, call_id, step, float(forwards[i]), i, (m + i) if need_qvar else None,
+                                 spot_ptr + 16 * i)
+            step += nb_steps[i]
+
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
                          snap_row, qvar_row, spot_ptr):
         self.heston_rng(nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset)

@@ -1066,3 +1066,34 @@ def test_payoff_sums_chain_equals_per_expiry(sv, vt):
     assert np.array_equal(a, b)
     assert np.all(a[2::3] == n)                       # every path counted for every strike
     eng.close()
+
+
+@pytest.mark.parametrize("m,vt,spot", [(8, 1, True), (19, 2, False), (1, 1, True)])
+def test_whole_chain_stepping_equals_slice_by_slice(sv, m, vt, spot):
+    """svmc_logsv_chain_rng (all expiries in one stepping launch, 16 slices per launch) against the slice-by-slice
+    launches: same prices, stderrs and terminal state, bit for bit -- ragged step counts, vol backbone, both
+    measures, quadratic-variance payoffs"""
+    from stochvolmodels_amd.engine import get_engine
+    from stochvolmodels_amd.pricers import logsv_pricer as lp
+    rng = np.random.default_rng(m)
+    ttms = np.cumsum(rng.uniform(0.01, 0.08, m))
+    fw = 1.0 + 0.02 * rng.standard_normal(m)
+    kk = [np.array([0.05, 0.2, 0.5]) if vt == 2 else f * np.array([0.8, 1.0, 1.2]) for f in fw]
+    ty = [np.array(["C", "P", "C"]) if vt == 2 else np.array(["P", "IC", "C"]) for _ in range(m)]
+    p = sv.LOGSV_BTC_PARAMS
+    kw = dict(ttms=ttms, forwards=fw, discfactors=np.full(m, 0.99), strikes_ttms=kk, optiontypes_ttms=ty, v0=p.sigma0,
+              theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+              vol_backbone_etas=1.0 + 0.1 * rng.uniform(-1, 1, m), is_spot_measure=spot, nb_path=30001,
+              nb_steps_per_year=333, variable_type=sv.VariableType(vt), seed=99)
+    out = {}
+    for flag in (True, False):
+        lp.WHOLE_CHAIN_STEPPING = flag
+        try:
+            pr, sd = sv.logsv_mc_chain_pricer(**kw)
+        finally:
+            lp.WHOLE_CHAIN_STEPPING = True
+        out[flag] = (np.concatenate(pr), np.concatenate(sd), get_engine(30001).get_state())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    for a, b in zip(out[True][2], out[False][2]):
+        np.testing.assert_array_equal(a, b)
