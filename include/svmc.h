@@ -202,6 +202,14 @@ SVMC_API int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t 
                                    uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
                                    double forward, double *x_snapshot, double *qvar_snapshot, double *spot_sums,
                                    void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+/* all expiries of a Heston chain in one stepping launch (per 16 slices), as svmc_logsv_chain_rng: the expiry loop of
+ * heston_mc_chain_pricer (pricers/heston_pricer.py:308-329); same bits as svmc_heston_slice_rng slice by slice */
+SVMC_API int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices,
+                                   const int *nb_steps_host, const double *dts_host, const double *forwards_host,
+                                   double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
+                                   uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
+                                   double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
+                                   svmc_stream_t stream);
 SVMC_API int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
                            double theta, double kappa, double rho, double volvol, const double *W0,
                            const double *W1, size_t ldw, svmc_stream_t stream);

@@ -60,6 +60,8 @@ def _declare(L: C.CDLL) -> None:
         "svmc_black_implied_vols": ([pf64, pf64, C.POINTER(C.c_int8), sz, f64, f64, f64, f64, f64, pf64], i32),
         "svmc_logsv_chain_rng": ([vp, vp, vp, sz, i32, C.POINTER(i32), pf64, pf64, pf64, f64, f64, f64, f64, f64, i32, u64, u32,
                                   u64, u32, vp, vp, vp, vp, sz, vp], i32),
+        "svmc_heston_chain_rng": ([vp, vp, vp, sz, i32, C.POINTER(i32), pf64, pf64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
+                                   vp, vp, vp, vp, sz, vp], i32),
         "svmc_logsv_slice_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, vp, vp, sz, f64, vp, vp, vp, vp,
                                 sz, vp], i32),
         "svmc_rough_logsv_slice": ([vp, vp, vp, sz, i32, f64, i32, pf64, pf64, pf64, f64, f64, f64, f64, f64, vp, vp, sz,

@@ -353,18 +353,22 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
     const size_t n = s->n_path;
     if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :303-305
     double t0 = 0.0;
-    uint32_t step0 = 0;
+    std::vector<int> nbs(c.m);
+    std::vector<double> dts(c.m);
     for (int i = 0; i < c.m; ++i) {                                                                       // :308-329
-        int nb;
-        double dt;
-        time_grid(c.ttms[i] - t0, nb_steps_per_year, nb, dt);
-        double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
-        if (int rc = svmc_heston_slice_rng(s->x, s->vol, s->qvar, n, nb, dt, theta, kappa, rho, volvol, scheme, seed,
-                                           call_id, 0, step0, c.forwards[i], s->snap + static_cast<size_t>(i) * n, qsnap,
-                                           s->spot + 2 * i, s->ws, s->ws_bytes, s->stream))
-            return rc;
-        step0 += static_cast<uint32_t>(nb);
+        time_grid(c.ttms[i] - t0, nb_steps_per_year, nbs[i], dts[i]);
         t0 = c.ttms[i];
+    }
+    double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
+    if (c.m == 1) {
+        if (int rc = svmc_heston_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
+                                           call_id, 0, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
+                                           s->stream))
+            return rc;
+    } else if (int rc = svmc_heston_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
+                                              rho, volvol, scheme, seed, call_id, 0, 0, s->snap, qsnap, s->spot, s->ws,
+                                              s->ws_bytes, s->stream)) {
+        return rc;
     }
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
 }

@@ -592,6 +592,65 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
     slice_epilogue(so, p, active, xv, q);
 }
 
+// whole-chain variant, as logsv_chain_rng_kernel: the slice loop inside the kernel, one launch tail per chain
+struct HestonChainSlices {
+    HestonConsts c[MAX_CHAIN_SLICES];
+    QeConsts qc[MAX_CHAIN_SLICES];
+    double forward[MAX_CHAIN_SLICES];
+    int nb_steps[MAX_CHAIN_SLICES];
+    int m;
+};
+
+template <int SCHEME>
+__global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                                 double *__restrict__ qvar, size_t n,
+                                                                 HestonChainSlices cs, uint64_t seed, uint32_t c3,
+                                                                 uint64_t path_offset, uint32_t step_offset,
+                                                                 double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                 double *__restrict__ partials)
+{
+    __shared__ LogTabEntry s_tab[256];
+    const LogTabEntry *tab = stage_log_table(s_tab);
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool active = p < n;
+    double xv = 0.0, v = 1.0, q = 0.0;
+    if (active) {
+        xv = x[p];
+        v = var[p];
+        q = qvar[p];
+    }
+    const uint64_t gp = path_offset + p;
+    uint32_t step = step_offset;
+    for (int i = 0; i < cs.m; ++i) {
+        const int nb = cs.nb_steps[i];
+        if (active) {
+            const HestonConsts c = cs.c[i];
+            const QeConsts qc = cs.qc[i];
+            for (int t = 0; t < nb; ++t) {
+                double w0, w1;
+                if (SCHEME == SVMC_HESTON_QE) {
+                    double u;
+                    draw_qe(seed, c3, gp, step + static_cast<uint32_t>(t), tab, w0, w1, u);
+                    heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
+                } else {
+                    draw_normals(seed, c3, gp, step + static_cast<uint32_t>(t), tab, w0, w1);
+                    heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+                }
+            }
+        }
+        step += static_cast<uint32_t>(nb);
+        const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
+                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+        slice_epilogue(so, p, active, xv, q);
+        __syncthreads();
+    }
+    if (active) {
+        x[p] = xv;
+        var[p] = v;
+        qvar[p] = q;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x, double *__restrict__ var,
                                                          double *__restrict__ qvar, size_t n, int nb_steps,
                                                          HestonConsts c, const double *__restrict__ W0,
@@ -1103,6 +1162,53 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
                                    call_id, path_offset, step_offset, so, stream))
         return rc;
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+}
+
+int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                          const double *dts_host, const double *forwards_host, double theta, double kappa, double rho,
+                          double volvol, int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                          uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                          void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    const char *fn = "svmc_heston_chain_rng";
+    SVMC_REQUIRE(x && var && qvar && x_snapshots && spot_sums && workspace, "svmc_heston_chain_rng: null pointer");
+    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, "svmc_heston_chain_rng: null grids / no slices");
+    SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, "svmc_heston_chain_rng: unknown scheme");
+    SVMC_REQUIRE(call_id < (1u << 24), "svmc_heston_chain_rng: call_id must fit 24 bits");
+    SVMC_REQUIRE(n_path > 0, "svmc_heston_chain_rng: n_path must be positive");
+    for (int i = 0; i < n_slices; ++i)
+        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, "svmc_heston_chain_rng: nb_steps and dt must be positive");
+    const unsigned g = rng_grid(n_path);
+    for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
+        HestonChainSlices cs;
+        cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
+        if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
+            return fail(SVMC_ERR_WORKSPACE, "svmc_heston_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
+        int steps = 0;
+        for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+            const int j = (i < cs.m) ? i0 + i : i0;
+            cs.c[i] = make_heston_consts(dts_host[j], theta, kappa, rho, volvol);
+            cs.qc[i] = make_qe_consts(dts_host[j], theta, kappa, rho, volvol);
+            cs.forward[i] = forwards_host[j];
+            cs.nb_steps[i] = (i < cs.m) ? nb_steps_host[j] : 0;
+            steps += cs.nb_steps[i];
+        }
+        double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
+        double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
+        if (scheme == SVMC_HESTON_QE)
+            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_QE>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x,
+                               var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
+                               static_cast<double *>(workspace));
+        else
+            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(g), dim3(rng_block()), 0,
+                               as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
+                               xs, qs, static_cast<double *>(workspace));
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
+                           static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
+        if (int rc = check_launch(fn)) return rc;
+        step_offset += static_cast<uint32_t>(steps);
+    }
+    return SVMC_OK;
 }
 
 static int rough_logsv_launch(const char *name, double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps,

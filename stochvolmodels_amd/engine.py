@@ -251,6 +251,19 @@ class HipEngine:
             int(bool(is_spot_measure)), int(seed), int(call_id), self.path_offset, int(step_offset), self.snapshot_ptr(0),
             self.snapshot_ptr(m) if need_qvar else None, spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
 
+    def heston_chain_rng(self, nb_steps: Sequence[int], dts: Sequence[float], forwards: Sequence[float], theta, kappa,
+                         rho, volvol, scheme, seed, call_id, step_offset, need_qvar: bool, spot_ptr: int) -> None:
+        """every expiry of a Heston chain in one stepping launch (svmc_heston_chain_rng); layout as logsv_chain_rng"""
+        m = len(nb_steps)
+        dp = C.POINTER(C.c_double)
+        nbs = (C.c_int * m)(*[int(v) for v in nb_steps])
+        d, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (dts, forwards))
+        self._timed("heston_chain_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_chain_rng(
+            self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, m, nbs, d.ctypes.data_as(dp), f.ctypes.data_as(dp),
+            float(theta), float(kappa), float(rho), float(volvol), int(scheme), int(seed), int(call_id), self.path_offset,
+            int(step_offset), self.snapshot_ptr(0), self.snapshot_ptr(m) if need_qvar else None, spot_ptr, self.ws.ptr,
+            self.ws_bytes, self.stream)))
+
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
                          snap_row, qvar_row, spot_ptr) -> None:
         self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_slice_rng(

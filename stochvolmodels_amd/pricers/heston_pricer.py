@@ -49,6 +49,10 @@ def _scheme_code(scheme) -> int:
     raise ValueError(f"unknown Heston scheme {scheme!r} (use 'euler' or 'qe')")
 
 
+# heston_mc_chain_pricer steps all expiries of a multi-expiry chain in one launch (svmc_heston_chain_rng) when True
+WHOLE_CHAIN_STEPPING = True
+
+
 class HestonPricer(ModelPricer):
 
     def price_chain(self, option_chain: OptionChain, params: HestonParams, **kwargs) -> List[np.ndarray]:
@@ -201,5 +205,10 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
         eng.heston_slice_rng(nb, dt, theta, kappa, rho, volvol, code, rng_seed, call_id, int(step0[i]), forward,
                              snap_row, qvar_row, spot_ptr)
 
+    def advance_chain(need_qvar: bool, spot_ptr: int) -> None:
+        eng.heston_chain_rng([g[0] for g in grids], [g[1] for g in grids], forwards, theta, kappa, rho, volvol, code,
+                             rng_seed, call_id, 0, need_qvar, spot_ptr)
+
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
-                                 variable_type, advance)
+                                 variable_type, advance,
+                                 advance_chain=advance_chain if (WHOLE_CHAIN_STEPPING and len(grids) > 1) else None)

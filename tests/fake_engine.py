@@ -90,6 +90,14 @@ class FakeEngine:
                                  spot_ptr + 16 * i)
             step += nb_steps[i]
 
+    def heston_chain_rng(self, nb_steps, dts, forwards, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset,
+                         need_qvar, spot_ptr):
+        m, step = len(nb_steps), step_offset
+        for i in range(m):
+            self.heston_slice_rng(nb_steps[i], dts[i], theta, kappa, rho, volvol, scheme, seed, call_id, step,
+                                  float(forwards[i]), i, (m + i) if need_qvar else None, spot_ptr + 16 * i)
+            step += nb_steps[i]
+
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
                          snap_row, qvar_row, spot_ptr):
         self.heston_rng(nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset)

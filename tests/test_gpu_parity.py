@@ -1097,3 +1097,31 @@ def test_whole_chain_stepping_equals_slice_by_slice(sv, m, vt, spot):
     np.testing.assert_array_equal(out[True][1], out[False][1])
     for a, b in zip(out[True][2], out[False][2]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("scheme,vt", [("euler", 1), ("qe", 2), ("qe", 1)])
+def test_heston_whole_chain_stepping_equals_slice_by_slice(sv, scheme, vt):
+    """svmc_heston_chain_rng against slice-by-slice svmc_heston_slice_rng: identical bits (18 expiries -> two launches)"""
+    from stochvolmodels_amd.engine import get_engine
+    from stochvolmodels_amd.pricers import heston_pricer as hp
+    m = 18
+    rng = np.random.default_rng(3)
+    ttms = np.cumsum(rng.uniform(0.01, 0.06, m))
+    fw = 1.0 + 0.02 * rng.standard_normal(m)
+    kk = [np.array([0.01, 0.04, 0.09]) if vt == 2 else f * np.array([0.8, 1.0, 1.2]) for f in fw]
+    ty = [np.array(["C", "P", "C"]) if vt == 2 else np.array(["IP", "C", "IC"]) for _ in range(m)]
+    kw = dict(ttms=ttms, forwards=fw, discfactors=np.full(m, 0.98), strikes_ttms=kk, optiontypes_ttms=ty, v0=0.05, theta=0.04,
+              kappa=3.0, rho=-0.6, volvol=0.7, nb_path=20011, scheme=scheme, nb_steps_per_year=250,
+              variable_type=sv.VariableType(vt), seed=5)
+    out = {}
+    for flag in (True, False):
+        hp.WHOLE_CHAIN_STEPPING = flag
+        try:
+            pr, sd = sv.heston_mc_chain_pricer(**kw)
+        finally:
+            hp.WHOLE_CHAIN_STEPPING = True
+        out[flag] = (np.concatenate(pr), np.concatenate(sd), get_engine(20011).get_state())
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    for a, b in zip(out[True][2], out[False][2]):
+        np.testing.assert_array_equal(a, b)
