@@ -29,6 +29,8 @@ def main():
     chain0 = sv.OptionChain(ttms=ttms, forwards=np.ones(4), strikes_ttms=(k,) * 4, optiontypes_ttms=(ty,) * 4,
                             discfactors=np.ones(4), ids=np.array(list("abcd")))
     p = sv.LOGSV_BTC_PARAMS
+    from stochvolmodels_amd.engine import get_engine
+    get_engine(1024).synchronize()            # library load + HIP runtime start-up are not part of the upload time
     t0 = time.perf_counter()
     W = lp.get_randoms_for_chain_valuation(ttms, nb_path=nb_path, nb_steps_per_year=360, seed=10)
     t_draw = time.perf_counter() - t0
