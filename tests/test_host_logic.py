@@ -227,3 +227,12 @@ def test_native_black_implied_vols_vs_bisection():
     assert np.isnan(out[:3]).all() and abs(out[3] - 0.12538) < 1e-4
     with pytest.raises(NotImplementedError):
         black_ivols_native(np.array([0.1]), 1.0, 1.0, np.array([1.0]), ["IC"])
+
+
+def test_build_keeps_basic_blocks_aligned():
+    """the stepping loop's speed depends on its placement in instruction memory (DESIGN.md section 5, 3.80 vs 4.08 ms
+    for identical instructions): the build must keep aligning basic blocks"""
+    from stochvolmodels_amd import build
+    f = build.flags()
+    assert "--align-all-blocks=4" in f and f[f.index("--align-all-blocks=4") - 1] == "-mllvm"
+    assert "--offload-arch=gfx950" in f
