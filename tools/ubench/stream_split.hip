@@ -8,7 +8,8 @@
 #include "svmc_rng.h"
 using namespace svmc;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+template <bool PRIO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72)))
 void k(double *x, double *sigma, double *qvar, size_t n, int t_begin, int t_end, LogsvFast c, uint64_t seed, uint64_t path0)
 {
     __shared__ LogTabEntry s_tab[256];
@@ -16,7 +17,18 @@ void k(double *x, double *sigma, double *qvar, size_t n, int t_begin, int t_end,
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;
+    const int quarter = (t_end - t_begin + 3) >> 2;
+    int stage = 0, next_stage_t = t_begin;
     for (int t = t_begin; t < t_end; ++t) {
+        if (PRIO && t == next_stage_t) {                   // the product kernel's least-progress-first priorities
+            switch (stage++) {
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+            }
+            next_stage_t += quarter;
+        }
         double z0, z1;
         draw_normals(seed, 0, path0 + p, t, tab, z0, z1);
         logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
@@ -45,7 +57,7 @@ int main()
             const size_t m = n / S;
             for (int g = 0; g < G; ++g)
                 for (int i = 0; i < S; ++i)
-                    hipLaunchKernelGGL(k, dim3(m / 256), dim3(256), 0, st[i], x + i * m, s + i * m, q + i * m, m, g * nb / G, (g + 1) * nb / G, c, 42ull, (uint64_t)(i * m));
+                    hipLaunchKernelGGL(k<true>, dim3(m / 256), dim3(256), 0, st[i], x + i * m, s + i * m, q + i * m, m, g * nb / G, (g + 1) * nb / G, c, 42ull, (uint64_t)(i * m));
             for (int i = 0; i < S; ++i) { hipEventRecord(done[i], st[i]); hipStreamWaitEvent(0, done[i], 0); }
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
