@@ -428,18 +428,25 @@ def logsv_chain_pricer(params, ttms, forwards, discfactors, strikes_ttms, option
 
 
 def heston_chain_pricer(v0, theta, kappa, volvol, rho, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors,
-                        vol_scaler=None):
-    """pricers/heston_pricer.py:217-282 (LOG_RETURN)"""
+                        vol_scaler=None, variable_type=LOG_RETURN):
+    """pricers/heston_pricer.py:217-282 (LOG_RETURN on the phi grid, Q_VAR calls on the psi grid)"""
     if vol_scaler is None:
         vol_scaler = np.minimum(0.3, np.sqrt(v0 * ttms[0]))
-    phi = phi_grid(vol_scaler, True)
-    psi = np.zeros_like(phi)
+    if variable_type == LOG_RETURN:
+        phi = phi_grid(vol_scaler, True)
+        psi = np.zeros_like(phi)
+    else:
+        psi = psi_grid()
+        phi = np.zeros_like(psi)
     a = np.zeros(phi.size, dtype=np.complex128)
     b = np.zeros(phi.size, dtype=np.complex128)
     t0, out = 0.0, []
     for i, ttm in enumerate(ttms):
         lm, a, b = heston_mgf_grid(phi, psi, ttm - t0, v0, theta, kappa, volvol, rho, a_t0=a, b_t0=b)
-        out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
+        if variable_type == LOG_RETURN:
+            out.append(mgf_vanilla_slice(phi, lm, forwards[i], strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
+        else:
+            out.append(mgf_qvar_slice(psi, lm, ttm, strikes_ttms[i], optiontypes_ttms[i], discfactors[i]))
         t0 = ttm
     return out
 

@@ -22,7 +22,7 @@ from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, timer
-from ..analytic import AnalyticGrid, vanilla_prices_from_capped
+from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
 from ..utils import mgf_pricer as mgfp
 from .logsv_pricer import _broadcast_state
 from .model_pricer import ModelParams, ModelPricer
@@ -60,7 +60,8 @@ class HestonPricer(ModelPricer):
         return heston_chain_pricer(v0=params.v0, theta=params.theta, kappa=params.kappa, volvol=params.volvol,
                                    rho=params.rho, ttms=option_chain.ttms, forwards=option_chain.forwards,
                                    discfactors=option_chain.discfactors, strikes_ttms=option_chain.strikes_ttms,
-                                   optiontypes_ttms=option_chain.optiontypes_ttms)
+                                   optiontypes_ttms=option_chain.optiontypes_ttms,
+                                   variable_type=kwargs.get("variable_type", VariableType.LOG_RETURN))
 
     def model_mc_price_chain(self, option_chain: OptionChain, params: HestonParams, nb_path: int = 100000,
                              variable_type: VariableType = VariableType.LOG_RETURN, **kwargs
@@ -134,8 +135,10 @@ def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rh
                         forwards: np.ndarray, strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray],
                         discfactors: np.ndarray, variable_type: VariableType = VariableType.LOG_RETURN,
                         vol_scaler: float = None) -> List[np.ndarray]:
-    """analytic Heston chain prices (reference :217-282), LOG_RETURN"""
-    if int(getattr(variable_type, "value", variable_type)) != 1:
+    """analytic Heston chain prices (reference :217-282): LOG_RETURN on the 1000-point phi grid, Q_VAR (calls on the
+    annualised quadratic variance) on the 40 000-point psi grid"""
+    vt = int(getattr(variable_type, "value", variable_type))
+    if vt not in (1, 2):
         raise NotImplementedError(f"variable_type={variable_type}")
     if vol_scaler is None:
         vol_scaler = np.minimum(0.3, np.sqrt(v0 * ttms[0]))
@@ -145,8 +148,12 @@ def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rh
         prices, ttm0 = [], 0.0
         for ttm, forward, discfactor, strikes, types in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms):
             grid.heston_advance(ttm - ttm0, v0, theta, kappa, volvol, rho, True)     # zero a, b == the None branch
-            capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
-            prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor), True))
+            if vt == 1:
+                capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
+                prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor), True))
+            else:
+                sums = grid.qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64))
+                prices.append(qvar_prices_from_sums(sums, float(ttm), types, float(discfactor)))
             ttm0 = ttm
         return prices
     finally:

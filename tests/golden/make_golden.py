@@ -422,6 +422,26 @@ def g_analytic_qvar():
     save("analytic_qvar", **out)
 
 
+def g_heston_qvar():
+    """analytic Heston options on the annualised quadratic variance (heston_chain_pricer, variable_type Q_VAR:
+    closed-form MGF on the 40 000-point psi grid, pricers/heston_pricer.py:217-282)"""
+    out = {}
+    ttms = np.array([0.25, 0.5, 1.0])
+    fw, df = np.ones(3), np.array([0.99, 0.98, 0.96])
+    sets = {"base": (hp.HestonParams(), np.linspace(0.02, 0.09, 8)),
+            "btc": (hp.BTC_HESTON_PARAMS, np.linspace(0.2, 1.4, 8))}
+    for tag, (p, kk) in sets.items():
+        types = np.array(["C"] * 8)         # the reference prices calls only on this variable
+        pr = hp.heston_chain_pricer(v0=p.v0, theta=p.theta, kappa=p.kappa, volvol=p.volvol, rho=p.rho, ttms=ttms,
+                                    forwards=fw, strikes_ttms=(kk,) * 3, optiontypes_ttms=(types,) * 3, discfactors=df,
+                                    variable_type=VariableType.Q_VAR)
+        out[f"{tag}_params"] = np.array([p.v0, p.theta, p.kappa, p.rho, p.volvol])
+        out[f"{tag}_strikes"], out[f"{tag}_types"] = kk, types
+        out[f"{tag}_prices"] = np.stack([np.asarray(a) for a in pr])
+    out.update(ttms=ttms, forwards=fw, discfactors=df)
+    save("heston_qvar", **out)
+
+
 # -- f.4: rough LogSV (pricers/rough_logsv/split_simulation.py, pricers/logsv_pricer.py:1164-1232) --------------
 def g_rough():
     import stochvolmodels as svm
@@ -551,5 +571,6 @@ if __name__ == "__main__":
     g_analytic()
     g_analytic_tight()
     g_analytic_qvar()
+    g_heston_qvar()
     g_rough()
     g_calibration()

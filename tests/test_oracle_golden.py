@@ -340,3 +340,14 @@ def test_rough_logsv_chain(oracle, golden, tag):
         # produced by its Numba fastmath build, hence not bit-equal to its NumPy-mode run either)
         for i in range(len(ttms)):
             np.testing.assert_allclose(pr[i], g[f"reference_regression_prices_{i}"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["base", "btc"])
+def test_heston_analytic_qvar(oracle, golden, tag):
+    """closed-form Heston MGF on the psi grid + the quadratic-variance call transform against the reference"""
+    g = golden("heston_qvar")
+    v0, theta, kappa, rho, volvol = (float(a) for a in g[f"{tag}_params"])
+    kk, ty = g[f"{tag}_strikes"], g[f"{tag}_types"]
+    pr = oracle.heston_chain_pricer(v0, theta, kappa, volvol, rho, g["ttms"], g["forwards"], (kk,) * 3, (ty,) * 3,
+                                    g["discfactors"], variable_type=2)
+    np.testing.assert_allclose(np.stack(pr), g[f"{tag}_prices"], rtol=1e-10, atol=1e-13)
