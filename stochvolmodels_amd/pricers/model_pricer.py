@@ -2,7 +2,7 @@
 ModelParams / ModelPricer: the Monte Carlo part of the reference's pricer interface
 (pricers/model_pricer.py:28-41, :83-265).
 
-Kept: price_chain, compute_chain_prices_with_vols, compute_model_ivols_for_chain, model_mc_price_chain,
+Kept: price_chain, price_slice, price_vanilla, compute_chain_prices_with_vols, compute_model_ivols_for_chain, model_mc_price_chain,
 simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols, get_log_return_mc_pdf,
 calibrate_model_params_to_chain with the reference's signatures.  Out of scope: the
 matplotlib plotting methods and the slice / single-option conveniences built on them.
@@ -44,6 +44,21 @@ class ModelPricer(ABC):
     def compute_model_ivols_for_chain(self, option_chain: OptionChain, params: ModelParams, **kwargs
                                       ) -> List[np.ndarray]:
         return self.compute_chain_prices_with_vols(option_chain=option_chain, params=params, **kwargs)[1]
+
+    def price_slice(self, params: ModelParams, ttm: float, forward: float, strikes: np.ndarray, optiontypes: np.ndarray,
+                    discfactor: float = 1.0, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        """one expiry through the chain pricer: (prices, Black implied vols) (reference :156-178)"""
+        chain = OptionChain.slice_to_chain(ttm=ttm, forward=forward, strikes=strikes, optiontypes=optiontypes,
+                                           discfactor=discfactor)
+        prices = self.price_chain(option_chain=chain, params=params, **kwargs)
+        return prices[0], chain.compute_model_ivols_from_chain_data(model_prices=prices)[0]
+
+    def price_vanilla(self, params: ModelParams, ttm: float, forward: float, strike: float, optiontype: str,
+                      discfactor: float = 1.0, **kwargs) -> Tuple[float, float]:
+        """one option through price_slice: (price, Black implied vol) (reference :180-195)"""
+        prices, ivols = self.price_slice(params=params, ttm=ttm, forward=forward, strikes=np.array([strike]),
+                                         optiontypes=np.array([optiontype]), discfactor=discfactor, **kwargs)
+        return prices[0], ivols[0]
 
     def calibrate_model_params_to_chain(self, option_chain: OptionChain, **kwargs):
         raise NotImplementedError("must be implemented in parent class")

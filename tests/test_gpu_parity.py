@@ -1153,3 +1153,18 @@ def test_heston_analytic_qvar_vs_reference(sv, golden, tag):
             assert np.all(np.abs(mc[i] - pr[i]) <= 4.0 * sd[i] + 0.01 * pr[i] + 1e-6), (i, mc[i], pr[i], sd[i])
     with pytest.raises(ValueError):                # the reference prices calls only on this variable
         sv.heston_chain_pricer(variable_type=sv.VariableType.Q_VAR, **dict(kw, optiontypes_ttms=(np.array(["P"] * 8),) * 3))
+
+
+def test_price_slice_and_vanilla_consistent_with_chain(sv):
+    """ModelPricer.price_slice / price_vanilla (reference model_pricer.py:156-195; its own consistency test is
+    tests/test_logsv_characterization.py:101-143): one slice / one option through the chain pricer"""
+    kk = np.array([0.9, 1.0, 1.1])
+    ty = np.array(["P", "C", "C"])
+    for pricer, params in ((sv.LogSVPricer(), sv.LOGSV_BTC_PARAMS), (sv.HestonPricer(), sv.HestonParams())):
+        chain = sv.OptionChain.slice_to_chain(ttm=0.25, forward=1.0, strikes=kk, optiontypes=ty, discfactor=0.99)
+        ref = pricer.price_chain(option_chain=chain, params=params)[0]
+        pr, iv = pricer.price_slice(params=params, ttm=0.25, forward=1.0, strikes=kk, optiontypes=ty, discfactor=0.99)
+        np.testing.assert_array_equal(pr, ref)
+        assert np.all(np.isfinite(iv)) and np.all(iv > 0)
+        p1, v1 = pricer.price_vanilla(params=params, ttm=0.25, forward=1.0, strike=1.0, optiontype="C", discfactor=0.99)
+        np.testing.assert_allclose([p1, v1], [pr[1], iv[1]], rtol=1e-12)
