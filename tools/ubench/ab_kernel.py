@@ -11,7 +11,7 @@ L.svmc_event_create.argtypes = [C.POINTER(vp)]
 L.svmc_event_record.argtypes = [vp, vp]
 L.svmc_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
 L.svmc_stream_synchronize.argtypes = [vp]
-n = 1 << 20
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 b = [vp() for _ in range(3)]
 for x in b:
     assert L.svmc_malloc(C.byref(x), 8 * n) == 0
@@ -30,4 +30,4 @@ for _ in range(20):
     L.svmc_logsv_terminal_rng(b[0], b[1], b[2], n, 1024, 1 / 1024, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1.0, 1, 7, 0, 0, 0, None)
     L.svmc_event_record(e1, None)
     ms = C.c_float(); L.svmc_event_elapsed_ms(e0, e1, C.byref(ms)); ts.append(ms.value)
-print(json.dumps(dict(lib=os.path.basename(sys.argv[1]), mean_ms=sum(ts) / len(ts), min_ms=min(ts))))
+print(json.dumps(dict(lib=os.path.basename(sys.argv[1]), log2_paths=n.bit_length() - 1, mean_ms=sum(ts) / len(ts), min_ms=min(ts), path_steps_per_s=n * 1024 / (sum(ts) / len(ts)) * 1e3)))
