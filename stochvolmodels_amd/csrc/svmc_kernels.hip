@@ -184,7 +184,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
 {
     __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ double s_exp[64];
+    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
             }
             double z0, z1;
             draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-            logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
+            logsv_step_fast(c, xv, L, s, s2, q, z0, z1, exp_of);
         }
         x[p] = xv;
         sigma[p] = s;
@@ -232,7 +234,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
     double *__restrict__ partials)
 {
     __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ double s_exp[64];
+    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                 }
                 double z0, z1;
                 draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
-                logsv_step_fast(c, xv, L, s, s2, q, z0, z1);
+                logsv_step_fast(c, xv, L, s, s2, q, z0, z1, exp_of);
             }
         }
         tg += nb;
@@ -467,15 +471,16 @@ __device__ __forceinline__ void rough_rk4_drift(const RoughConsts &c, const doub
     for (int i = 0; i < N; ++i) zh[i] = z0[i] + (h / 6.0) * (s1[i] + 2.0 * s2[i] + 2.0 * s3[i] + s4[i]);
 }
 
-template <int N>
-__device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N], double &ls, double &y, double z0, double z1)
+template <int N, class Exp>
+__device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N], double &ls, double &y, double z0, double z1,
+                                           Exp &&exp_of)
 {
     double d[N], sn[N], vh[N];
     rough_rk4_drift<N>(c, v, 0.5 * c.h, d);                                                      // :273
     double yw = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) yw += c.w[i] * d[i];
-    const double Yh = yw * exp_fast(c.ito + c.volvol_w_sqrt_h * z0);   // :238-239
+    const double Yh = yw * exp_of(c.ito + c.volvol_w_sqrt_h * z0);   // :238-239
     const double Q = c.w_inv * (Yh - yw);
 #pragma unroll
     for (int i = 0; i < N; ++i) sn[i] = d[i] + Q;
@@ -519,7 +524,9 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
                                                             int from_origin, SliceOut so)
 {
     __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ double s_exp[64];
+    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const auto exp_of = [&](double a) { return exp_tab(a, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
     double ls = 0.0, y = 0.0;
@@ -539,11 +546,11 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
             for (int t = 0; t < nb_steps; ++t) {
                 double z0, z1;
                 draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-                rough_step<N>(c, v, ls, y, z0, z1);
+                rough_step<N>(c, v, ls, y, z0, z1, exp_of);
             }
         } else {
             const double *const w[2] = {Z0 + p, Z1 + p};
-            streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1]); });
+            streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1], exp_of); });
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];

@@ -86,9 +86,11 @@ inline LogsvFast make_logsv_fast(const LogsvConsts &c)
     return f;
 }
 
-// z0, z1 are UNSCALED N(0,1); s2 = sigma^2 is carried
+// z0, z1 are UNSCALED N(0,1); s2 = sigma^2 is carried; exp_of(L) is the exponential to use (exp_fast, or exp_tab with
+// the block's LDS table in the issue-bound kernels)
+template <class Exp>
 __device__ __forceinline__ void logsv_step_fast(const LogsvFast &f, double &x, double &L, double &sigma, double &s2,
-                                                double &qvar, double z0, double z1)
+                                                double &qvar, double z0, double z1, Exp &&exp_of)
 {
     const double s = sigma;
     const double y = rcp_1n(s);
@@ -96,11 +98,17 @@ __device__ __forceinline__ void logsv_step_fast(const LogsvFast &f, double &x, d
     x = fma(f.B * s, z0, x);
     const double d = fma(f.c1, y, fma(f.c2, s, f.c3));
     L = fma(f.es, z1, fma(f.bs, z0, L + d));
-    const double sn = exp_fast(L);
+    const double sn = exp_of(L);
     const double s2n = sn * sn;
     qvar = fma(f.hA, s2 + s2n, qvar);
     sigma = sn;
     s2 = s2n;
+}
+
+__device__ __forceinline__ void logsv_step_fast(const LogsvFast &f, double &x, double &L, double &sigma, double &s2,
+                                                double &qvar, double z0, double z1)
+{
+    logsv_step_fast(f, x, L, sigma, s2, qvar, z0, z1, [](double v) { return exp_fast(v); });
 }
 
 // ---- Heston Euler with the reference's floor: pricers/heston_pricer.py:372-379 ---------------------

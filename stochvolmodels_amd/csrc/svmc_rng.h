@@ -32,6 +32,17 @@ __device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)
     return lds;
 }
 
+// the 512 B table of exp_tab(), staged with the log table (one barrier for both)
+__constant__ double g_exp_table[64] = {SVMC_EXP_TABLE_INIT};
+
+__device__ __forceinline__ const LogTabEntry *stage_tables(LogTabEntry (&lds_log)[256], double (&lds_exp)[64])
+{
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_log[i] = g_log_table[i];
+    for (unsigned i = threadIdx.x; i < 64u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
+    __syncthreads();
+    return lds_log;
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&r)[4])
 {

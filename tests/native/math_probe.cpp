@@ -3,8 +3,10 @@
 #include "svmc_log_table.h"
 #include "svmc_math.h"
 static const svmc::LogTabEntry LOG_TAB[256] = {SVMC_LOG_TABLE_INIT};
+static const double EXP_TAB[64] = {SVMC_EXP_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
+void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_tab(x[i], EXP_TAB); }
 void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }
 void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log_tab(x[i], LOG_TAB); }
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }

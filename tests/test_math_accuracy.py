@@ -51,6 +51,20 @@ def test_exp(probe):
     assert np.isnan(_call(probe, "probe_exp", np.array([np.nan]))[0])
 
 
+def test_exp_table(probe):
+    """exp_tab (64-entry table, degree-3 tail polynomial: the exponential of the issue-bound stepping kernels)"""
+    rng = np.random.default_rng(10)
+    for lo, hi in ((-1, 1), (-30, 30), (-700, 700)):
+        x = rng.uniform(lo, hi, N)
+        assert _ulp(_call(probe, "probe_exp_tab", x), np.exp(x.astype(np.longdouble))) <= 1.5
+    x = np.arange(-4096, 4096) * (np.log(2.0) / 64)                 # the table nodes, both sides of every rounding tie
+    for eps in (0.0, 1e-17, -1e-17, 2.7e-3, -2.7e-3):
+        assert _ulp(_call(probe, "probe_exp_tab", x + eps), np.exp((x + eps).astype(np.longdouble))) <= 1.5
+    assert _call(probe, "probe_exp_tab", np.array([800.0]))[0] == np.inf
+    assert _call(probe, "probe_exp_tab", np.array([-800.0]))[0] == 0.0
+    assert _call(probe, "probe_exp_tab", np.array([0.0]))[0] == 1.0
+
+
 def test_neg_log(probe):
     rng = np.random.default_rng(1)
     u = rng.integers(0, 2 ** 52, N).astype(np.float64) * 2.0 ** -52 + 2.0 ** -53       # the RNG lattice
