@@ -196,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         q = qvar[p];
         double L = log(s);                                                                      // :1039
         double s2 = s * s;
-        const uint64_t gp = path_offset + p;
+        const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
         const int quarter = (nb_steps + 3) >> 2;
         int stage = 0, next_stage_t = 0;
         for (int t = 0; t < nb_steps; ++t) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                 next_stage_t += quarter;
             }
             double z0, z1;
-            draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
+            draw_normals(lane, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
             logsv_step_fast(c, xv, L, s, s2, q, z0, z1, exp_of);
         }
         x[p] = xv;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         s = sigma[p];
         q = qvar[p];
     }
-    const uint64_t gp = path_offset + p;
+    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
     const int quarter = (cs.total_steps + 3) >> 2;
     int stage = 0, next_stage_t = 0, tg = 0;
     for (int i = 0; i < cs.m; ++i) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                     next_stage_t += quarter;
                 }
                 double z0, z1;
-                draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
+                draw_normals(lane, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
                 logsv_step_fast(c, xv, L, s, s2, q, z0, z1, exp_of);
             }
         }

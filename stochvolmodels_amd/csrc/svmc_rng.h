@@ -64,6 +64,71 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
 }
 
+// The same function with the work that does not depend on the step taken out of the time loop.  The counter is
+// (path_lo, path_hi, step, c3): in round 1 the product M0 * path_lo, the word path_hi ^ k0 and the whole new third word
+// hi(M0 path_lo) ^ c3 ^ k1 are per-lane constants, M1 * step is wave-uniform (scalar unit), and round 2's product
+// M1 * (third word) is a per-lane constant again.  Left to the compiler the xor3's of rounds 1-2 each needed a
+// v_mov to get a second scalar operand in; here round 1 is one v_xor and round 2 one v_xor + one xor3.
+struct PhiloxLane {
+    uint32_t a;        // path_hi ^ k0
+    uint32_t b;        // hi(M0 path_lo) ^ c3 ^ k1            (round-1 third word)
+    uint32_t lo0;      // lo(M0 path_lo)                      (round-1 fourth word)
+    uint32_t hi_b;     // hi(M1 b)
+    uint32_t lo_b;     // lo(M1 b)                            (round-2 second word)
+    uint32_t k0, k1;   // round-2 keys
+};
+
+__device__ __forceinline__ PhiloxLane philox_prepare(uint64_t seed, uint32_t c3, uint64_t path)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+    const uint64_t p0 = static_cast<uint64_t>(M0) * static_cast<uint32_t>(path);
+    PhiloxLane l;
+    l.a = static_cast<uint32_t>(path >> 32) ^ k0;
+    l.b = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+    l.lo0 = static_cast<uint32_t>(p0);
+    const uint64_t pb = static_cast<uint64_t>(M1) * l.b;
+    l.hi_b = static_cast<uint32_t>(pb >> 32);
+    l.lo_b = static_cast<uint32_t>(pb);
+    l.k0 = k0 + W0;
+    l.k1 = k1 + W1;
+    // opaque to the optimiser: otherwise it re-splits a into (path_hi, k0) and pays the second xor inside the loop
+    asm volatile("" : "+v"(l.a), "+v"(l.b), "+v"(l.lo0), "+v"(l.hi_b), "+v"(l.lo_b));
+    return l;
+}
+
+__device__ __forceinline__ void philox_draw(const PhiloxLane &l, uint32_t step, uint32_t (&r)[4])
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    // round 1: c = (hi(M1 step) ^ a, lo(M1 step), b, lo0)
+    const uint64_t p1 = static_cast<uint64_t>(M1) * step;                  // wave-uniform
+    uint32_t c0 = static_cast<uint32_t>(p1 >> 32) ^ l.a;
+    const uint32_t c1_r1 = static_cast<uint32_t>(p1);                      // wave-uniform
+    // round 2
+    const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
+    uint32_t k0 = l.k0, k1 = l.k1;
+    c0 = l.hi_b ^ __builtin_amdgcn_readfirstlane(c1_r1 ^ k0);              // (uniform ^ uniform) stays on the scalar unit
+    uint32_t c2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), l.lo0, k1, 0x96);
+    uint32_t c1 = l.lo_b;
+    uint32_t c3 = static_cast<uint32_t>(p0);
+    k0 += W0;
+    k1 += W1;
+#pragma unroll
+    for (int i = 2; i < 10; ++i) {
+        const uint64_t q0 = static_cast<uint64_t>(M0) * c0;
+        const uint64_t q1 = static_cast<uint64_t>(M1) * c2;
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(q1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(q0 >> 32), c3, k1, 0x96);
+        c1 = static_cast<uint32_t>(q1);
+        c3 = static_cast<uint32_t>(q0);
+        c0 = n0;
+        c2 = n2;
+        k0 += W0;
+        k1 += W1;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+
 // top 52 bits of hi:lo as the mantissa of a double in [1,2): two v_alignbit_b32
 __device__ __forceinline__ double mantissa_1_2(uint32_t lo, uint32_t hi)
 {
@@ -107,6 +172,22 @@ __device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t pat
     const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
     const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
+    const double e = neg_log_tab(u1, tab);
+    const double R = sqrt_pos(e + e);
+    double sn, cs;
+    sincos_quarter(r[2] & 3u, rr, sn, cs);
+    w0 = R * cs;
+    w1 = R * sn;
+}
+
+// the same pair from a prepared lane state (philox_prepare outside the time loop)
+__device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t step, const LogTabEntry *tab, double &w0,
+                                             double &w1)
+{
+    uint32_t r[4];
+    philox_draw(lane, step, r);
+    const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
+    const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
     const double e = neg_log_tab(u1, tab);
     const double R = sqrt_pos(e + e);
     double sn, cs;
