@@ -542,10 +542,10 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
             for (int i = 0; i < N; ++i) v[i] = vol[static_cast<size_t>(i) * n + p];
         }
         if (RNG) {
-            const uint64_t gp = path_offset + p;
+            const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
             for (int t = 0; t < nb_steps; ++t) {
                 double z0, z1;
-                draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
+                draw_normals(lane, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
                 rough_step<N>(c, v, ls, y, z0, z1, exp_of);
             }
         } else {
@@ -579,16 +579,16 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         xv = x[p];
         v = var[p];
         q = qvar[p];
-        const uint64_t gp = path_offset + p;
+        const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
         for (int t = 0; t < nb_steps; ++t) {
             const uint32_t step = step_offset + static_cast<uint32_t>(t);
             double w0, w1;
             if (SCHEME == SVMC_HESTON_QE) {
                 double u;
-                draw_qe(seed, c3, gp, step, tab, w0, w1, u);
+                draw_qe(lane, step, tab, w0, w1, u);
                 heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
             } else {
-                draw_normals(seed, c3, gp, step, tab, w0, w1);
+                draw_normals(lane, step, tab, w0, w1);
                 heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
             }
         }
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
         v = var[p];
         q = qvar[p];
     }
-    const uint64_t gp = path_offset + p;
+    const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
     uint32_t step = step_offset;
     for (int i = 0; i < cs.m; ++i) {
         const int nb = cs.nb_steps[i];
@@ -637,10 +637,10 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
                 double w0, w1;
                 if (SCHEME == SVMC_HESTON_QE) {
                     double u;
-                    draw_qe(seed, c3, gp, step + static_cast<uint32_t>(t), tab, w0, w1, u);
+                    draw_qe(lane, step + static_cast<uint32_t>(t), tab, w0, w1, u);
                     heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
                 } else {
-                    draw_normals(seed, c3, gp, step + static_cast<uint32_t>(t), tab, w0, w1);
+                    draw_normals(lane, step + static_cast<uint32_t>(t), tab, w0, w1);
                     heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
                 }
             }

@@ -196,6 +196,24 @@ __device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t st
     w1 = R * sn;
 }
 
+// draw_qe from a prepared lane state (prepare it with the stream-4 tag: philox_prepare(seed, c3 | 4u, path))
+__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const LogTabEntry *tab, double &w0,
+                                        double &w1, double &u)
+{
+    uint32_t r[4];
+    philox_draw(lane, step, r);
+    const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
+    const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
+    const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
+    u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
+    const double e = neg_log_tab(u1, tab);
+    const double R = sqrt_pos(e + e);
+    double sn, cs;
+    sincos_quarter(r[2] & 3u, rr, sn, cs);
+    w0 = R * cs;
+    w1 = R * sn;
+}
+
 // stream 1: one uniform in (0,1)
 __device__ __forceinline__ double draw_uniform(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step)
 {
