@@ -294,7 +294,8 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  *   u1 = ((r0 | r1<<32) >> 12) * 2^-52 + 2^-53      in (0,1), exact in fp64
  *   rr = ((r2 | r3<<32) >> 12) * 2^-52 - 1/2        in [-1/2, 1/2), exact in fp64
  *   q  = r2 & 3
- *   stream 0:  R = sqrt(-2 ln u1);  theta = (pi/2)(q + rr);  w0 = R cos(theta);  w1 = R sin(theta)
+ *   stream 0:  R = sqrt(-ln u1);  x = (pi/2) rr;  w0 = s0 R (cos x - sin x);  w1 = s1 R (cos x + sin x);
+ *              s0 = -1 if r2 & 1, s1 = -1 if r2 & 2   (= sqrt(-2 ln u1) (s0 cos, s1 sin)(x + pi/4))
  *   stream 1:  uniform = u1
  * ---------------------------------------------------------------------------------------------- */
 void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
@@ -343,14 +344,13 @@ static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, 
     philox_draw(seed, call_id, path, step, stream, r);
     double u1 = m52(r[0], r[1]) + 0x1.0p-53;
     double rr = m52(r[2], r[3]) - 0.5;
-    double R = sqrt(-2.0 * log(u1));
+    double R = sqrt(-log(u1));                               /* the sqrt2 of sqrt(-2 ln u) lives in (a, b) */
     double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);     /* |angle| <= pi/4: no reduction error */
-    switch (r[2] & 3u) {                                     /* rotate by q quarter turns */
-    case 0: *w0 = R * c;  *w1 = R * s;  break;
-    case 1: *w0 = R * -s; *w1 = R * c;  break;
-    case 2: *w0 = R * -c; *w1 = R * -s; break;
-    default: *w0 = R * s; *w1 = R * -c; break;
-    }
+    double a = c - s, b = c + s;                             /* sqrt2 (cos, sin)(x + pi/4) */
+    if (r[2] & 1u) a = -a;
+    if (r[2] & 2u) b = -b;
+    *w0 = R * a;
+    *w1 = R * b;
 }
 
 /* stream 4 (Heston QE): pair and uniform from one Philox call -- device twin draw_qe, csrc/svmc_rng.h */
@@ -363,14 +363,13 @@ void svo_draw_qe(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, 
     double rr = m52(r[2] & 0xFFC00000u, r[3]) - 0.5;
     uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     *u = (double)k * 0x1.0p-32 + 0x1.0p-33;
-    double R = sqrt(-2.0 * log(u1));
+    double R = sqrt(-log(u1));
     double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);
-    switch (r[2] & 3u) {
-    case 0: *w0 = R * c;  *w1 = R * s;  break;
-    case 1: *w0 = R * -s; *w1 = R * c;  break;
-    case 2: *w0 = R * -c; *w1 = R * -s; break;
-    default: *w0 = R * s; *w1 = R * -c; break;
-    }
+    double a = c - s, b = c + s;
+    if (r[2] & 1u) a = -a;
+    if (r[2] & 2u) b = -b;
+    *w0 = R * a;
+    *w1 = R * b;
 }
 
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step)

@@ -6,7 +6,7 @@
 // instructions by using what this path knows about its arguments:
 //   neg_log(u)      u in (0,1) normal            -> no denormal/negative/NaN handling, integer frexp
 //   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
-//   sincos_quarter  |r| <= 1/2, quadrant given   -> no range reduction at all
+//   cossin_diag     |r| <= 1/2, two sign bits given -> no range reduction, no quadrant swap
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
 // Accuracy (tests/test_math_accuracy.py, vs 80-bit libm on the host build; tests/test_gpu_parity.py on
@@ -232,9 +232,13 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
     return fma(-dk, 0x1.62e42fee00000p-1, -a);
 }
 
-// cos and sin of (pi/2)(q + r) for |r| <= 1/2 and q in {0,1,2,3}: two 7-term even/odd polynomials in r (degree 13 / 14), then the
-// quadrant rotation by sign flips and one swap.
-SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)
+// The direction of a Box-Muller pair, scaled by sqrt2: with x = (pi/2) r, |r| <= 1/2, returns
+//     a = s0 (cos x - sin x) = s0 sqrt2 cos(x + pi/4),    b = s1 (cos x + sin x) = s1 sqrt2 sin(x + pi/4),
+// s0 = -1 if q & 1, s1 = -1 if q & 2.  x + pi/4 is uniform on [0, pi/2) and the two signs are independent fair bits, so
+// (a, b)/sqrt2 is uniform on the circle -- without the quadrant swap (four 32-bit selects) a rotation by q quarter
+// turns needs; the sqrt2 is absorbed by taking the radius as sqrt(-ln u) instead of sqrt(-2 ln u).  Two 7-term
+// even/odd polynomials in r (degree 13 / 14), two FMAs, two sign xors.
+SVMC_HD void cossin_diag(uint32_t q, double r, double &a, double &b)
 {
     const double z = r * r;
     double ps = 0x1.e3f38399551bfp-25;
@@ -243,7 +247,7 @@ SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)
     ps = fma_k(ps, z, -0x1.32d2cce2e5b19p-8);
     ps = fma_k(ps, z, 0x1.466bc677587f8p-4);
     ps = fma_k(ps, z, -0x1.4abbce625be41p-1);
-    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);
+    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);      // sin((pi/2) r) = r ps
     double pc = -0x1.b2f3eb054afcdp-28;
     pc = fma_k(pc, z, 0x1.f9ce245cada0bp-22);
     pc = fma_k(pc, z, -0x1.a6d1eef479be1p-16);
@@ -251,16 +255,11 @@ SVMC_HD void sincos_quarter(uint32_t q, double r, double &sn, double &cs)
     pc = fma_k(pc, z, -0x1.55d3c7e3cb241p-6);
     pc = fma_k(pc, z, 0x1.03c1f081b5ac0p-2);
     pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);
-    const double s0 = ps * r;            // sin((pi/2) r)
-    const double c0 = fma_k(pc, z, 1.0);  // cos((pi/2) r)
-    // q=0: (c, s)  q=1: (-s, c)  q=2: (-c, -s)  q=3: (s, -c)
-    const bool swap = (q & 1u) != 0u;
-    const double cq = swap ? s0 : c0;
-    const double sq = swap ? c0 : s0;
-    const uint32_t cneg = ((q + 1u) & 2u) << 30;
-    const uint32_t sneg = (q & 2u) << 30;
-    cs = bits_to_double(double_lo(cq), double_hi(cq) ^ cneg);
-    sn = bits_to_double(double_lo(sq), double_hi(sq) ^ sneg);
+    const double c0 = fma_k(pc, z, 1.0);          // cos((pi/2) r)
+    const double am = fma(-ps, r, c0);            // cos - sin = sqrt2 cos(x + pi/4)   in (0, sqrt2]
+    const double bm = fma(ps, r, c0);             // cos + sin = sqrt2 sin(x + pi/4)   in [0, sqrt2)
+    a = bits_to_double(double_lo(am), double_hi(am) ^ (q << 31));
+    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((q << 30) & 0x80000000u));
 }
 
 }  // namespace svmc

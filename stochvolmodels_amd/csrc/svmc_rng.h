@@ -10,8 +10,10 @@
 //   (r0, r1, r2, r3) = philox4x32_10(ctr = (path_lo, path_hi, step, stream | call_id << 8), key = seed)
 //   u1 = double(1.m) - (1 - 2^-53),  m = top 52 bits of r1:r0          in (0,1), exact
 //   rr = double(1.m) - 1.5,          m = top 52 bits of r3:r2          in [-1/2, 1/2), exact
-//   q  = r2 & 3                                                          quadrant (bits not used by rr)
-//   stream 0:  R = sqrt(-2 ln u1), theta = (pi/2)(q + rr),  (w0, w1) = R (cos theta, sin theta)
+//   s0 = -1 if r2 & 1 else +1,  s1 = -1 if r2 & 2 else +1               two sign bits (not used by rr)
+//   stream 0:  R = sqrt(-ln u1), x = (pi/2) rr,  (w0, w1) = R (s0 (cos x - sin x), s1 (cos x + sin x))
+//              = sqrt(-2 ln u1) (s0 cos(x + pi/4), s1 sin(x + pi/4)):  a Box-Muller pair whose angle is uniform on the
+//              circle by construction (x + pi/4 uniform on the first quadrant, independent signs)
 //   stream 1:  uniform = u1
 #pragma once
 #include <hip/hip_runtime.h>
@@ -151,12 +153,11 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_
     philox_draw(seed, c3, path, step, r);
     const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
     const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
-    const double e = neg_log_tab(u1, tab);
-    const double R = sqrt_pos(e + e);
-    double sn, cs;
-    sincos_quarter(r[2] & 3u, rr, sn, cs);
-    w0 = R * cs;
-    w1 = R * sn;
+    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    double a, b;
+    cossin_diag(r[2], rr, a, b);
+    w0 = R * a;
+    w1 = R * b;
 }
 
 // stream 4 (Heston QE): the Box-Muller pair AND the uniform of the exponential branch from ONE Philox call.
@@ -172,12 +173,11 @@ __device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t pat
     const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
     const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double e = neg_log_tab(u1, tab);
-    const double R = sqrt_pos(e + e);
-    double sn, cs;
-    sincos_quarter(r[2] & 3u, rr, sn, cs);
-    w0 = R * cs;
-    w1 = R * sn;
+    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    double a, b;
+    cossin_diag(r[2], rr, a, b);
+    w0 = R * a;
+    w1 = R * b;
 }
 
 // the same pair from a prepared lane state (philox_prepare outside the time loop)
@@ -188,12 +188,11 @@ __device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t st
     philox_draw(lane, step, r);
     const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
     const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
-    const double e = neg_log_tab(u1, tab);
-    const double R = sqrt_pos(e + e);
-    double sn, cs;
-    sincos_quarter(r[2] & 3u, rr, sn, cs);
-    w0 = R * cs;
-    w1 = R * sn;
+    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    double a, b;
+    cossin_diag(r[2], rr, a, b);
+    w0 = R * a;
+    w1 = R * b;
 }
 
 // draw_qe from a prepared lane state (prepare it with the stream-4 tag: philox_prepare(seed, c3 | 4u, path))
@@ -206,12 +205,11 @@ __device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, c
     const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
     const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double e = neg_log_tab(u1, tab);
-    const double R = sqrt_pos(e + e);
-    double sn, cs;
-    sincos_quarter(r[2] & 3u, rr, sn, cs);
-    w0 = R * cs;
-    w1 = R * sn;
+    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    double a, b;
+    cossin_diag(r[2], rr, a, b);
+    w0 = R * a;
+    w1 = R * b;
 }
 
 // stream 1: one uniform in (0,1)

@@ -13,6 +13,6 @@ void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n
 void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
 void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) svmc::sincos_quarter(q[i], r[i], s[i], c[i]);
+    for (size_t i = 0; i < n; ++i) svmc::cossin_diag(q[i], r[i], c[i], s[i]);   // c <- a = s0 (cos - sin), s <- b = s1 (cos + sin)
 }
 }

@@ -108,18 +108,22 @@ def test_sqrt_and_rcp(probe):
     assert _ulp(_call(probe, "probe_rcp", a), 1 / a.astype(np.longdouble)) <= 1.0
 
 
-def test_sincos_quarter(probe):
+def test_cossin_diag(probe):
+    """the Box-Muller direction: a = s0 (cos x - sin x), b = s1 (cos x + sin x), x = (pi/2) r, signs from two bits
+    of q (other bits of q must not matter): absolute accuracy 3e-16 (values up to sqrt2), i.e. sqrt2 (cos, sin) of
+    x + pi/4 with independent signs"""
     rng = np.random.default_rng(3)
     r = np.concatenate([rng.uniform(-0.5, 0.5, N), [-0.5, 0.0, 0.5 - 2.0 ** -53]])
     n = r.size
     pi = np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16)
-    for q in range(4):
+    x = pi / 2 * r.astype(np.longdouble)
+    for q in (0, 1, 2, 3, 0xFFFFFFFC, 0x80000001, 0x7FFFFFFE):
         qq = np.full(n, q, dtype=np.uint32)
-        s, c = np.empty(n), np.empty(n)
-        probe.probe_sincos(qq.ctypes.data_as(C.POINTER(C.c_uint32)), r.ctypes.data_as(DP), s.ctypes.data_as(DP),
-                           c.ctypes.data_as(DP), C.c_size_t(n))
-        ang = pi / 2 * (q + r.astype(np.longdouble))
-        assert np.max(np.abs(s - np.sin(ang))) <= 2.3e-16
-        assert np.max(np.abs(c - np.cos(ang))) <= 2.3e-16
-        if q == 0:
-            assert _ulp(s, np.sin(ang)) <= 2.0 and _ulp(c, np.cos(ang)) <= 2.0
+        b, a = np.empty(n), np.empty(n)
+        probe.probe_sincos(qq.ctypes.data_as(C.POINTER(C.c_uint32)), r.ctypes.data_as(DP), b.ctypes.data_as(DP),
+                           a.ctypes.data_as(DP), C.c_size_t(n))
+        s0 = -1.0 if q & 1 else 1.0
+        s1 = -1.0 if q & 2 else 1.0
+        assert np.max(np.abs(a - s0 * (np.cos(x) - np.sin(x)))) <= 3e-16
+        assert np.max(np.abs(b - s1 * (np.cos(x) + np.sin(x)))) <= 3e-16
+        np.testing.assert_allclose(np.float64(a * a + b * b), 2.0, rtol=0, atol=1e-15)     # on the circle of radius sqrt2

@@ -86,7 +86,7 @@ if __name__ == "__main__":
         print("sin S deg", deg, "abs err:", mp.nstr(max_err(S, c, 0, q, lambda z: mp.sqrt(z)), 5))
         c = cheb_fit(C, 0, q, deg)
         print("cos C deg", deg, "abs err:", mp.nstr(max_err(C, c, 0, q, lambda z: z), 5))
-    show("SIN_S (deg 6 in z: the 7 coefficients of sincos_quarter)", cheb_fit(S, 0, q, 6))
+    show("SIN_S (deg 6 in z: the 7 coefficients of cossin_diag)", cheb_fit(S, 0, q, 6))
     show("COS_C (deg 6 in z)", cheb_fit(C, 0, q, 6))
     print("ln2_hi", float.hex(0.6931471803691238), "ln2_lo", float(mp.log(2) - mp.mpf(0.6931471803691238)).hex())
     print("log2e", float(1 / mp.log(2)).hex())

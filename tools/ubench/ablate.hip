@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             xv += sqrt_pos(e + e); q += mantissa_1_2(r[2], r[3]);
         } else if (MODE == 5) {  // philox + quarter-turn sincos
             philox_draw(seed, 0, p, t, r);
-            double sn, cs; sincos_quarter(r[2] & 3u, mantissa_1_2(r[2], r[3]) - 1.5, sn, cs);
+            double sn, cs; cossin_diag(r[2], mantissa_1_2(r[2], r[3]) - 1.5, cs, sn);
             xv += sn + mantissa_1_2(r[0], r[1]); q += cs;
         } else if (MODE == 6) {  // exp only
             L += 1e-3; s = exp_fast(L); xv += s;

@@ -21,7 +21,7 @@ __global__ void acc_kernel(const double *x, double *out, int n, int what)
     case 3: { double a = neg_log(v), b = -log(v); r = fabs(a - b) / fabs(b); } break;
     case 4: { double a = sqrt_pos(v), b = sqrt(v); r = fabs(a - b) / fabs(b); } break;
     case 5: { double a = rcp_fast(v), b = 1.0 / v; r = fabs(a - b) / fabs(b); } break;
-    case 6: { double s, c, s2, c2; sincos_quarter(0, v, s, c); sincospi(0.5 * v, &s2, &c2); r = fmax(fabs(s - s2), fabs(c - c2)); } break;
+    case 6: { double a, b, s2, c2; cossin_diag(0, v, a, b); sincospi(0.5 * v, &s2, &c2); r = fmax(fabs(a - (c2 - s2)), fabs(b - (c2 + s2))); } break;
     case 7: { double y = __builtin_amdgcn_sqrt(v); r = fabs(y * y / v - 1.0) * 0.5; } break;      // v_sqrt_f64 rel err
     }
     out[i] = r;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void time_kernel(double *out, double seed, int
         if (WHAT == 6) acc += 1.0 / v;
         if (WHAT == 7) acc += rcp_fast(v);
         if (WHAT == 8) { double s, c; sincospi(v, &s, &c); acc += s + c; }
-        if (WHAT == 9) { double s, c; sincos_quarter(i & 3, v - 0.5, s, c); acc += s + c; }
+        if (WHAT == 9) { double s, c; cossin_diag(i & 3, v - 0.5, c, s); acc += s + c; }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -70,7 +70,7 @@ int main()
         {"v_sqrt_f64 rel err", 7, 1e-6, 80, true},
         {"exp_fast vs OCML exp rel, x in [-20,20]", 2, -20, 20, false}, {"neg_log vs OCML rel, u in (0,1)", 3, 1e-16, 1, true},
         {"sqrt_pos vs OCML rel", 4, 1e-12, 80, true}, {"rcp_fast vs IEEE div rel", 5, 0.01, 100, true},
-        {"sincos_quarter vs OCML sincospi abs", 6, -0.5, 0.5, false}};
+        {"cossin_diag vs OCML sincospi abs", 6, -0.5, 0.5, false}};
     for (auto &t : tests) {
         for (int i = 0; i < n; ++i) {
             double u = (g() >> 11) * 0x1.0p-53;
@@ -83,7 +83,7 @@ int main()
         printf("%-45s max %.3e  (= 2^%.1f)\n", t.name, mx, std::log2(mx));
     }
     const int blocks = 256 * 8, iters = 4096;
-    const char *names[] = {"OCML exp", "exp_fast", "OCML log", "neg_log", "OCML sqrt", "sqrt_pos", "IEEE div", "rcp_fast", "OCML sincospi", "sincos_quarter"};
+    const char *names[] = {"OCML exp", "exp_fast", "OCML log", "neg_log", "OCML sqrt", "sqrt_pos", "IEEE div", "rcp_fast", "OCML sincospi", "cossin_diag"};
     float ms[10] = {timeit<0>(dout, blocks, iters), timeit<1>(dout, blocks, iters), timeit<2>(dout, blocks, iters), timeit<3>(dout, blocks, iters),
                     timeit<4>(dout, blocks, iters), timeit<5>(dout, blocks, iters), timeit<6>(dout, blocks, iters), timeit<7>(dout, blocks, iters),
                     timeit<8>(dout, blocks, iters), timeit<9>(dout, blocks, iters)};
