@@ -195,7 +195,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         s = sigma[p];
         q = qvar[p];
         double L = log(s);                                                                      // :1039
-        double s2 = s * s, acc = 0.0;
+        double s2 = s * s, acc = 0.0, xacc = 0.0;
         const double s2_start = s2;
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
         const int quarter = (nb_steps + 3) >> 2;
@@ -207,9 +207,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
             }
             double z0, z1;
             draw_normals(lane, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-            logsv_step_acc(c, xv, L, s, s2, acc, z0, z1, exp_of);
+            logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of);
         }
-        logsv_fold_acc(c, xv, q, acc, s2_start, s2);
+        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s2);
         x[p] = xv;
         sigma[p] = s;
         qvar[p] = q;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         if (active) {
             const LogsvFast c = cs.c[i];
             double L = log(s);                                                                  // :1039
-            double s2 = s * s, acc = 0.0;
+            double s2 = s * s, acc = 0.0, xacc = 0.0;
             const double s2_start = s2;
             for (int t = 0; t < nb; ++t) {
                 if (tg + t == next_stage_t) {              // wave-uniform
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                 }
                 double z0, z1;
                 draw_normals(lane, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
-                logsv_step_acc(c, xv, L, s, s2, acc, z0, z1, exp_of);
+                logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of);
             }
-            logsv_fold_acc(c, xv, q, acc, s2_start, s2);
+            logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s2);
         }
         tg += nb;
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,

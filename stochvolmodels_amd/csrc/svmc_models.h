@@ -113,17 +113,17 @@ __device__ __forceinline__ void logsv_step_fast(const LogsvFast &f, double &x, d
 
 // The same step with the two running sums of sigma^2 (the drift of x and the quadratic variance) replaced by ONE
 // accumulator acc = sum_{t=1..T} sigma_t^2; the caller folds it in where x and qvar are needed (logsv_fold_acc):
-//     x_T    = x_0 + sum B sigma_t z0_t + ahA (acc + sigma_0^2 - sigma_T^2)        [= ahA sum_{t=0..T-1} sigma_t^2]
+//     x_T    = x_0 + B xacc + ahA (acc + sigma_0^2 - sigma_T^2),  xacc = sum_t sigma_t z0_t
 //     qvar_T = qvar_0 + hA (2 acc + sigma_0^2 - sigma_T^2)                          [= hA sum (sigma_t^2 + sigma_{t+1}^2)]
 // and L is advanced by single FMAs (no constant has to be moved into a vector register): 9 arithmetic instructions
 // around the exp and the reciprocal instead of 12.  Identical in exact arithmetic; rounding differs at 1e-16.
 template <class Exp>
-__device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &x, double &L, double &sigma, double &s2,
+__device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc, double &L, double &sigma, double &s2,
                                                double &acc, double z0, double z1, Exp &&exp_of)
 {
     const double s = sigma;
     const double y = rcp_1n(s);
-    x = fma(f.B * s, z0, x);
+    xacc = fma(s, z0, xacc);                      // sum sigma_t z0_t; the factor B = eta sqrt(dt) is applied in the fold
     L = fma(f.c2, s, L);
     L = fma(f.c1, y, L);
     L = L + f.c3;
@@ -137,9 +137,10 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &x, do
 
 // fold the accumulator of logsv_step_acc into x and qvar (s2_start = sigma^2 when acc was last zero); a path whose
 // sigma overflowed keeps the reference's outcome (x -> -+inf, qvar -> inf) instead of inf - inf
-__device__ __forceinline__ void logsv_fold_acc(const LogsvFast &f, double &x, double &qvar, double acc, double s2_start,
-                                               double s2_now)
+__device__ __forceinline__ void logsv_fold_acc(const LogsvFast &f, double &x, double &qvar, double xacc, double acc,
+                                               double s2_start, double s2_now)
 {
+    x = fma(f.B, xacc, x);
     const double tail = s2_start - s2_now;
     const bool finite = acc < __builtin_huge_val();
     const double d = finite ? acc + tail : acc;
