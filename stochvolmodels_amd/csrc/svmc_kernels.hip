@@ -584,6 +584,8 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         v = var[p];
         q = qvar[p];
         const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
+        const HestonEulerFast ef = make_heston_euler_fast(c);
+        double xacc = 0.0, vacc = 0.0;
         for (int t = 0; t < nb_steps; ++t) {
             const uint32_t step = step_offset + static_cast<uint32_t>(t);
             double w0, w1;
@@ -593,9 +595,10 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
                 heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
             } else {
                 draw_normals(lane, step, tab, w0, w1);
-                heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+                heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);
             }
         }
+        if (SCHEME != SVMC_HESTON_QE) heston_fold_acc(ef, xv, q, xacc, vacc);
         x[p] = xv;
         var[p] = v;
         qvar[p] = q;
@@ -637,6 +640,8 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
         if (active) {
             const HestonConsts c = cs.c[i];
             const QeConsts qc = cs.qc[i];
+            const HestonEulerFast ef = make_heston_euler_fast(c);
+            double xacc = 0.0, vacc = 0.0;
             for (int t = 0; t < nb; ++t) {
                 double w0, w1;
                 if (SCHEME == SVMC_HESTON_QE) {
@@ -645,9 +650,10 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
                     heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
                 } else {
                     draw_normals(lane, step + static_cast<uint32_t>(t), tab, w0, w1);
-                    heston_euler_step(c, xv, v, q, c.sdt * w0, c.sdt * w1);
+                    heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);
                 }
             }
+            if (SCHEME != SVMC_HESTON_QE) heston_fold_acc(ef, xv, q, xacc, vacc);
         }
         step += static_cast<uint32_t>(nb);
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,

@@ -179,6 +179,45 @@ __device__ __forceinline__ void heston_euler_step(const HestonConsts &c, double 
     var = (vn > 1e-4) ? vn : ((vn != vn) ? vn : 1e-4);                  // np.maximum(v, 1e-4)     :379
 }
 
+// The same Euler step for the issue-bound on-device-RNG kernels: the drift of x and the quadratic variance are both
+// dt * sum v_t, so ONE accumulator serves both (folded in by heston_fold_acc), x accumulates sum sqrt(v_t) z0_t with
+// the factor sqrt(dt) applied at the fold, and the variance update uses host-premultiplied constants.  z0, z1 are
+// UNSCALED N(0,1).  Identical in exact arithmetic to heston_euler_step, floor included.
+struct HestonEulerFast {
+    double dt, sdt, one_m_kdt, ktdt, a0, a1;   // 1 - kappa dt, kappa theta dt, volvol sqrt(dt) rho, volvol sqrt(dt) rho_1
+};
+
+__host__ __device__ inline HestonEulerFast make_heston_euler_fast(const HestonConsts &c)
+{
+    HestonEulerFast f;
+    f.dt = c.dt;
+    f.sdt = c.sdt;
+    f.one_m_kdt = 1.0 - c.kappa * c.dt;
+    f.ktdt = c.kappa * c.theta * c.dt;
+    f.a0 = c.volvol * c.sdt * c.rho;
+    f.a1 = c.volvol * c.sdt * c.rho_1;
+    return f;
+}
+
+__device__ __forceinline__ void heston_euler_step_acc(const HestonEulerFast &f, double &xacc, double &var, double &vacc,
+                                                      double z0, double z1)
+{
+    const double v = var;
+    const double s = sqrt_pos0(v);
+    vacc = vacc + v;
+    xacc = fma(s, z0, xacc);
+    const double m = fma(f.a1, z1, f.a0 * z0);
+    const double vn = fma(s, m, fma(v, f.one_m_kdt, f.ktdt));
+    var = (vn > 1e-4) ? vn : ((vn != vn) ? vn : 1e-4);                  // np.maximum(v, 1e-4)     :379
+}
+
+__device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double &x, double &qvar, double xacc, double vacc)
+{
+    const double q = f.dt * vacc;
+    x = fma(f.sdt, xacc, fma(-0.5, q, x));
+    qvar = qvar + q;
+}
+
 // ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------
 struct QeConsts {
     double dt, theta, E, c1, c2, K1, K2, K3, K4, A, K0_plain, K13;
