@@ -67,11 +67,25 @@ class TorchComm:
             self._bufs[key] = t
         return t.data_ptr(), t
 
+    def _stream_ordered(self, engine, handle) -> bool:
+        """True when libsvmc's launches and the collective are ordered by the stream alone: the engine launches on
+        the very stream torch regards as current on that device (the default stream, unless someone changed either).
+        torch.distributed then does what it does for torch's own kernels -- the collective waits for the prior work
+        of the current stream and the current stream waits for the collective -- and no host synchronisation is
+        needed.  SVMC_DIST_STRICT_SYNC=1 forces the host synchronisations regardless."""
+        if not handle.is_cuda or os.environ.get("SVMC_DIST_STRICT_SYNC") == "1":
+            return False
+        mine = getattr(engine, "stream", None)
+        mine = int(getattr(mine, "value", mine) or 0)
+        return int(self._torch.cuda.current_stream(handle.device).cuda_stream) == mine
+
     def all_reduce_sum(self, engine, handle) -> None:
-        engine.synchronize()                       # svmc kernels that wrote the buffer are complete
         handle = handle.view(-1)
+        ordered = self._stream_ordered(engine, handle)
+        if not ordered:
+            engine.synchronize()                   # svmc kernels that wrote the buffer are complete
         self._dist.all_reduce(handle, op=self._dist.ReduceOp.SUM, group=self.group)
-        if handle.is_cuda:
+        if handle.is_cuda and not ordered:
             self._torch.cuda.synchronize(handle.device)   # reduced values visible to the next svmc kernels
 
     def to_host(self, engine, ptr, handle, n: int):
