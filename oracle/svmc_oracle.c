@@ -293,7 +293,7 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  *   r0..r3 = philox(ctr, key)
  *   u1 = ((r0 | r1<<32) >> 12) * 2^-52 + 2^-53      in (0,1), exact in fp64
  *   rr = ((r2 | r3<<32) >> 12) * 2^-52 - 1/2        in [-1/2, 1/2), exact in fp64
- *   q  = r2 & 3
+ *   s0, s1 = signs from r2 & 1, r2 & 2
  *   stream 0:  R = sqrt(-ln u1);  x = (pi/2) rr;  w0 = s0 R (cos x - sin x);  w1 = s1 R (cos x + sin x);
  *              s0 = -1 if r2 & 1, s1 = -1 if r2 & 2   (= sqrt(-2 ln u1) (s0 cos, s1 sin)(x + pi/4))
  *   stream 1:  uniform = u1

@@ -244,8 +244,8 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     return c;
 }
 
-// z0 drives the log-price, z1 the quadratic branch; the uniform of the exponential branch is drawn lazily
-// (draw_u() is only evaluated by waves that have a lane in that branch).  Quotients are reciprocal + one Newton
+// z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential branch (the
+// streamed kernel loads it only in waves that have a lane there; the on-device draw gets it from the same Philox call).  Quotients are reciprocal + one Newton
 // step (2^-48: far inside the 1e-9 the parity tests state), logs go through the LDS table (absolute accuracy
 // 1e-19 on arguments near 1, which is what the martingale correction feeds it), sqrt is svmc_math.h's; the
 // arithmetic order is the CPU twin's.

@@ -161,7 +161,7 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_
 }
 
 // stream 4 (Heston QE): the Box-Muller pair AND the uniform of the exponential branch from ONE Philox call.
-// u1 and the angle keep 42 mantissa bits each (r1 / r3 + the top 10 bits of r0 / r2), the quadrant is r2 & 3, and
+// u1 and the angle keep 42 mantissa bits each (r1 / r3 + the top 10 bits of r0 / r2), the two direction signs are r2 & 1 and r2 & 2, and
 // the 32 bits left over (r0[21:0] : r2[11:2]) make u = (k + 0.5) 2^-32 -- exact in fp64, so the CPU twin gets the
 // same bits.  42-bit radii reach 7.6 sigma; a 32-bit uniform truncates the exponential branch at e^-22.
 __device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
