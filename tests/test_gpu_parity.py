@@ -1168,3 +1168,21 @@ def test_price_slice_and_vanilla_consistent_with_chain(sv):
         assert np.all(np.isfinite(iv)) and np.all(iv > 0)
         p1, v1 = pricer.price_vanilla(params=params, ttm=0.25, forward=1.0, strike=1.0, optiontype="C", discfactor=0.99)
         np.testing.assert_allclose([p1, v1], [pr[1], iv[1]], rtol=1e-12)
+
+
+def test_reference_quickstart_known_answers(sv):
+    """the reference's offline quickstart (examples/getting_started/quickstart.py:11-47), statement for statement on
+    this package, against the four numbers it asserts itself (rtol 5e-6): prices AND Black implied vols -- the only
+    published anchors for the price -> vol inversion the reference delegates to a third-party package"""
+    params = sv.LogSvParams(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0)
+    pricer = sv.LogSVPricer()
+    vanilla_price, vanilla_ivol = pricer.price_vanilla(params=params, ttm=0.25, forward=1.0, strike=1.0, optiontype="C")
+    chain = sv.OptionChain.get_uniform_chain(ttms=np.array([0.25, 0.5]), ids=np.array(["3m", "6m"]),
+                                             forwards=np.array([1.0, 1.0]), strikes=np.array([0.8, 0.9, 1.0, 1.1, 1.2]))
+    chain_prices, chain_ivols = pricer.compute_chain_prices_with_vols(option_chain=chain, params=params)
+    assert all(np.all(np.isfinite(v)) for v in (*chain_prices, *chain_ivols))
+    assert [v.shape for v in chain_prices] == [(5,), (5,)] and [v.shape for v in chain_ivols] == [(5,), (5,)]
+    np.testing.assert_allclose(vanilla_price, 0.197331, rtol=5.0e-6, atol=1.0e-8)
+    np.testing.assert_allclose(vanilla_ivol, 0.999577, rtol=5.0e-6, atol=1.0e-8)
+    np.testing.assert_allclose(chain_prices[1][2], 0.275202, rtol=5.0e-6, atol=1.0e-8)
+    np.testing.assert_allclose(chain_ivols[1][2], 0.995757, rtol=5.0e-6, atol=1.0e-8)
