@@ -166,7 +166,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -238,7 +238,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(nb, args.cpu_sample_paths, P, strikes, types)
             result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nb, P)
-    if world > 1:
+    if torch.distributed.is_initialized():     # world > 1, or a lone rank under SVMC_DIST_SINGLE_RANK_GROUP=1
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -109,9 +109,13 @@ def init_from_env(backend: Optional[str] = None):
     """one process per GPU launched by torch.distributed.run: bind LOCAL_RANK's GPU, create the process
     group over RCCL and make it the default communicator of the chain pricers."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("SVMC_DIST_SINGLE_RANK_GROUP") != "1":
         set_default_comm(None)
         return get_default_comm()
+    # SVMC_DIST_SINGLE_RANK_GROUP=1 builds the process group for a lone rank too, so that a 1-GPU box runs the very
+    # code of the N>1 path (RCCL communicator, torch-owned reduction buffers, stream-ordered collectives)
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("RANK", "0")
     # the host driver of these boxes only supports dmabuf IPC; RCCL's cross-process handles need this before HIP starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch

@@ -17,6 +17,9 @@ def main(out_path):
     from stochvolmodels_amd.pricers import heston_pricer, logsv_pricer
 
     comm = svdist.init_from_env()
+    if os.environ.get("SVMC_EXPECT_BACKEND"):
+        assert dist.is_initialized() and dist.get_backend() == os.environ["SVMC_EXPECT_BACKEND"], "group not built"
+        assert type(comm).__name__ == "TorchComm"
     res = {}
     pr, sd = logsv_pricer.logsv_mc_chain_pricer(**LOGSV_CASE)
     res["logsv_prices"], res["logsv_stderrs"] = np.stack(pr), np.stack(sd)

@@ -436,6 +436,35 @@ def test_ranks_share_one_gpu(oracle, tmp_path, world):
             np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} rank {r}/{world}")
 
 
+def test_rccl_group_on_one_rank(oracle, tmp_path):
+    """the RCCL leg of the N>1 path on a 1-GPU box: a lone rank builds the "nccl" process group
+    (SVMC_DIST_SINGLE_RANK_GROUP=1) and prices through TorchComm -- torch-owned reduction buffers written by
+    libsvmc's kernels, all-reduces over RCCL ordered by the stream alone -- and must return the single-process
+    oracle result; a second run with the host synchronisations forced must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from test_dist_gloo import _expected
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = _expected(oracle)
+    runs = []
+    for tag, strict in (("ordered", "0"), ("strict", "1")):
+        out = str(tmp_path / tag)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                   SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_EXPECT_BACKEND="nccl", SVMC_DIST_STRICT_SYNC=strict,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("SVMC_DIST_BACKEND", None)
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_worker.py"), out], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()
+        got = np.load(out + ".rank0.npz")
+        for key in got.files:
+            np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} ({tag})")
+        runs.append({k: got[k] for k in got.files})
+    for key in runs[0]:
+        np.testing.assert_array_equal(runs[0][key], runs[1][key], err_msg=key)
+
+
 def test_vol_paths(sv, oracle, golden):
     """simulate_vol_paths: reference outputs on supplied brownians; on-device draw vs the CPU twin; the reference's
     own shape / first-row / measure checks (tests/test_logsv_characterization.py:638-673)"""
