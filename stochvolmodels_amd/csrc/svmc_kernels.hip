@@ -44,8 +44,8 @@ __global__ __launch_bounds__(BLOCK) void fill_normals_kernel(double *__restrict_
                                                              uint32_t c3, uint64_t path_offset,
                                                              uint32_t step_offset)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     const uint64_t gp = path_offset + p;
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
 {
-    __shared__ LogTabEntry s_tab[256];
+    __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[64];
-    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials)
 {
-    __shared__ LogTabEntry s_tab[256];
+    __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[64];
-    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -399,8 +399,8 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
                                                                 const double *__restrict__ brownians, size_t ldb,
                                                                 uint64_t seed, uint32_t c3, uint64_t path_offset)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double s = v0, L = log(v0);
@@ -527,9 +527,9 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
                                                             uint32_t c3, uint64_t path_offset, uint32_t step_offset,
                                                             int from_origin, SliceOut so)
 {
-    __shared__ LogTabEntry s_tab[256];
+    __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[64];
-    const LogTabEntry *tab = stage_tables(s_tab, s_exp);
+    const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double a) { return exp_tab(a, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
                                                            uint32_t c3, uint64_t path_offset,
                                                            uint32_t step_offset, SliceOut so)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
             if (SCHEME == SVMC_HESTON_QE) {
                 double u;
                 draw_qe(lane, step, tab, w0, w1, u);
-                heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
+                heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
             } else {
                 draw_normals(lane, step, tab, w0, w1);
                 heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
                                                                  double *__restrict__ x_snap, double *__restrict__ q_snap,
                                                                  double *__restrict__ partials)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
                 if (SCHEME == SVMC_HESTON_QE) {
                     double u;
                     draw_qe(lane, step + static_cast<uint32_t>(t), tab, w0, w1, u);
-                    heston_qe_step(qc, tab, xv, v, q, w0, w1, [&]() { return u; });
+                    heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
                 } else {
                     draw_normals(lane, step + static_cast<uint32_t>(t), tab, w0, w1);
                     heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);

@@ -207,7 +207,7 @@ SVMC_HD double neg_log(double u)
 // 6-term Taylor polynomial -- no reciprocal and a 5-step Horner chain instead of the divide + 7-term polynomial of
 // neg_log().  The interval containing m = 1 has c = 1 exactly, keeping full relative accuracy as u -> 1.
 // On the device `tab` is a 4 KB LDS copy: a 16-byte ds_read per call, in the LDS pipe beside the VALU stream.
-struct LogTabEntry {
+struct alignas(16) LogTabEntry {
     double inv_c, log_c;
 };
 
@@ -260,6 +260,47 @@ SVMC_HD void cossin_diag(uint32_t q, double r, double &a, double &b)
     const double bm = fma(ps, r, c0);             // cos + sin = sqrt2 sin(x + pi/4)   in [0, sqrt2)
     a = bits_to_double(double_lo(am), double_hi(am) ^ (q << 31));
     b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((q << 30) & 0x80000000u));
+}
+
+// The same direction from the raw random words and a table: the angle's 52 mantissa bits are hi[31:0] : lo[31:12]
+// (r = 1.m - 3/2 in [-1/2, 1/2)); the top 8 bits pick the interval j with midpoint r_j = (j + 1/2)/256 - 1/2 and the
+// other 44 give d = r - r_j exactly, |d| <= 2^-9.  With {A_j, B_j} = {cos - sin, cos + sin}((pi/2) r_j) from the table
+// (4 KB, staged in LDS on the device: one ds_read_b128 beside the VALU stream),
+//     a = A_j cos y - B_j sin y,   b = B_j cos y + A_j sin y,   y = (pi/2) d,  |y| <= 0.0031,
+// where sin y needs three Taylor terms and cos y three (next terms 2e-19 / 1e-18 relative): 10 fp64 instructions
+// instead of the 16 of the two degree-13/14 polynomials.  Signs: s0 = -1 if sgn & 1, s1 = -1 if sgn & 2; a > 0 and
+// b >= 0 before the signs go in, so s0 is a plain OR of the sign bit (one v_lshl_or_b32).  Absolute accuracy 5e-16.
+struct alignas(16) DiagTabEntry {
+    double a, b;
+};
+
+SVMC_HD void cossin_diag_tab(uint32_t sgn, uint32_t lo, uint32_t hi, const DiagTabEntry *tab, double &a, double &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep hi a plain register value: left to itself the compiler re-derives its bit fields from a split of the
+    // Philox multiply that produced it (one more 32-bit multiply per step)
+    asm volatile("" : "+v"(hi));
+    const DiagTabEntry e = tab[hi >> 24];
+    const uint32_t mhi = __builtin_amdgcn_alignbit(0x3ffu, hi, 12) & 0xfff00fffu;
+    const uint32_t mlo = __builtin_amdgcn_alignbit(hi, lo, 12);
+#else
+    const DiagTabEntry e = tab[hi >> 24];
+    const uint32_t mhi = (0x3ff00000u | (hi >> 12)) & 0xfff00fffu;
+    const uint32_t mlo = (hi << 20) | (lo >> 12);
+#endif
+    const double d = bits_to_double(mlo, mhi) - (1.0 + 0x1.0p-9);
+    const double z = d * d;
+    double ps = 0x1.466bc6775aae2p-4;              //  (pi/2)^5 / 120
+    ps = fma_k(ps, z, -0x1.4abbce625be53p-1);      // -(pi/2)^3 / 6
+    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);       //   pi/2
+    const double sn = d * ps;                      // sin y
+    double pc = 0x1.03c1f081b5ac4p-2;              //  (pi/2)^4 / 24
+    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);      // -(pi/2)^2 / 2
+    const double cs = fma_k(pc, z, 1.0);           // cos y
+    const double am = fma(-e.b, sn, e.a * cs);     // in (0, sqrt2]
+    const double bm = fma(e.a, sn, e.b * cs);      // in [0, sqrt2)
+    a = bits_to_double(double_lo(am), double_hi(am) | (sgn << 31));
+    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((sgn << 30) & 0x80000000u));
 }
 
 }  // namespace svmc

@@ -24,9 +24,24 @@
 
 namespace svmc {
 
-// the 4 KB table of neg_log_tab(): constant memory -> LDS once per block (blocks are 256 threads = 256 entries)
+// The tables of the draw, constant memory -> LDS once per block: 4 KB for neg_log_tab() and 4 KB for cossin_diag_tab()
+// (blocks are 256 threads = one entry of each per thread); the stepping kernels that call exp_tab() stage its 512 B
+// with them behind the same barrier.
 __constant__ LogTabEntry g_log_table[256] = {SVMC_LOG_TABLE_INIT};
+__constant__ DiagTabEntry g_diag_table[256] = {SVMC_DIAG_TABLE_INIT};
+__constant__ double g_exp_table[64] = {SVMC_EXP_TABLE_INIT};
 
+struct RngTables {
+    const LogTabEntry *log;
+    const DiagTabEntry *diag;
+};
+
+struct RngTablesLds {
+    LogTabEntry log[256];
+    DiagTabEntry diag[256];
+};
+
+// the log table alone (the streamed Heston QE kernel: its martingale correction takes logs, it draws nothing)
 __device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)[256])
 {
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds[i] = g_log_table[i];
@@ -34,15 +49,25 @@ __device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)
     return lds;
 }
 
-// the 512 B table of exp_tab(), staged with the log table (one barrier for both)
-__constant__ double g_exp_table[64] = {SVMC_EXP_TABLE_INIT};
-
-__device__ __forceinline__ const LogTabEntry *stage_tables(LogTabEntry (&lds_log)[256], double (&lds_exp)[64])
+__device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
 {
-    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_log[i] = g_log_table[i];
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
+        lds.log[i] = g_log_table[i];
+        lds.diag[i] = g_diag_table[i];
+    }
+    __syncthreads();
+    return RngTables{lds.log, lds.diag};
+}
+
+__device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&lds_exp)[64])
+{
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
+        lds.log[i] = g_log_table[i];
+        lds.diag[i] = g_diag_table[i];
+    }
     for (unsigned i = threadIdx.x; i < 64u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
     __syncthreads();
-    return lds_log;
+    return RngTables{lds.log, lds.diag};
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -145,17 +170,13 @@ __device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t
                   static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
 }
 
-// stream 0: Box-Muller pair of UNSCALED N(0,1)
-__device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
-                                             const LogTabEntry *tab, double &w0, double &w1)
+// the pair from the four words of one Philox call: radius from r1:r0, direction from r3:r2 (+ the sign bits r2 & 3)
+__device__ __forceinline__ void normals_from_words(const uint32_t (&r)[4], const RngTables &t, double &w0, double &w1)
 {
-    uint32_t r[4];
-    philox_draw(seed, c3, path, step, r);
     const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
-    const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
-    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    const double R = sqrt_pos(neg_log_tab(u1, t.log));     // sqrt(-ln u1): the sqrt2 lives in (a, b)
     double a, b;
-    cossin_diag(r[2], rr, a, b);
+    cossin_diag_tab(r[2], r[2], r[3], t.diag, a, b);
     w0 = R * a;
     w1 = R * b;
 }
@@ -164,52 +185,51 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_
 // u1 and the angle keep 42 mantissa bits each (r1 / r3 + the top 10 bits of r0 / r2), the two direction signs are r2 & 1 and r2 & 2, and
 // the 32 bits left over (r0[21:0] : r2[11:2]) make u = (k + 0.5) 2^-32 -- exact in fp64, so the CPU twin gets the
 // same bits.  42-bit radii reach 7.6 sigma; a 32-bit uniform truncates the exponential branch at e^-22.
-__device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
-                                        const LogTabEntry *tab, double &w0, double &w1, double &u)
+__device__ __forceinline__ void qe_from_words(const uint32_t (&r)[4], const RngTables &t, double &w0, double &w1, double &u)
 {
-    uint32_t r[4];
-    philox_draw(seed, c3 | 4u, path, step, r);
     const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
-    const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
     const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    const double R = sqrt_pos(neg_log_tab(u1, t.log));
     double a, b;
-    cossin_diag(r[2], rr, a, b);
+    cossin_diag_tab(r[2], r[2] & 0xFFC00000u, r[3], t.diag, a, b);
     w0 = R * a;
     w1 = R * b;
 }
 
+// stream 0: Box-Muller pair of UNSCALED N(0,1)
+__device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
+                                             const RngTables &t, double &w0, double &w1)
+{
+    uint32_t r[4];
+    philox_draw(seed, c3, path, step, r);
+    normals_from_words(r, t, w0, w1);
+}
+
+__device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
+                                        const RngTables &t, double &w0, double &w1, double &u)
+{
+    uint32_t r[4];
+    philox_draw(seed, c3 | 4u, path, step, r);
+    qe_from_words(r, t, w0, w1, u);
+}
+
 // the same pair from a prepared lane state (philox_prepare outside the time loop)
-__device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t step, const LogTabEntry *tab, double &w0,
+__device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
                                              double &w1)
 {
     uint32_t r[4];
     philox_draw(lane, step, r);
-    const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
-    const double rr = mantissa_1_2(r[2], r[3]) - 1.5;
-    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
-    double a, b;
-    cossin_diag(r[2], rr, a, b);
-    w0 = R * a;
-    w1 = R * b;
+    normals_from_words(r, t, w0, w1);
 }
 
 // draw_qe from a prepared lane state (prepare it with the stream-4 tag: philox_prepare(seed, c3 | 4u, path))
-__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const LogTabEntry *tab, double &w0,
+__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
                                         double &w1, double &u)
 {
     uint32_t r[4];
     philox_draw(lane, step, r);
-    const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
-    const double rr = mantissa_1_2(r[2] & 0xFFC00000u, r[3]) - 1.5;
-    const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
-    u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double R = sqrt_pos(neg_log_tab(u1, tab));       // sqrt(-ln u1): the sqrt2 lives in (a, b)
-    double a, b;
-    cossin_diag(r[2], rr, a, b);
-    w0 = R * a;
-    w1 = R * b;
+    qe_from_words(r, t, w0, w1, u);
 }
 
 // stream 1: one uniform in (0,1)

@@ -4,6 +4,7 @@
 #include "svmc_math.h"
 static const svmc::LogTabEntry LOG_TAB[256] = {SVMC_LOG_TABLE_INIT};
 static const double EXP_TAB[64] = {SVMC_EXP_TABLE_INIT};
+static const svmc::DiagTabEntry DIAG_TAB[256] = {SVMC_DIAG_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
 void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_tab(x[i], EXP_TAB); }
@@ -14,5 +15,10 @@ void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n;
 void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)
 {
     for (size_t i = 0; i < n; ++i) svmc::cossin_diag(q[i], r[i], c[i], s[i]);   // c <- a = s0 (cos - sin), s <- b = s1 (cos + sin)
+}
+// the table-assisted direction from raw words: sgn carries the two sign bits, hi:lo the 52 angle bits (lo[11:0] unused)
+void probe_diag_tab(const uint32_t *sgn, const uint32_t *lo, const uint32_t *hi, double *a, double *b, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) svmc::cossin_diag_tab(sgn[i], lo[i], hi[i], DIAG_TAB, a[i], b[i]);
 }
 }
