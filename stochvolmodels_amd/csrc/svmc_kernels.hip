@@ -691,7 +691,7 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
                                                             const double *__restrict__ Z1,
                                                             const double *__restrict__ U, size_t ldw)
 {
-    __shared__ LogTabEntry s_tab[256];
+    __shared__ LogTabEntry s_tab[512];
     const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;

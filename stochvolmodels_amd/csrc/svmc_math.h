@@ -129,6 +129,17 @@ SVMC_HD double sqrt_pos(double t)
     return fma(d, h, g);                  // h is only 2^-24 accurate: its error enters at 2^-71
 }
 
+// sqrt(t) to 2^-47: the Goldschmidt step alone (4 instructions instead of 6).  The radius of the Box-Muller pair:
+// the normals carry 7e-15 relative, the accuracy class of the step's reciprocal (rcp_1n).
+SVMC_HD double sqrt_pos_1g(double t)
+{
+    const double y = rsq_seed(t);
+    const double g = t * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    return fma(g, r, g);
+}
+
 // sqrt(t) for t >= 0 including exact zero (the rsq seed of 0 is +inf): Heston's variance before its first floor.
 SVMC_HD double sqrt_pos0(double t)
 {
@@ -202,13 +213,13 @@ SVMC_HD double neg_log(double u)
     return fma(-dk, 0x1.62e42fee00000p-1, -a);      // -(k ln2 + ln m)
 }
 
-// Table-assisted -ln(u), any positive normal u: the top 8 bits of the [sqrt(1/2), sqrt(2)) mantissa pick
-// { fl(1/c_j), -ln fl(1/c_j) } (tools/gen_log_table.py); f = fma(m, 1/c_j, -1) has |f| <= 2^-9, so ln(1+f) is its
-// 6-term Taylor polynomial -- no reciprocal and a 5-step Horner chain instead of the divide + 7-term polynomial of
+// Table-assisted -ln(u), any positive normal u: the top 9 bits of the [sqrt(1/2), sqrt(2)) mantissa pick
+// { fl(1/c_j), ln fl(1/c_j) } (tools/gen_log_table.py); f = fma(m, 1/c_j, -1) has |f| <= 2^-10, so ln(1+f) is
+// f + f^2 P(f) with a cubic P -- no reciprocal and a 3-step Horner chain instead of the divide + 7-term polynomial of
 // neg_log().  The interval containing m = 1 has c = 1 exactly, keeping full relative accuracy as u -> 1.
-// On the device `tab` is a 4 KB LDS copy: a 16-byte ds_read per call, in the LDS pipe beside the VALU stream.
+// On the device `tab` is an 8 KB LDS copy: a 16-byte ds_read per call, in the LDS pipe beside the VALU stream.
 struct alignas(16) LogTabEntry {
-    double inv_c, log_c;
+    double inv_c, neg_log_c;
 };
 
 SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
@@ -217,19 +228,19 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
     hx += 0x3ff00000u - 0x3fe6a09eu;
     const int k = static_cast<int>(hx >> 20) - 0x3ff;
     const uint32_t frac = hx & 0x000fffffu;
-    const LogTabEntry e = tab[frac >> 12];
+    const LogTabEntry e = tab[frac >> 11];
     const double m = bits_to_double(double_lo(u), frac + 0x3fe6a09eu);
     const double dk = static_cast<double>(k);
-    const double f = fma(m, e.inv_c, -1.0);
-    double p = -0x1.5555555555555p-3;              // -1/6
-    p = fma_k(p, f, 0x1.999999999999ap-3);         //  1/5
-    p = fma_k(p, f, -0x1.0000000000000p-2);        // -1/4
-    p = fma_k(p, f, 0x1.5555555555555p-2);         //  1/3
-    p = fma_k(p, f, -0x1.0000000000000p-1);        // -1/2
+    const double f = fma(m, e.inv_c, -1.0);        // |f| <= 2^-10
+    double p = 0x1.9999ac9fdd43ep-3;               // log1p(f) = f + f^2 P(f), P fitted on |f| <= 2^-10 (2e-17 relative)
+    p = fma_k(p, f, -0x1.00000b18fcc98p-2);
+    p = fma_k(p, f, 0x1.5555555555419p-2);
+    p = fma_k(p, f, -0x1.ffffffffffe8fp-2);
     const double r = fma(f * f, p, f);             // log1p(f)
-    const double lg = e.log_c + r;                 // ln(m)
-    const double a = fma(dk, 0x1.a39ef35793c76p-33, lg);
-    return fma(-dk, 0x1.62e42fee00000p-1, -a);
+    const double nl = e.neg_log_c - r;             // -ln(m): with k = 0 and c = 1 this is -log1p(u - 1), relative accuracy kept
+    // one constant for ln2: k ln2 is rounded once (in the fma), and fl(ln2) is off by 2^-55 relative -- at most
+    // 0.1 ULP of any result with k != 0, all of which exceed 0.34
+    return fma(-dk, 0x1.62e42fefa39efp-1, nl);
 }
 
 // The direction of a Box-Muller pair, scaled by sqrt2: with x = (pi/2) r, |r| <= 1/2, returns

@@ -24,10 +24,10 @@
 
 namespace svmc {
 
-// The tables of the draw, constant memory -> LDS once per block: 4 KB for neg_log_tab() and 4 KB for cossin_diag_tab()
-// (blocks are 256 threads = one entry of each per thread); the stepping kernels that call exp_tab() stage its 512 B
+// The tables of the draw, constant memory -> LDS once per block: 8 KB for neg_log_tab() and 4 KB for cossin_diag_tab()
+// (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 512 B
 // with them behind the same barrier.
-__constant__ LogTabEntry g_log_table[256] = {SVMC_LOG_TABLE_INIT};
+__constant__ LogTabEntry g_log_table[512] = {SVMC_LOG_TABLE_INIT};
 __constant__ DiagTabEntry g_diag_table[256] = {SVMC_DIAG_TABLE_INIT};
 __constant__ double g_exp_table[64] = {SVMC_EXP_TABLE_INIT};
 
@@ -37,14 +37,14 @@ struct RngTables {
 };
 
 struct RngTablesLds {
-    LogTabEntry log[256];
+    LogTabEntry log[512];
     DiagTabEntry diag[256];
 };
 
 // the log table alone (the streamed Heston QE kernel: its martingale correction takes logs, it draws nothing)
-__device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)[256])
+__device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)[512])
 {
-    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds[i] = g_log_table[i];
+    for (unsigned i = threadIdx.x; i < 512u; i += blockDim.x) lds[i] = g_log_table[i];
     __syncthreads();
     return lds;
 }
@@ -53,6 +53,7 @@ __device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
 {
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
         lds.log[i] = g_log_table[i];
+        lds.log[i + 256u] = g_log_table[i + 256u];
         lds.diag[i] = g_diag_table[i];
     }
     __syncthreads();
@@ -63,6 +64,7 @@ __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&ld
 {
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
         lds.log[i] = g_log_table[i];
+        lds.log[i + 256u] = g_log_table[i + 256u];
         lds.diag[i] = g_diag_table[i];
     }
     for (unsigned i = threadIdx.x; i < 64u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
@@ -174,7 +176,7 @@ __device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t
 __device__ __forceinline__ void normals_from_words(const uint32_t (&r)[4], const RngTables &t, double &w0, double &w1)
 {
     const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
-    const double R = sqrt_pos(neg_log_tab(u1, t.log));     // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    const double R = sqrt_pos_1g(neg_log_tab(u1, t.log));  // sqrt(-ln u1): the sqrt2 lives in (a, b)
     double a, b;
     cossin_diag_tab(r[2], r[2], r[3], t.diag, a, b);
     w0 = R * a;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void qe_from_words(const uint32_t (&r)[4], const RngT
     const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
     const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
     u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double R = sqrt_pos(neg_log_tab(u1, t.log));
+    const double R = sqrt_pos_1g(neg_log_tab(u1, t.log));
     double a, b;
     cossin_diag_tab(r[2], r[2] & 0xFFC00000u, r[3], t.diag, a, b);
     w0 = R * a;

@@ -2,7 +2,7 @@
 #include <stddef.h>
 #include "svmc_log_table.h"
 #include "svmc_math.h"
-static const svmc::LogTabEntry LOG_TAB[256] = {SVMC_LOG_TABLE_INIT};
+static const svmc::LogTabEntry LOG_TAB[512] = {SVMC_LOG_TABLE_INIT};
 static const double EXP_TAB[64] = {SVMC_EXP_TABLE_INIT};
 static const svmc::DiagTabEntry DIAG_TAB[256] = {SVMC_DIAG_TABLE_INIT};
 extern "C" {
@@ -11,6 +11,7 @@ void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i 
 void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }
 void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log_tab(x[i], LOG_TAB); }
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }
+void probe_sqrt_1g(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos_1g(x[i]); }
 void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
 void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)
 {

@@ -56,8 +56,8 @@ def test_normals_match_oracle_stream(sv, oracle):
     W0 = eng.download(w0p, nb * n).reshape(nb, n)
     W1 = eng.download(w1p, nb * n).reshape(nb, n)
     O0, O1 = oracle.fill_normals(seed, n, nb, call_id=3, path_offset=123456789012, step_offset=11)
-    np.testing.assert_allclose(W0, O0, rtol=0, atol=1e-14)
-    np.testing.assert_allclose(W1, O1, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(W0, O0, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(W1, O1, rtol=0, atol=1e-13)
     eng.close()
 
 
@@ -161,7 +161,7 @@ def test_logsv_reference_test_case(sv, golden):
                                                qvar0=np.zeros(n), theta=p["theta"], kappa1=p["kappa1"],
                                                kappa2=p["kappa2"], beta=p["beta"], volvol=p["volvol"], nb_path=n,
                                                W0=W0, W1=W1, dt=float(g["dt"]))
-    np.testing.assert_allclose(x[:256], g["x_head"], rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(x[:256], g["x_head"], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(s[:256], g["sigma_head"], rtol=1e-11)
     np.testing.assert_allclose(q[:256], g["qvar_head"], rtol=1e-11)
     assert np.all(np.isfinite(x)) and np.all(s > 0) and np.all(q >= 0)
@@ -220,15 +220,15 @@ def test_payoff_reference_known_answers(sv):
                                        discfactor=0.95)
     pay = np.vstack([np.maximum(spots - 1, 0), np.maximum(1 - spots, 0), np.maximum(spots - 1, 0) / spots,
                      np.maximum(1 - spots, 0) / spots])
-    np.testing.assert_allclose(pr, 0.95 * pay.mean(axis=1), atol=1e-14)
-    np.testing.assert_allclose(sd, 0.95 * pay.std(axis=1) / np.sqrt(3), atol=1e-14)
+    np.testing.assert_allclose(pr, 0.95 * pay.mean(axis=1), atol=1e-13)
+    np.testing.assert_allclose(sd, 0.95 * pay.std(axis=1) / np.sqrt(3), atol=1e-13)
     x0 = np.log(np.array([0.75, 0.95, 1.05, 1.25]))
     kw = dict(ttm=1.0, forward=1.0, strikes_ttm=np.array([1.0]), optiontypes_ttm=np.array(["C"]))
     p1, s1 = sv.compute_mc_vars_payoff(x0=x0, sigma0=np.ones(4), qvar0=np.zeros(4), **kw)
     x4 = np.tile(x0, 4)
     p4, s4 = sv.compute_mc_vars_payoff(x0=x4, sigma0=np.ones(16), qvar0=np.zeros(16), **kw)
-    np.testing.assert_allclose(p4, p1, atol=1e-14)
-    np.testing.assert_allclose(s4, s1 / 2.0, atol=1e-14)
+    np.testing.assert_allclose(p4, p1, atol=1e-13)
+    np.testing.assert_allclose(s4, s1 / 2.0, atol=1e-13)
 
 
 def test_payoff_errors(sv):
