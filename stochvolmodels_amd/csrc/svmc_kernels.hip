@@ -184,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
 {
     __shared__ RngTablesLds s_tab;
-    __shared__ double s_exp[64];
+    __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
     double *__restrict__ partials)
 {
     __shared__ RngTablesLds s_tab;
-    __shared__ double s_exp[64];
+    __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
                                                             int from_origin, SliceOut so)
 {
     __shared__ RngTablesLds s_tab;
-    __shared__ double s_exp[64];
+    __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double a) { return exp_tab(a, s_exp); };
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;

@@ -167,22 +167,25 @@ SVMC_HD double exp_fast(double x)
     return ldexp(y, static_cast<int>(n));
 }
 
-// exp(x) with a 64-entry table: x = n ln2/64 + r, n = 64 k + j, |r| <= ln2/128; exp(x) = 2^k T[j] (1 + r + r^2 Q(r)),
-// T[j] = fl(2^(j/64)), Q of degree 3 fitted on the reduced interval (4.4e-18).  15 instructions against exp_fast's 19;
-// the table read goes through the LDS pipe beside the VALU stream.  <= 1.1 ULP (tests/test_math_accuracy.py).
+// exp(x) with a 256-entry table: x = n ln2/256 + r, n = 256 k + j, |r| <= ln2/512; exp(x) = 2^k T[j] (1 + r + r^2 Q(r)),
+// T[j] = fl(2^(j/256)), Q quadratic, fitted on the reduced interval (1e-17).  n comes out of the 1.5 2^52 rounding trick
+// (its integer form is the low word of the biased sum, so no rint / convert) and the reduction uses ONE constant for
+// ln2/256: r is off by n |fl(c) - c|, i.e. 3.4e-17 |x| relative in the result.  The arguments here are
+// log-volatilities: <= 1.3 ULP on |x| <= 1, 2.5 ULP at |x| = 5 (sigma between 0.007 and 150), 2.4e-14 at the ends of
+// the double range (tests/test_math_accuracy.py).  11 instructions, 8 of them fp64 arithmetic, against exp_fast's 19;
+// the table read goes through the LDS pipe beside the VALU stream.
 SVMC_HD double exp_tab(double x, const double *tab)
 {
-    const double n = rint(x * 0x1.71547652b82fep+6);
-    double r = fma(-n, 0x1.62e42fee00000p-7, x);
-    r = fma(-n, 0x1.a39ef35793c76p-39, r);
-    const int ni = static_cast<int>(n);
-    const double t = tab[ni & 63];
-    double q = 0x1.111120af69e26p-7;
-    q = fma_k(q, r, 0x1.55556b3304f80p-5);
-    q = fma_k(q, r, 0x1.5555555554dd4p-3);
-    q = fma_k(q, r, 0x1.ffffffffff57fp-2);
+    const double kf = fma(x, 0x1.71547652b82fep+8, 0x1.8p+52);
+    const int ni = static_cast<int>(double_lo(kf));
+    const double n = kf - 0x1.8p+52;
+    const double r = fma(-n, 0x1.62e42fefa39efp-9, x);
+    const double t = tab[ni & 255];
+    double q = 0x1.55555660ffb24p-5;
+    q = fma_k(q, r, 0x1.555556e6d4e0ep-3);
+    q = fma_k(q, r, 0x1.0000000000000p-1);
     const double p = fma(q, r * r, r);
-    return ldexp(fma(t, p, t), ni >> 6);
+    return ldexp(fma(t, p, t), ni >> 8);
 }
 
 // -ln(u) for any positive normal u (the RNG calls it on (0,1); Heston QE on arguments around 1).  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,

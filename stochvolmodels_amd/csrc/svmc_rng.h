@@ -25,11 +25,11 @@
 namespace svmc {
 
 // The tables of the draw, constant memory -> LDS once per block: 8 KB for neg_log_tab() and 4 KB for cossin_diag_tab()
-// (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 512 B
+// (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 2 KB
 // with them behind the same barrier.
 __constant__ LogTabEntry g_log_table[512] = {SVMC_LOG_TABLE_INIT};
 __constant__ DiagTabEntry g_diag_table[256] = {SVMC_DIAG_TABLE_INIT};
-__constant__ double g_exp_table[64] = {SVMC_EXP_TABLE_INIT};
+__constant__ double g_exp_table[256] = {SVMC_EXP_TABLE_INIT};
 
 struct RngTables {
     const LogTabEntry *log;
@@ -60,14 +60,14 @@ __device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
     return RngTables{lds.log, lds.diag};
 }
 
-__device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&lds_exp)[64])
+__device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&lds_exp)[256])
 {
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
         lds.log[i] = g_log_table[i];
         lds.log[i + 256u] = g_log_table[i + 256u];
         lds.diag[i] = g_diag_table[i];
     }
-    for (unsigned i = threadIdx.x; i < 64u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
     __syncthreads();
     return RngTables{lds.log, lds.diag};
 }

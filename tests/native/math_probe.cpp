@@ -3,7 +3,7 @@
 #include "svmc_log_table.h"
 #include "svmc_math.h"
 static const svmc::LogTabEntry LOG_TAB[512] = {SVMC_LOG_TABLE_INIT};
-static const double EXP_TAB[64] = {SVMC_EXP_TABLE_INIT};
+static const double EXP_TAB[256] = {SVMC_EXP_TABLE_INIT};
 static const svmc::DiagTabEntry DIAG_TAB[256] = {SVMC_DIAG_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }

@@ -52,17 +52,23 @@ def test_exp(probe):
 
 
 def test_exp_table(probe):
-    """exp_tab (64-entry table, degree-3 tail polynomial: the exponential of the issue-bound stepping kernels)"""
+    """exp_tab (256-entry table, quadratic tail, one-constant reduction: the exponential of the issue-bound stepping
+    kernels, whose arguments are log-volatilities).  <= 1.5 ULP on |x| <= 1, <= 3 ULP on |x| <= 5; the one-constant
+    reduction adds 3.4e-17 |x| relative beyond that (2.4e-14 at the ends of the double range)."""
     rng = np.random.default_rng(10)
-    for lo, hi in ((-1, 1), (-30, 30), (-700, 700)):
+    for lo, hi, bound in ((-1, 1, 1.5), (-5, 5, 3.0), (-30, 30, 11.0)):
         x = rng.uniform(lo, hi, N)
-        assert _ulp(_call(probe, "probe_exp_tab", x), np.exp(x.astype(np.longdouble))) <= 1.5
-    x = np.arange(-4096, 4096) * (np.log(2.0) / 64)                 # the table nodes, both sides of every rounding tie
-    for eps in (0.0, 1e-17, -1e-17, 2.7e-3, -2.7e-3):
+        assert _ulp(_call(probe, "probe_exp_tab", x), np.exp(x.astype(np.longdouble))) <= bound
+    x = rng.uniform(-700, 700, N)
+    rel = np.abs(_call(probe, "probe_exp_tab", x).astype(np.longdouble) / np.exp(x.astype(np.longdouble)) - 1)
+    assert float(rel.max()) <= 3e-14
+    x = np.arange(-400, 401) * (np.log(2.0) / 256)                  # the table nodes, both sides of every rounding tie
+    for eps in (0.0, 1e-17, -1e-17, 1.35e-3, -1.35e-3):
         assert _ulp(_call(probe, "probe_exp_tab", x + eps), np.exp((x + eps).astype(np.longdouble))) <= 1.5
     assert _call(probe, "probe_exp_tab", np.array([800.0]))[0] == np.inf
     assert _call(probe, "probe_exp_tab", np.array([-800.0]))[0] == 0.0
     assert _call(probe, "probe_exp_tab", np.array([0.0]))[0] == 1.0
+    assert np.isnan(_call(probe, "probe_exp_tab", np.array([np.nan]))[0])
 
 
 def test_neg_log(probe):
