@@ -4,14 +4,18 @@
 // it spends 34% of its issue slots in log+sqrt, 15% in sincospi, 11% in exp and 5% in the IEEE divide
 // (tools/ubench/ablate.hip).  The versions below do the same fp64 arithmetic with ~2.5x fewer
 // instructions by using what this path knows about its arguments:
-//   neg_log(u)      u in (0,1) normal            -> no denormal/negative/NaN handling, integer frexp
+//   neg_log(u)      u > 0 normal                 -> no denormal/negative/NaN handling, integer frexp
+//   neg_log_tab     same, 512-entry table        -> no reciprocal, cubic tail (the RNG's radius)
 //   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
-//   cossin_diag     |r| <= 1/2, two sign bits given -> no range reduction, no quadrant swap
+//   sqrt_pos_1g     same, Goldschmidt step only  -> 2^-47 (the RNG's radius)
+//   cossin_diag_tab raw angle bits + 2 sign bits -> no range reduction, no quadrant swap, 256-entry table
+//   cossin_diag     the same direction, table-free (two 7-term polynomials; kept as the reference form)
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
+//   exp_tab(x)      log-volatilities             -> 256-entry table, quadratic tail, one reduction constant
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
 // Accuracy (tests/test_math_accuracy.py, vs 80-bit libm on the host build; tests/test_gpu_parity.py on
-// the device build): exp, sin, cos <= 2 ULP; -log <= 3 ULP; sqrt, 1/x correctly rounded on the sampled
-// ranges.  Coefficients: tools/gen_minimax.py.
+// the device build): exp_fast, sin, cos, table log <= 2 ULP; -log <= 3 ULP; sqrt_pos, 1/x correctly rounded on the
+// sampled ranges; exp_tab <= 1.5 ULP on |x| <= 1 (see there).  Coefficients: tools/gen_minimax.py.
 //
 // The same source compiles for the host (g++, used only by the accuracy test) -- there the hardware
 // seeds are emulated with single-precision reciprocals, the worst seed the refinement must cope with.
