@@ -586,6 +586,7 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
+        if (SCHEME != SVMC_HESTON_QE) v = heston_euler_guard_zero(v);
         for (int t = 0; t < nb_steps; ++t) {
             const uint32_t step = step_offset + static_cast<uint32_t>(t);
             double w0, w1;
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
             const QeConsts qc = cs.qc[i];
             const HestonEulerFast ef = make_heston_euler_fast(c);
             double xacc = 0.0, vacc = 0.0;
+            if (SCHEME != SVMC_HESTON_QE) v = heston_euler_guard_zero(v);
             for (int t = 0; t < nb; ++t) {
                 double w0, w1;
                 if (SCHEME == SVMC_HESTON_QE) {

@@ -151,6 +151,13 @@ SVMC_HD double sqrt_pos0(double t)
     return (t == 0.0) ? 0.0 : r;
 }
 
+// the same to 2^-47 (Heston QE's diffusion coefficient, which can be exactly zero)
+SVMC_HD double sqrt_pos0_1g(double t)
+{
+    const double r = sqrt_pos_1g(t);
+    return (t == 0.0) ? 0.0 : r;
+}
+
 // exp(x) = 2^n * (1 + r + r^2 E(r)),  n = rint(x log2 e),  r = x - n ln2 (hi/lo),  |r| <= ln2/2
 SVMC_HD double exp_fast(double x)
 {

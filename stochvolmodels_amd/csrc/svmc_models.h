@@ -203,12 +203,20 @@ __device__ __forceinline__ void heston_euler_step_acc(const HestonEulerFast &f, 
                                                       double z0, double z1)
 {
     const double v = var;
-    const double s = sqrt_pos0(v);
+    const double s = sqrt_pos_1g(v);                                    // v > 0: heston_euler_guard_zero + the floor
     vacc = vacc + v;
     xacc = fma(s, z0, xacc);
     const double m = fma(f.a1, z1, f.a0 * z0);
     const double vn = fma(s, m, fma(v, f.one_m_kdt, f.ktdt));
     var = (vn > 1e-4) ? vn : ((vn != vn) ? vn : 1e-4);                  // np.maximum(v, 1e-4)     :379
+}
+
+// Only the incoming variance of a slice can be exactly zero (every later one is floored at 1e-4), and sqrt_pos_1g does
+// not take zero: 2^-1000 in its place gives sqrt = 2^-500, which the accumulators and the next variance absorb without
+// a trace (x, v, qvar come out as with an exact zero; a one-step slice keeps dt 2^-1000 in qvar).
+__device__ __forceinline__ double heston_euler_guard_zero(double var)
+{
+    return (var == 0.0) ? 0x1.0p-1000 : var;
 }
 
 __device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double &x, double &qvar, double xacc, double vacc)
@@ -247,7 +255,8 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
 // z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential branch (the
 // streamed kernel loads it only in waves that have a lane there; the on-device draw gets it from the same Philox call).  Quotients are reciprocal + one Newton
 // step (2^-48: far inside the 1e-9 the parity tests state), logs go through the LDS table (absolute accuracy
-// 1e-19 on arguments near 1, which is what the martingale correction feeds it), sqrt is svmc_math.h's; the
+// 1e-19 on arguments near 1, which is what the martingale correction feeds it), the square roots stop after the
+// Goldschmidt step (2^-47: the scheme matches two moments of the variance, not its bits); the
 // arithmetic order is the CPU twin's.
 template <class DrawU>
 __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEntry *tab, double &x, double &var,
@@ -260,9 +269,9 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
     double v1, K0;
     if (s2 <= 1.5 * m2) {                                 // psi = s2/m^2 <= psi_c, decided without the divide
         const double ip = 2.0 * m2 * rcp_1n(s2);          // 2/psi >= 4/3
-        const double b2 = ip - 1.0 + sqrt_pos(ip * (ip - 1.0));
+        const double b2 = ip - 1.0 + sqrt_pos_1g(ip * (ip - 1.0));
         const double a = m * rcp_1n(1.0 + b2);
-        const double b = sqrt_pos(b2);
+        const double b = sqrt_pos_1g(b2);
         v1 = a * (b + z1) * (b + z1);
         if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
             K0 = -c.K13 * v0;
@@ -280,7 +289,7 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
         else
             K0 = (c.A < bt) ? (neg_log_tab(p + bt * (1.0 - p) * rcp_1n(bt - c.A), tab) - c.K13 * v0) : c.K0_plain;
     }
-    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0(c.K3 * v0 + c.K4 * v1) * z0;
+    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0_1g(c.K3 * v0 + c.K4 * v1) * z0;
     qvar = qvar + 0.5 * c.dt * (v0 + v1);
     var = v1;
 }
