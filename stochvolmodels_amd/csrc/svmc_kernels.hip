@@ -186,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
-    const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
+    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         xv = x[p];
         s = sigma[p];
         q = qvar[p];
-        double L = log(s);                                                                      // :1039
+        double L = log(s) * LOG_UNITS_PER_NAT;                                                  // :1039
         double s2 = s * s, acc = 0.0, xacc = 0.0;
         const double s2_start = s2;
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
-    const auto exp_of = [&](double v) { return exp_tab(v, s_exp); };
+    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         const int nb = cs.nb_steps[i];
         if (active) {
             const LogsvFast c = cs.c[i];
-            double L = log(s);                                                                  // :1039
+            double L = log(s) * LOG_UNITS_PER_NAT;                                              // :1039
             double s2 = s * s, acc = 0.0, xacc = 0.0;
             const double s2_start = s2;
             for (int t = 0; t < nb; ++t) {
@@ -935,8 +935,8 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (int rc = check_state(fn, x, sigma, qvar, nb_steps, dt)) return rc;
     if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
     if (n_path == 0) return SVMC_OK;
-    const LogsvFast c = make_logsv_fast(
-        make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure));
+    const LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
+        make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
     hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
                        n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
     return check_launch(fn);
@@ -1012,8 +1012,8 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
         cs.total_steps = 0;
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
             const int j = (i < cs.m) ? i0 + i : i0;        // unused entries repeat a valid one
-            cs.c[i] = make_logsv_fast(make_logsv_consts(dts_host[j], theta, kappa1, kappa2, beta, volvol,
-                                                        etas_host ? etas_host[j] : 1.0, is_spot_measure));
+            cs.c[i] = logsv_fast_in_log_units(make_logsv_fast(make_logsv_consts(
+                dts_host[j], theta, kappa1, kappa2, beta, volvol, etas_host ? etas_host[j] : 1.0, is_spot_measure)));
             cs.forward[i] = forwards_host[j];
             cs.nb_steps[i] = (i < cs.m) ? nb_steps_host[j] : 0;
             cs.total_steps += cs.nb_steps[i];

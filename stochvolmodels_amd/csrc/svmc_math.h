@@ -199,6 +199,26 @@ SVMC_HD double exp_tab(double x, const double *tab)
     return ldexp(fma(t, p, t), ni >> 8);
 }
 
+// The same exponential for an argument carried in units of ln2/256: exp2u_tab(y) = 2^(y/256) = exp(y ln2/256).  The LogSV
+// stepping kernels keep the log-volatility in these units (their per-step constants are pre-multiplied by 256/ln2 on
+// the host), so the reduction is EXACT -- n = rint(y) by the 1.5 2^52 trick, r = y - n with |r| <= 1/2 and no rounding
+// -- and the accuracy no longer depends on the size of the argument: 2^(r/256) - 1 = r E(r) with a cubic E (5e-18),
+// the table and the scaling as in exp_tab.  11 instructions, three of them plain adds where exp_tab has FMAs, and
+// both constants of the reduction are gone (exp_tab needs one of its two in a VGPR pair).  <= 1.1 ULP.
+SVMC_HD double exp2u_tab(double y, const double *tab)
+{
+    const double kf = y + 0x1.8p+52;
+    const int ni = static_cast<int>(double_lo(kf));
+    const double r = y - (kf - 0x1.8p+52);
+    const double t = tab[ni & 255];
+    double q = 0x1.3b2ab8452c312p-39;
+    q = fma_k(q, r, 0x1.c6b0903967234p-29);
+    q = fma_k(q, r, 0x1.ebfbdff82c584p-19);
+    q = fma_k(q, r, 0x1.62e42fefa39d8p-9);
+    const double p = q * r;
+    return ldexp(fma(t, p, t), ni >> 8);
+}
+
 // -ln(u) for any positive normal u (the RNG calls it on (0,1); Heston QE on arguments around 1).  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,
 // f = m - 1, s = f/(2+f), ln(1+f) = f - (f^2/2 - s (f^2/2 + R)), R = s^2 G(s^2)   (Cody-Waite / fdlibm form)
 SVMC_HD double neg_log(double u)

@@ -86,6 +86,20 @@ inline LogsvFast make_logsv_fast(const LogsvConsts &c)
     return f;
 }
 
+// The accumulator-form kernels carry L = ln(sigma) in units of ln2/256 (svmc_math.h exp2u_tab: exact reduction): the
+// five constants that advance L are multiplied by 256/ln2 once, on the host.
+constexpr double LOG_UNITS_PER_NAT = 0x1.71547652b82fep+8;     // 256 / ln2
+
+inline LogsvFast logsv_fast_in_log_units(LogsvFast f)
+{
+    f.c1 *= LOG_UNITS_PER_NAT;
+    f.c2 *= LOG_UNITS_PER_NAT;
+    f.c3 *= LOG_UNITS_PER_NAT;
+    f.bs *= LOG_UNITS_PER_NAT;
+    f.es *= LOG_UNITS_PER_NAT;
+    return f;
+}
+
 // z0, z1 are UNSCALED N(0,1); s2 = sigma^2 is carried; exp_of(L) is the exponential to use (exp_fast, or exp_tab with
 // the block's LDS table in the issue-bound kernels)
 template <class Exp>

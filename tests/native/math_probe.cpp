@@ -8,6 +8,7 @@ static const svmc::DiagTabEntry DIAG_TAB[256] = {SVMC_DIAG_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
 void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_tab(x[i], EXP_TAB); }
+void probe_exp2u_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp2u_tab(x[i], EXP_TAB); }
 void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }
 void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log_tab(x[i], LOG_TAB); }
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }

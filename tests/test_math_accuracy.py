@@ -71,6 +71,24 @@ def test_exp_table(probe):
     assert np.isnan(_call(probe, "probe_exp_tab", np.array([np.nan]))[0])
 
 
+def test_exp2u_table(probe):
+    """exp2u_tab(y) = 2^(y/256), the exponential of the LogSV stepping kernels (log-volatility carried in units of
+    ln2/256, reduction exact): <= 1.1 ULP whatever the size of the argument"""
+    rng = np.random.default_rng(12)
+    two = np.longdouble(2.0)
+    for lo, hi in ((-400, 400), (-3000, 3000), (-250000, 250000)):
+        y = rng.uniform(lo, hi, N)
+        assert _ulp(_call(probe, "probe_exp2u_tab", y), two ** (y.astype(np.longdouble) / 256)) <= 1.1
+    y = np.arange(-2000, 2001).astype(np.float64)                    # the table nodes and the rounding ties between them
+    for eps in (0.0, 0.5, -0.5, 0.4999999, -0.4999999):
+        assert _ulp(_call(probe, "probe_exp2u_tab", y + eps), two ** ((y + eps).astype(np.longdouble) / 256)) <= 1.1
+    assert _call(probe, "probe_exp2u_tab", np.array([0.0]))[0] == 1.0
+    assert _call(probe, "probe_exp2u_tab", np.array([256.0 * 1100]))[0] == np.inf          # v_ldexp saturation semantics
+    assert _call(probe, "probe_exp2u_tab", np.array([-256.0 * 1200]))[0] == 0.0
+    assert np.isnan(_call(probe, "probe_exp2u_tab", np.array([np.nan]))[0])
+    assert np.isnan(_call(probe, "probe_exp2u_tab", np.array([np.inf]))[0])                # as exp_tab: inf - inf in the reduction
+
+
 def test_neg_log(probe):
     rng = np.random.default_rng(1)
     u = rng.integers(0, 2 ** 52, N).astype(np.float64) * 2.0 ** -52 + 2.0 ** -53       # the RNG lattice
