@@ -46,6 +46,10 @@ _EXPORTS = {
     "HestonPricer": "pricers.heston_pricer", "HestonParams": "pricers.heston_pricer",
     "BTC_HESTON_PARAMS": "pricers.heston_pricer", "heston_mc_chain_pricer": "pricers.heston_pricer",
     "simulate_heston_x_vol_terminal": "pricers.heston_pricer",
+    "compute_analytic_qvar": "pricers.logsv.vol_moments_ode",
+    "compute_analytic_vol_moments": "pricers.logsv.vol_moments_ode",
+    "fit_model_vol_backbone_to_varswaps": "pricers.logsv.vol_moments_ode",
+    "compute_var_swap_strike": "utils.var_swap_pricer",
 }
 
 __all__ = sorted(_EXPORTS)

@@ -11,6 +11,7 @@ from dataclasses import dataclass
 from typing import Tuple, List, Optional, Sequence
 
 import numpy as np
+import pandas as pd
 
 _VALID_OPTION_TYPES = frozenset({"C", "P", "IC", "IP"})
 
@@ -169,6 +170,25 @@ class OptionChain:
         """mid vol of each slice linearly interpolated to the forward (reference :281-286)"""
         return np.array([np.interp(x=f, xp=k, fp=v)
                          for f, k, v in zip(self.forwards, self.strikes_ttms, self.get_mid_vols())])
+
+    def get_slice_varswap_strikes(self, floor_with_atm_vols: bool = True) -> pd.Series:
+        """variance-swap strike (as a volatility) per maturity, replicated from the chain's own strikes priced at the
+        mid vols (reference :402-426; its Black prices come from the third-party package, here from black_price --
+        UNDISCOUNTED, as the replication wants them); floored with the ATM vol by default because a sparse strike
+        grid biases the replication low."""
+        from ..utils.var_swap_pricer import compute_var_swap_strike
+        out = np.zeros_like(self.ttms, dtype=float)
+        for idx, (ttm, forward, strikes, types, vols) in enumerate(zip(self.ttms, self.forwards, self.strikes_ttms,
+                                                                       self.optiontypes_ttms, self.get_mid_vols())):
+            strikes = np.asarray(strikes, dtype=float)
+            is_put = np.asarray(types).astype(str) == "P"
+            mid = black_price(float(forward), strikes, float(ttm), np.asarray(vols, dtype=float), ~is_put)
+            out[idx] = compute_var_swap_strike(puts=pd.Series(mid[is_put], index=strikes[is_put]),
+                                               calls=pd.Series(mid[~is_put], index=strikes[~is_put]),
+                                               forward=float(forward), ttm=float(ttm))
+        if floor_with_atm_vols:
+            out = np.maximum(self.get_chain_atm_vols(), out)
+        return pd.Series(out, index=self.ttms)
 
     def compute_model_ivols_from_chain_data(self, model_prices, forwards=None) -> List[np.ndarray]:
         """model prices -> Black implied vols, slice by slice (reference data/option_chain.py:327-346).

@@ -1,8 +1,8 @@
 """
 LogSvParams: parameters of the log-normal SV model with quadratic drift, Eq. (3.12)
     dsigma = (kappa1 + kappa2 sigma)(theta - sigma) dt + beta sigma dW0 + volvol sigma dW1
-(hot-path subset of the reference's pricers/logsv/logsv_params.py:34-161; the moment-matrix / grid
-helpers serve the analytic pricer and are out of scope).
+(the reference's pricers/logsv/logsv_params.py:34-161, plus the generator of the truncated volatility-moment
+system :269-323 that the variance-swap backbone fit of the calibration uses).
 """
 from __future__ import annotations
 
@@ -85,3 +85,20 @@ class LogSvParams(ModelParams):
     @property
     def gamma(self) -> float:
         return self.kappa1 / self.theta
+
+    def get_vol_moments_lambda(self, n_terms: int = 4) -> np.ndarray:
+        """generator of the truncated moment system of Y = sigma - theta (reference :269-323; Eq. (3.48)).
+
+        Ito on Y^n with dsigma = -(kappa + kappa2 Y) Y dt + vartheta (Y + theta) dW, kappa = kappa1 + kappa2 theta:
+            d/dt E[Y^n] = (c_n - n kappa) E[Y^n] - n kappa2 E[Y^(n+1)] + 2 c_n theta E[Y^(n-1)] + c_n theta^2 E[Y^(n-2)],
+            c_n = vartheta^2 n (n - 1) / 2.
+        Row n of the matrix holds the coefficients of E[Y^(n-2)] .. E[Y^(n+1)] that fall on the unknowns
+        E[Y^1] .. E[Y^n_terms]; the E[Y^0] = 1 term of row 2 and the closure of the last row go to the free vector
+        (vol_moments_ode.compute_analytic_vol_moments)."""
+        n = np.arange(1, n_terms + 1, dtype=float)
+        c = 0.5 * self.vartheta2 * n * (n - 1.0)
+        lam = np.diag(c - n * self.kappa)
+        lam += np.diag(-n[:-1] * self.kappa2, k=1)
+        lam += np.diag(2.0 * c[1:] * self.theta, k=-1)
+        lam += np.diag(c[2:] * self.theta2, k=-2)
+        return lam

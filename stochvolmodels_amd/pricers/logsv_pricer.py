@@ -15,6 +15,7 @@ from enum import Enum
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
+import pandas as pd
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
@@ -27,6 +28,7 @@ from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_
 from ..utils import mgf_pricer as mgfp
 from .logsv.affine_expansion import ExpansionOrder, _order_code
 from .logsv.logsv_params import LogSvParams
+from .logsv.vol_moments_ode import fit_model_vol_backbone_to_varswaps
 from .model_pricer import ModelPricer
 
 class LogsvModelCalibrationType(Enum):
@@ -54,22 +56,32 @@ class CalibrationEngine(Enum):
 
 
 _FREE_PARAMS = {LogsvModelCalibrationType.PARAMS4: ("sigma0", "theta", "beta", "volvol"),
-                LogsvModelCalibrationType.PARAMS5: ("sigma0", "theta", "kappa1", "beta", "volvol")}
+                LogsvModelCalibrationType.PARAMS5: ("sigma0", "theta", "kappa1", "beta", "volvol"),
+                LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT: ("beta", "volvol")}
 
 
-def _calibration_parser(calibration_type: LogsvModelCalibrationType, params0: LogSvParams):
+def _calibration_parser(calibration_type: LogsvModelCalibrationType, params0: LogSvParams,
+                        varswap_strikes: Optional[pd.Series] = None):
     """optimizer vector -> LogSvParams.  PARAMS4 keeps params0's kappas, PARAMS5 ties kappa2 = kappa1 / theta
-    (LogSvParams(kappa2=None)); H / nodes / weights always come from params0 (reference codec :106-160)."""
+    (LogSvParams(kappa2=None)); PARAMS_WITH_VARSWAP_FIT solves for (beta, volvol) only and, for every candidate,
+    refits the vol backbone so that the model reproduces the term structure of `varswap_strikes`
+    (vol_moments_ode.fit_model_vol_backbone_to_varswaps); H / nodes / weights always come from params0 (reference
+    codec :106-160).  PARAMS6 raises as in the reference."""
     names = _FREE_PARAMS.get(calibration_type)
     if names is None:
-        raise NotImplementedError(f"{calibration_type}")      # PARAMS6: as the reference; varswap fit: not built
+        raise NotImplementedError(f"{calibration_type}")
     tied = calibration_type == LogsvModelCalibrationType.PARAMS5
+    with_varswaps = calibration_type == LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT
 
     def parse(pars: np.ndarray) -> LogSvParams:
-        fields = dict(kappa1=params0.kappa1, kappa2=None if tied else params0.kappa2, H=params0.H,
-                      nodes=params0.nodes, weights=params0.weights)
+        fields = dict(sigma0=params0.sigma0, theta=params0.theta, kappa1=params0.kappa1,
+                      kappa2=None if tied else params0.kappa2, H=params0.H, nodes=params0.nodes, weights=params0.weights)
         fields.update(zip(names, pars))
-        return LogSvParams(**fields)
+        params = LogSvParams(**fields)
+        if with_varswaps:
+            params.set_vol_backbone(fit_model_vol_backbone_to_varswaps(log_sv_params=params,
+                                                                       varswap_strikes=varswap_strikes))
+        return params
     return names, parse
 
 
@@ -177,7 +189,9 @@ class LogSVPricer(ModelPricer):
         _, market_vols_ttms = option_chain.get_chain_data_as_xy()
         market_vols = np.concatenate(market_vols_ttms).ravel()
         weights = chain_calibration_weights(option_chain, market_vols, is_vega_weighted, is_unit_ttm_vega)
-        names, parse = _calibration_parser(model_calibration_type, params0)
+        varswap_strikes = (option_chain.get_slice_varswap_strikes(floor_with_atm_vols=True)
+                           if model_calibration_type == LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT else None)
+        names, parse = _calibration_parser(model_calibration_type, params0, varswap_strikes)
         p0 = np.array([getattr(params0, n) for n in names], dtype=float)
         bounds = tuple((getattr(params_min, n), getattr(params_max, n)) for n in names)
         comm = kwargs.get("comm")

@@ -553,6 +553,116 @@ def g_calibration():
     save("calibration", **out)
 
 
+def g_varswap():
+    """Volatility moments / expected quadratic variance (pricers/logsv/vol_moments_ode.py), the variance-swap backbone
+    fit, the strip replication of utils/var_swap_pricer.py, the chain's varswap strikes and the calibration mode
+    PARAMS_WITH_VARSWAP_FIT (codec + full runs).  As in g_calibration the third-party Black routines the reference
+    calls are bound to the host helpers of stochvolmodels_amd.data.option_chain (here also
+    compute_bsm_vanilla_slice_prices), so the chain-level vectors pin the LOOP, not that package."""
+    import pandas as pd
+    import stochvolmodels as svm
+    import stochvolmodels.data.option_chain as roc
+    from stochvolmodels.pricers.logsv.vol_moments_ode import (compute_analytic_vol_moments,
+                                                              fit_model_vol_backbone_to_varswaps)
+    from stochvolmodels.utils.var_swap_pricer import compute_var_swap_strike
+    from stochvolmodels_amd.data import option_chain as host
+
+    out = {}
+    sets = {"btc": BTC, "test": TEST,
+            "mix": LogSvParams(sigma0=0.9, theta=0.6, kappa1=2.0, kappa2=1.5, beta=0.4, volvol=1.1)}
+    ts = np.array([0.0, 0.02, 0.25, 1.0, 3.0])
+    for tag, p in sets.items():
+        out[f"par_{tag}"] = params_vec(p)
+        for k in (3, 4, 8):
+            out[f"lambda_{tag}_{k}"] = p.get_vol_moments_lambda(n_terms=k)
+            out[f"mom_{tag}_{k}"] = np.stack([compute_analytic_vol_moments(p, t=t, n_terms=k) for t in ts])
+            out[f"imom_{tag}_{k}"] = np.stack([compute_analytic_vol_moments(p, t=t, n_terms=k, is_qvar=True) for t in ts])
+            out[f"qvar_{tag}_{k}"] = np.array([compute_analytic_qvar(p, ttm=t, n_terms=k) for t in ts])
+    out["ts"] = ts
+    # backbone fit: a front maturity under 0.06 (square-root damping) and a dip in total variance (ratio <= 0 -> 1)
+    vs_ttms = np.array([0.04, 0.1, 0.25, 0.5, 0.55, 1.0])
+    vs_strikes = np.array([0.95, 0.9, 0.85, 0.8, 0.72, 0.78])
+    out["vs_ttms"], out["vs_strikes"] = vs_ttms, vs_strikes
+    for tag, p in sets.items():
+        out[f"eta_{tag}"] = fit_model_vol_backbone_to_varswaps(p, pd.Series(vs_strikes, index=vs_ttms)).to_numpy()
+    # strip replication: forward between strikes / on a strike, ragged one-sided quotes, two strikes only
+    rng = np.random.default_rng(8)
+    cases = []
+    for n, fwd in ((9, 1.03), (9, 1.0), (5, 97.0), (2, 1.0)):
+        strikes = np.sort(fwd * np.exp(rng.uniform(-0.35, 0.35, n)))
+        if n == 9 and fwd == 1.0:
+            strikes[4] = 1.0
+        strikes[-1] = max(strikes[-1], fwd * 1.01)
+        vols = 0.5 + 0.3 * np.abs(np.log(strikes / fwd))
+        ttm = float(rng.uniform(0.05, 1.0))
+        is_put = strikes < fwd
+        pr = host.black_price(fwd, strikes, ttm, vols, ~is_put)
+        puts, calls = pd.Series(pr[is_put], index=strikes[is_put]), pd.Series(pr[~is_put], index=strikes[~is_put])
+        k = len(cases)
+        out[f"strip{k}_strikes"], out[f"strip{k}_prices"], out[f"strip{k}_isput"] = strikes, pr, is_put
+        out[f"strip{k}_fwd_ttm"] = np.array([fwd, ttm])
+        out[f"strip{k}_kvar"] = np.array([compute_var_swap_strike(puts=puts, calls=calls, forward=fwd, ttm=ttm)])
+        cases.append(k)
+    out["n_strips"] = np.array([len(cases)])
+
+    # chain level: bind the third-party Black routines to the host helpers
+    def vegas_ttms(ttms, forwards, strikes_ttms, optiontypes_ttms, vols_ttms):
+        return [host.black_vega(float(f), np.asarray(k, float), float(t), np.asarray(v, float))
+                for t, f, k, v in zip(ttms, forwards, strikes_ttms, vols_ttms)]
+
+    def ivols_ttms(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, model_prices_ttms):
+        return [host.infer_black_ivols(np.asarray(p, float), float(t), float(f), np.asarray(k, float), ty, float(d))
+                for t, f, d, k, ty, p in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                             model_prices_ttms)]
+
+    def slice_prices(ttm, forward, strikes, vols, optiontypes, discfactor=1.0):
+        return host.black_price(float(forward), np.asarray(strikes, float), float(ttm), np.asarray(vols, float),
+                                np.asarray(optiontypes).astype(str) == "C", float(discfactor))
+    roc.bsm.compute_bsm_vegas_ttms = vegas_ttms
+    roc.bsm.infer_bsm_ivols_from_model_chain_prices = ivols_ttms
+    roc.bsm.compute_bsm_vanilla_slice_prices = slice_prices
+
+    ttms = np.array([0.05, 0.1, 0.25, 0.5])
+    forwards = np.array([1.0, 1.0, 1.01, 1.02])
+    strikes = tuple(f * np.linspace(0.7, 1.3, 13) for f in forwards)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, forwards))
+    ids = np.array(["t0", "t1", "t2", "t3"])
+    true = LogSvParams(sigma0=0.5, theta=0.6, kappa1=2.0, kappa2=2.5, beta=-0.3, volvol=1.0)
+    true.set_vol_backbone(pd.Series(np.array([1.15, 1.1, 0.95, 0.9]), index=ttms))
+    base = svm.OptionChain(ttms=ttms, forwards=forwards, strikes_ttms=strikes, optiontypes_ttms=types,
+                           discfactors=np.ones(4), ids=ids)
+    pricer = svm.LogSVPricer()
+    mids = pricer.compute_model_ivols_for_chain(option_chain=base, params=true)
+    chain = svm.OptionChain(ttms=ttms, forwards=forwards, strikes_ttms=strikes, optiontypes_ttms=types,
+                            discfactors=np.ones(4), ids=ids, bid_ivs=tuple(m - 0.005 for m in mids),
+                            ask_ivs=tuple(m + 0.005 for m in mids))
+    out["chain_ttms"], out["chain_forwards"] = ttms, forwards
+    for i in range(4):
+        out[f"chain_strikes_{i}"], out[f"chain_types_{i}"], out[f"chain_mid_{i}"] = strikes[i], types[i], mids[i]
+    out["chain_varswaps_floored"] = chain.get_slice_varswap_strikes(floor_with_atm_vols=True).to_numpy()
+    out["chain_varswaps_raw"] = chain.get_slice_varswap_strikes(floor_with_atm_vols=False).to_numpy()
+    out["chain_true"] = params_vec(true)
+    # the codec of the mode: (beta, volvol) -> parameters with the refitted backbone
+    start = LogSvParams(sigma0=0.5, theta=0.6, kappa1=2.0, kappa2=2.5, beta=0.0, volvol=1.4)
+    vs = chain.get_slice_varswap_strikes(floor_with_atm_vols=True)
+    codec = lp._LogSvParameterCodec(params0=start, params_min=start, params_max=start,
+                                    calibration_type=lp.LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT,
+                                    varswap_strikes=vs)
+    for j, pars in enumerate((np.array([0.0, 1.4]), np.array([-0.45, 0.8]), np.array([0.7, 2.2]))):
+        q = codec.parse(pars)
+        out[f"codec{j}_pars"], out[f"codec{j}_params"] = pars, params_vec(q)
+        out[f"codec{j}_backbone"] = q.vol_backbone.to_numpy()
+    out["start"] = params_vec(start)
+    CT, CE = lp.LogsvModelCalibrationType, lp.CalibrationEngine
+    for tag, kw in (("an", dict(calibration_engine=CE.ANALYTIC)),
+                    ("mc", dict(calibration_engine=CE.MC, nb_path=4000, nb_steps=360, seed=10))):
+        fit = pricer.calibrate_model_params_to_chain(option_chain=chain, params0=start,
+                                                     model_calibration_type=CT.PARAMS_WITH_VARSWAP_FIT, **kw)
+        print(tag, fit)
+        out[f"{tag}_fit"], out[f"{tag}_backbone"] = params_vec(fit), fit.vol_backbone.to_numpy()
+    save("varswap", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python make_golden.py g_rough g_calibration ...
         oracle.build()
@@ -573,4 +683,5 @@ if __name__ == "__main__":
     g_analytic_qvar()
     g_heston_qvar()
     g_rough()
+    g_varswap()
     g_calibration()

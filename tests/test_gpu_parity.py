@@ -936,6 +936,32 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
         assert fit.kappa1 + fit.kappa2 * fit.theta - 1.5 * (fit.beta ** 2 + fit.volvol ** 2) >= -1e-8
 
 
+@pytest.mark.parametrize("tag", ["an", "mc"])
+def test_logsv_varswap_fit_calibration_vs_reference(sv, golden, tag):
+    """PARAMS_WITH_VARSWAP_FIT: SLSQP over (beta, volvol) only, the vol backbone refitted to the chain's variance-swap
+    strikes for every candidate -- same chain, start point, randoms and optimizer options as the reference's run
+    (tests/golden/make_golden.py g_varswap; the host pieces alone are in tests/test_varswap_golden.py)."""
+    g = golden("varswap")
+    mids = [g[f"chain_mid_{i}"] for i in range(4)]
+    chain = sv.OptionChain(ttms=g["chain_ttms"], forwards=g["chain_forwards"],
+                           strikes_ttms=tuple(g[f"chain_strikes_{i}"] for i in range(4)),
+                           optiontypes_ttms=tuple(g[f"chain_types_{i}"] for i in range(4)), discfactors=np.ones(4),
+                           ids=np.array(["t0", "t1", "t2", "t3"]), bid_ivs=tuple(m - 0.005 for m in mids),
+                           ask_ivs=tuple(m + 0.005 for m in mids))
+    s = g["start"]
+    start = sv.LogSvParams(sigma0=s[0], theta=s[1], kappa1=s[2], kappa2=s[3], beta=s[4], volvol=s[5])
+    CE = sv.CalibrationEngine
+    kw = dict(an=dict(calibration_engine=CE.ANALYTIC), mc=dict(calibration_engine=CE.MC, nb_path=4000, nb_steps=360, seed=10))[tag]
+    pricer = sv.LogSVPricer()
+    fit = pricer.calibrate_model_params_to_chain(option_chain=chain, params0=start, disp=False,
+                                                 model_calibration_type=sv.LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT, **kw)
+    tol = dict(rtol=2e-3, atol=2e-3) if tag == "mc" else dict(rtol=2e-2, atol=1e-2)    # an: RK45 rtol 1e-3 in the reference
+    np.testing.assert_allclose(_vec(fit), g[f"{tag}_fit"], **tol)
+    np.testing.assert_allclose(fit.vol_backbone.to_numpy(), g[f"{tag}_backbone"], **tol)
+    assert _vec(fit)[:4].tolist() == s[:4].tolist()                        # sigma0, theta, kappa1, kappa2 are not touched
+    assert pricer.last_calibration["n_eval"] > 5
+
+
 def test_heston_calibration_vs_reference(sv, golden):
     g = golden("calibration")
     chain = _calibration_chain(sv, g, "heston_")

@@ -169,9 +169,10 @@ def test_calibration_parser_and_constraints():
     names, parse = _calibration_parser(sv.LogsvModelCalibrationType.PARAMS5, p0)
     p = parse(np.array([0.5, 0.5, 2.0, -0.2, 0.9]))
     assert names == ("sigma0", "theta", "kappa1", "beta", "volvol") and p.kappa2 == 4.0     # kappa1 / theta
-    for ct in (sv.LogsvModelCalibrationType.PARAMS6, sv.LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT):
-        with pytest.raises(NotImplementedError):
-            _calibration_parser(ct, p0)
+    with pytest.raises(NotImplementedError):                     # as the reference
+        _calibration_parser(sv.LogsvModelCalibrationType.PARAMS6, p0)
+    names_vs, _ = _calibration_parser(sv.LogsvModelCalibrationType.PARAMS_WITH_VARSWAP_FIT, p0)
+    assert names_vs == ("beta", "volvol")                        # its parse() is covered in tests/test_varswap_golden.py
     assert _calibration_constraints(parse, sv.ConstraintsType.UNCONSTRAINT) is None
     c = _calibration_constraints(parse, sv.ConstraintsType.INVERSE_MARTINGALE_MOMENT4)
     x = np.array([0.5, 0.5, 2.0, -0.2, 0.9])
