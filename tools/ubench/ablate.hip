@@ -12,8 +12,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                                                     int nb_steps, LogsvFast c,
                                                                                     uint64_t seed)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;
@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             xv += w0; q += w1;
         } else if (MODE == 4) {  // philox + table log + sqrt
             philox_draw(seed, 0, p, t, r);
-            const double e = neg_log_tab(mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53), tab);
-            xv += sqrt_pos(e + e); q += mantissa_1_2(r[2], r[3]);
-        } else if (MODE == 5) {  // philox + quarter-turn sincos
+            const double e = neg_log_tab(mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53), tab.log);
+            xv += sqrt_pos_1g(e); q += mantissa_1_2(r[2], r[3]);
+        } else if (MODE == 5) {  // philox + the table-assisted direction
             philox_draw(seed, 0, p, t, r);
-            double sn, cs; cossin_diag(r[2], mantissa_1_2(r[2], r[3]) - 1.5, cs, sn);
+            double sn, cs; cossin_diag_tab(r[2], r[2], r[3], tab.diag, cs, sn);
             xv += sn + mantissa_1_2(r[0], r[1]); q += cs;
         } else if (MODE == 6) {  // exp only
             L += 1e-3; s = exp_fast(L); xv += s;

@@ -13,8 +13,8 @@ template <int PAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72)))
 void k(double *x, double *sigma, double *qvar, size_t n, int nb, LogsvFast c, uint64_t seed)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;

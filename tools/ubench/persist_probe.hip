@@ -15,8 +15,8 @@ using namespace svmc;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_plain(double *x, double *sigma, double *qvar, size_t n, int nb, LogsvFast c, uint64_t seed)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_persist(double *x, double *sigma, double *qvar, size_t n, int nb, int seg, LogsvFast c, uint64_t seed,
                unsigned *ctl, unsigned long long max_spin)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const unsigned W = (unsigned)((n + 63) / 64), S = (unsigned)((nb + seg - 1) / seg), T = W * S;
     const unsigned lane = threadIdx.x & 63;
     for (;;) {

@@ -12,8 +12,8 @@ using namespace svmc;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k(double *x, double *sigma, double *qvar, size_t n, int nb_steps, LogsvFast c, uint64_t seed, uint64_t *t0, uint64_t *t1)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t start = wall_clock64();
     double xv = x[p], s = sigma[p], q = qvar[p], L = log(s), s2 = s * s;
@@ -29,8 +29,8 @@ void k(double *x, double *sigma, double *qvar, size_t n, int nb_steps, LogsvFast
 __global__ __launch_bounds__(256)
 void k2(double *x, double *sigma, double *qvar, size_t n, int nb_steps, LogsvFast c, uint64_t seed, uint64_t *t0, uint64_t *t1)
 {
-    __shared__ LogTabEntry s_tab[256];
-    const LogTabEntry *tab = stage_log_table(s_tab);
+    __shared__ RngTablesLds s_tab;
+    const RngTables tab = stage_rng_tables(s_tab);
     const size_t half = n / 2;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;      // p < half
     const size_t pb = p + half;
