@@ -59,13 +59,16 @@ class TorchComm:
         return self._torch.device("cuda", engine.device)
 
     def alloc(self, engine, n_doubles: int, tag: str):
-        # one persistent tensor per (engine, tag), zero-initialised (never hands garbage to the collective)
+        # one persistent tensor per (engine, tag), zero-initialised; the HANDLE is the live prefix t[:n_doubles], so
+        # the collective reduces exactly the doubles this chain wrote -- every rank calls with the same n_doubles
+        # (it is a function of the chain alone), whatever chains each rank priced before
         key = (id(engine), tag)
+        n = max(int(n_doubles), 1)
         t = self._bufs.get(key)
-        if t is None or t.numel() < n_doubles:
-            t = self._torch.zeros(max(n_doubles, 1), dtype=self._torch.float64, device=self._device(engine))
+        if t is None or t.numel() < n:
+            t = self._torch.zeros(n, dtype=self._torch.float64, device=self._device(engine))
             self._bufs[key] = t
-        return t.data_ptr(), t
+        return t.data_ptr(), t.narrow(0, 0, n)
 
     def _stream_ordered(self, engine, handle) -> bool:
         """True when libsvmc's launches and the collective are ordered by the stream alone: the engine launches on
@@ -140,5 +143,22 @@ def init_from_env(backend: Optional[str] = None):
         dist.all_reduce(warm)
         if warm.is_cuda:
             torch.cuda.synchronize(warm.device)
-    set_default_comm(TorchComm())
+    comm = TorchComm()
+    _share_rng_seed(comm)
+    set_default_comm(comm)
     return get_default_comm()
+
+
+def _share_rng_seed(comm) -> None:
+    """every rank must key Philox with the SAME (seed, call counter): the union of the shards is one path set only
+    then.  An un-seeded process draws its seed from OS entropy (utils/funcs.py), so rank 0's pair is broadcast when
+    the group is built; afterwards set_seed(value) / seed= must be called identically on all ranks (as any SPMD
+    program does)."""
+    from .utils import funcs
+    t = comm._torch
+    dev = "cuda" if comm._dist.get_backend(comm.group) == "nccl" else "cpu"
+    seed, calls = funcs.get_rng_state()
+    buf = t.tensor([seed & 0xFFFFFFFF, seed >> 32, calls], dtype=t.int64, device=dev)
+    comm._dist.broadcast(buf, src=0, group=comm.group)
+    lo, hi, calls = (int(v) for v in buf.cpu().tolist())
+    funcs.set_rng_state((hi << 32) | lo, calls)

@@ -13,6 +13,8 @@ class and fails loudly when libsvmc.so or a GPU is missing.
 from __future__ import annotations
 
 import ctypes as C
+import sys
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -100,6 +102,7 @@ class HipEngine:
         self._factors: Optional[DeviceBuffer] = None   # rough LogSV: [n_factors][n_path]
         self._sums = {}
         self._prof = None   # list of (name, start_event, stop_event) while kernel timing is on
+        self.closed = False
         if n_snapshots:
             self.reserve_snapshots(n_snapshots)
 
@@ -198,17 +201,19 @@ class HipEngine:
         """upload the local column range [col0, col0 + n_path) of host [nb_steps, nb_path_total] arrays."""
         nb = arrays[0].shape[0]
         buf = self._rand_buffer(len(arrays) * nb * self.n_path)
-        ptrs = []
+        ptrs, keep = [], []         # `keep`: converted temporaries must outlive the asynchronous copies below
         for i, a in enumerate(arrays):
             a = np.asarray(a)
             if a.dtype != np.float64 or not a.flags.c_contiguous:
                 a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
             assert a.ndim == 2 and a.shape[0] == nb and a.shape[1] >= col0 + self.n_path
             dst = buf.offset(i * nb * self.n_path)
             _lib.check(self.lib.svmc_memcpy2d_h2d(dst, 8 * self.n_path, a.ctypes.data + 8 * col0, 8 * a.shape[1],
                                                   8 * self.n_path, nb, self.stream))
             ptrs.append(dst)
         self.synchronize()
+        del keep
         return tuple(ptrs)
 
     def fill_normals(self, nb_steps: int, seed: int, call_id: int = 0, step_offset: int = 0) -> Tuple[int, int]:
@@ -394,6 +399,9 @@ class HipEngine:
             int(variable_type), out_ptr, self.ws.ptr, self.ws_bytes, self.stream))
 
     def close(self) -> None:
+        """free every HBM buffer of the engine; any later launch through it fails in the C ABI's null-pointer
+        checks (SvmcError), it never touches freed memory"""
+        self.closed = True
         for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values()):
             if b is not None:
                 b.free()
@@ -498,16 +506,39 @@ def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_p
     return prices, stderrs
 
 
-# engines are cached per (device, n_path, path_offset): buffers stay resident across calls
+# Engines are cached per (device id, n_path, path_offset) so that buffers stay resident across calls.  The cache is
+# process-global and guarded by a lock; the engines themselves are NOT thread-safe (one stream, one set of state
+# buffers): concurrent callers must use distinct (n_path, path_offset) keys or their own HipEngine objects.
+# Eviction (more than MAX_CACHED_ENGINES resident) only ever closes an engine nobody else references -- a caller that
+# kept the object returned by get_engine() keeps its HBM -- and an engine that was closed raises SvmcError (null
+# pointer) on its next launch instead of touching freed memory.
+MAX_CACHED_ENGINES = 4
 _ENGINES = {}
+_ENGINES_LOCK = threading.Lock()
+
+
+def _current_device() -> int:
+    dev = C.c_int()
+    _lib.check(_lib.load().svmc_get_device(C.byref(dev)))
+    return dev.value
 
 
 def get_engine(n_path: int, path_offset: int = 0, device: Optional[int] = None) -> HipEngine:
-    key = (device, int(n_path), int(path_offset))
-    eng = _ENGINES.get(key)
-    if eng is None:
-        if len(_ENGINES) >= 4:  # bound resident HBM: drop the oldest engine
-            _ENGINES.pop(next(iter(_ENGINES))).close()
-        eng = HipEngine(n_path, device=device, path_offset=path_offset)
+    dev = _current_device() if device is None else int(device)     # None = the CURRENT HIP device, resolved now
+    key = (dev, int(n_path), int(path_offset))
+    with _ENGINES_LOCK:
+        eng = _ENGINES.get(key)
+        if eng is not None and not eng.closed:
+            _ENGINES[key] = _ENGINES.pop(key)          # most recently used last
+            return eng
+        if len(_ENGINES) >= MAX_CACHED_ENGINES:        # bound resident HBM: drop the least recently used FREE engine
+            for k in list(_ENGINES):
+                # references: the dict, the loop variable below, getrefcount's argument
+                cand = _ENGINES[k]
+                if sys.getrefcount(cand) <= 3:
+                    _ENGINES.pop(k).close()
+                    break
+                del cand
+        eng = HipEngine(n_path, device=dev, path_offset=path_offset)
         _ENGINES[key] = eng
-    return eng
+        return eng

@@ -47,6 +47,19 @@ def set_seed(value: int) -> None:
         _rng_calls = 0
 
 
+def get_rng_state() -> Tuple[int, int]:
+    """(seed, calls consumed): what dist.init_from_env broadcasts from rank 0 so that all ranks share one stream"""
+    with _rng_lock:
+        return _rng_seed, _rng_calls
+
+
+def set_rng_state(seed: int, calls: int) -> None:
+    global _rng_seed, _rng_calls
+    with _rng_lock:
+        _rng_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _rng_calls = int(calls) & 0xFFFFFF
+
+
 def next_rng_call(seed: Optional[int] = None) -> Tuple[int, int]:
     """(seed, call_id) for one generator call: explicit seed -> call 0 (pure replay); otherwise the
     process seed and the next call id."""

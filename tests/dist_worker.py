@@ -53,6 +53,16 @@ def main(out_path):
     res["rough_prices"], res["rough_stderrs"] = np.stack(pr), np.stack(sd)
     pr, sd = logsv_pricer.rough_logsv_mc_chain_pricer(nb_path=1001, nb_steps_per_year=120, seed=5, **ROUGH_CASE)
     res["rough_rng_prices"], res["rough_rng_stderrs"] = np.stack(pr), np.stack(sd)
+    # a SHORTER chain after the longer ones: the collectives must reduce only the live prefix of the persistent buffers
+    short = {k: (v[:1] if k in ("ttms", "forwards", "discfactors", "strikes_ttms", "optiontypes_ttms", "vol_backbone_etas")
+                 else v) for k, v in LOGSV_CASE.items()}
+    pr, sd = logsv_pricer.logsv_mc_chain_pricer(**short)
+    res["short_prices"], res["short_stderrs"] = np.stack(pr), np.stack(sd)
+    # un-seeded calls: rank 0's entropy seed and call counter are shared when the group is built
+    from stochvolmodels_amd.utils import funcs
+    res["rng_state"] = np.array(funcs.get_rng_state(), dtype=np.uint64)
+    pr, sd = logsv_pricer.logsv_mc_chain_pricer(**{**short, "seed": None})
+    res["unseeded_prices"] = np.stack(pr)
     res["rank_paths"] = np.array([e.n_path for e in engines.values()])
     res["rank_offsets"] = np.array([e.path_offset for e in engines.values()])
     np.savez(out_path + f".rank{comm.rank}.npz", **res)

@@ -77,9 +77,14 @@ def test_sharded_chain_matches_single_process(oracle, tmp_path, world):
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     exp = _expected(oracle)
+    exp["short_prices"], exp["short_stderrs"] = exp["logsv_prices"][:1], exp["logsv_stderrs"][:1]
     offsets = []
+    rank0 = np.load(out + ".rank0.npz")
     for r in range(world):
         got = np.load(out + f".rank{r}.npz")
+        # every rank keys Philox with rank 0's (seed, call counter): un-seeded prices are one global result
+        assert np.array_equal(got["rng_state"], rank0["rng_state"]), (r, got["rng_state"], rank0["rng_state"])
+        assert np.array_equal(got["unseeded_prices"], rank0["unseeded_prices"])
         for key, ref in exp.items():                       # every rank returns the global result
             np.testing.assert_allclose(got[key], ref, rtol=1e-11, atol=1e-14, err_msg=f"{key} rank {r}/{world}")
         assert set(got["rank_paths"]) == {(1001 * (r + 1)) // world - (1001 * r) // world}
