@@ -284,25 +284,31 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Counter-based randoms.  Philox4x32-10: J. Salmon, M. Moraes, R. Dror, D. Shaw, "Parallel random
- * numbers: as easy as 1, 2, 3", SC'11 (constants and round function from the paper; checked against
- * the Random123 known-answer vectors in tests/test_oracle_golden.py).
+ * Counter-based randoms.  Philox4x32: J. Salmon, M. Moraes, R. Dror, D. Shaw, "Parallel random
+ * numbers: as easy as 1, 2, 3", SC'11 (constants and round function from the paper; the round function is
+ * checked at its 10-round setting against the Random123 known-answer vectors in tests/test_oracle_golden.py).
+ * The svmc streams use SEVEN rounds, the smallest Crush-resistant count the paper reports for 4x32.
  *
- * svmc stream definition (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h):
- *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step, stream | call_id << 8)
- *   r0..r3 = philox(ctr, key)
- *   u1 = ((r0 | r1<<32) >> 12) * 2^-52 + 2^-53      in (0,1), exact in fp64
- *   rr = ((r2 | r3<<32) >> 12) * 2^-52 - 1/2        in [-1/2, 1/2), exact in fp64
- *   s0, s1 = signs from r2 & 1, r2 & 2
- *   stream 0:  R = sqrt(-ln u1);  x = (pi/2) rr;  w0 = s0 R (cos x - sin x);  w1 = s1 R (cos x + sin x);
- *              s0 = -1 if r2 & 1, s1 = -1 if r2 & 2   (= sqrt(-2 ln u1) (s0 cos, s1 sin)(x + pi/4))
- *   stream 1:  uniform = u1
+ * svmc stream definition, version 2 (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h).
+ * One call yields the Box-Muller pairs of TWO consecutive time steps:
+ *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8)
+ *   r0..r3 = philox4x32_7(ctr, key);  (ra, rb) = (r0, r1) for an even step, (r2, r3) for an odd one
+ *   u1 = (ra + 1/2) 2^-32                                  in (0,1), exact in fp64
+ *   j  = rb >> 24;  d = ((rb & 0x00FFFFFC) + 2) 2^-32 - 2^-9;  x = (pi/2) ((j + 1/2)/256 - 1/2 + d)
+ *   s0, s1 = signs from rb & 1, rb & 2
+ *   streams 0, 3:  R = sqrt(-ln u1);  w0 = s0 R (cos x - sin x);  w1 = s1 R (cos x + sin x)
+ *              (= sqrt(-2 ln u1) (s0 cos, s1 sin)(x + pi/4))
+ *   stream 1:  one call per draw, uniform = ((r0 | r1<<32) >> 12) 2^-52 + 2^-53
+ *   stream 2 (vol paths, one Brownian per step): normal t = component t & 1 of pair (t >> 1) & 1 of call t >> 2
+ *   stream 4 (Heston QE): one call per step, pair from (r0, r1), uniform (r2 + 1/2) 2^-32
  * ---------------------------------------------------------------------------------------------- */
-void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+#define SVO_PHILOX_ROUNDS 7
+
+void svo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4])
 {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         uint32_t n1 = (uint32_t)p1;
@@ -314,21 +320,48 @@ void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    svo_philox4x32(ctr, key, 10, out);
+}
+
 static inline double m52(uint32_t lo, uint32_t hi)
 {
     return (double)((((uint64_t)hi << 32) | lo) >> 12) * 0x1.0p-52;   /* in [0,1), exact */
 }
 
-static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
+static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t index, uint32_t stream,
                                uint32_t r[4])
 {
-    uint32_t ctr[4] = { (uint32_t)path, (uint32_t)(path >> 32), step, stream | (call_id << 8) };
+    uint32_t ctr[4] = { (uint32_t)path, (uint32_t)(path >> 32), index, stream | (call_id << 8) };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    svo_philox4x32_10(ctr, key, r);
+    svo_philox4x32(ctr, key, SVO_PHILOX_ROUNDS, r);
+}
+
+/* the pair of one (ra, rb) word pair */
+static inline void pair_from_words(uint32_t ra, uint32_t rb, double *w0, double *w1)
+{
+    static const double HALF_PI = 1.57079632679489661923;
+    double u1 = ((double)ra + 0.5) * 0x1.0p-32;
+    double d = (double)((rb & 0x00FFFFFCu) + 2u) * 0x1.0p-32 - 0x1.0p-9;
+    double rr = (((double)(rb >> 24) + 0.5) * 0x1.0p-8 - 0.5) + d;    /* exact: in [-1/2, 1/2) */
+    double R = sqrt(-log(u1));                               /* the sqrt2 of sqrt(-2 ln u) lives in (a, b) */
+    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);     /* |angle| <= pi/4: no reduction error */
+    double a = c - s, b = c + s;                             /* sqrt2 (cos, sin)(x + pi/4) */
+    if (rb & 1u) a = -a;
+    if (rb & 2u) b = -b;
+    *w0 = R * a;
+    *w1 = R * b;
 }
 
 static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
-                                double *w0, double *w1);
+                                double *w0, double *w1)
+{
+    uint32_t r[4];
+    philox_draw(seed, call_id, path, step >> 1, stream, r);
+    if (step & 1u) pair_from_words(r[2], r[3], w0, w1);
+    else pair_from_words(r[0], r[1], w0, w1);
+}
 
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1)
@@ -336,40 +369,13 @@ void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t s
     draw_normals_stream(seed, call_id, path, step, 0u, w0, w1);
 }
 
-static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
-                                double *w0, double *w1)
-{
-    static const double HALF_PI = 1.57079632679489661923;
-    uint32_t r[4];
-    philox_draw(seed, call_id, path, step, stream, r);
-    double u1 = m52(r[0], r[1]) + 0x1.0p-53;
-    double rr = m52(r[2], r[3]) - 0.5;
-    double R = sqrt(-log(u1));                               /* the sqrt2 of sqrt(-2 ln u) lives in (a, b) */
-    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);     /* |angle| <= pi/4: no reduction error */
-    double a = c - s, b = c + s;                             /* sqrt2 (cos, sin)(x + pi/4) */
-    if (r[2] & 1u) a = -a;
-    if (r[2] & 2u) b = -b;
-    *w0 = R * a;
-    *w1 = R * b;
-}
-
 /* stream 4 (Heston QE): pair and uniform from one Philox call -- device twin draw_qe, csrc/svmc_rng.h */
 void svo_draw_qe(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, double *w0, double *w1, double *u)
 {
-    static const double HALF_PI = 1.57079632679489661923;
     uint32_t r[4];
     philox_draw(seed, call_id, path, step, 4u, r);
-    double u1 = m52(r[0] & 0xFFC00000u, r[1]) + 0x1.0p-53;
-    double rr = m52(r[2] & 0xFFC00000u, r[3]) - 0.5;
-    uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
-    *u = (double)k * 0x1.0p-32 + 0x1.0p-33;
-    double R = sqrt(-log(u1));
-    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);
-    double a = c - s, b = c + s;
-    if (r[2] & 1u) a = -a;
-    if (r[2] & 2u) b = -b;
-    *w0 = R * a;
-    *w1 = R * b;
+    pair_from_words(r[0], r[1], w0, w1);
+    *u = ((double)r[2] + 0.5) * 0x1.0p-32;
 }
 
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step)
@@ -432,10 +438,14 @@ void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
                              double theta, double kappa, double rho, double volvol, int scheme,
                              uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset)
 {
-    double sdt = sqrt(dt), rho_1 = sqrt(1.0 - rho * rho), w0, w1;
-    qe_consts c = qe_make_consts(dt, theta, kappa, rho, volvol);
+    const double sdt = sqrt(dt), rho_1 = sqrt(1.0 - rho * rho);
+    const qe_consts c = qe_make_consts(dt, theta, kappa, rho, volvol);
+    /* paths are independent: OpenMP over paths for the full-size parity tests (tests/test_gpu_fullsize.py) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (size_t p = 0; p < n_path; ++p) {
-        double xp = x[p], vp = var[p], qp = qvar[p];
+        double xp = x[p], vp = var[p], qp = qvar[p], w0, w1;
         for (int t = 0; t < nb_steps; ++t) {
             uint32_t step = step_offset + (uint32_t)t;
             if (scheme == SVO_HESTON_QE) {
@@ -475,7 +485,7 @@ void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
             if (brownians) {
                 w = brownians[(size_t)t * ldb + p];
             } else {
-                if ((t & 1) == 0) draw_normals_stream(seed, call_id, path_offset + p, (uint32_t)(t >> 1), 2u, &z0, &z1);
+                if ((t & 1) == 0) draw_normals_stream(seed, call_id, path_offset + p, (uint32_t)(t >> 1), 2u, &z0, &z1);   /* = pair (t >> 1) & 1 of call t >> 2 */
                 w = sdt * ((t & 1) ? z1 : z0);
             }
             L = (L + ((((k1theta / s) - kappa1) + kappa2 * (theta - s)) + adj * s - 0.5 * vartheta2) * dt) + vartheta * w;

@@ -67,6 +67,7 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
 /* ---- counter-based RNG shared (by specification, not by code) with the HIP kernels ------------ */
 
 /* Philox4x32-10 (Salmon et al., SC'11). */
+void svo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* The svmc draw: counter = (path_lo, path_hi, step, stream | call_id << 8), key = seed.

@@ -22,6 +22,9 @@ constexpr int CHAIN_CHUNKS = 20;       // strike chunks (of any expiries) per ch
 // block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
 // 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
 static constexpr int rng_block() { return BLOCK; }
+#ifndef SVMC_RNG_SGPRS
+#define SVMC_RNG_SGPRS 72              // SGPR budget of the LogSV stepping kernels (tools/ubench/ab_kernels.py sweeps it)
+#endif
 static inline unsigned rng_grid(size_t n) { return static_cast<unsigned>((n + rng_block() - 1) / rng_block()); }
 
 static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
@@ -48,13 +51,13 @@ __global__ __launch_bounds__(BLOCK) void fill_normals_kernel(double *__restrict_
     const RngTables tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
-    const uint64_t gp = path_offset + p;
-    for (int t = 0; t < nb_steps; ++t) {
-        double w0, w1;
-        draw_normals(seed, c3, gp, step_offset + static_cast<uint32_t>(t), tab, w0, w1);
-        W0[static_cast<size_t>(t) * ldw + p] = w0;
-        W1[static_cast<size_t>(t) * ldw + p] = w1;
-    }
+    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
+    size_t row = p;
+    rng_time_loop(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
+        W0[row] = w0;
+        W1[row] = w1;
+        row += ldw;
+    });
 }
 
 __global__ __launch_bounds__(BLOCK) void fill_uniforms_kernel(double *__restrict__ U, size_t ldw, size_t n,
@@ -178,7 +181,10 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
     }
 }
 
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
+// DRIFT_IN_Z1: the per-step drift constant rides on the second normal (svmc_models.h logsv_fold_drift; every model with
+// volvol != 0), one VALU instruction per step less; false is the volvol = 0 instantiation.
+template <bool DRIFT_IN_Z1>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
@@ -200,16 +206,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
         const int quarter = (nb_steps + 3) >> 2;
         int stage = 0, next_stage_t = 0;
-        for (int t = 0; t < nb_steps; ++t) {
-            if (t == next_stage_t) {                       // wave-uniform
-                progress_priority(stage++);
-                next_stage_t += quarter;
-            }
-            double z0, z1;
-            draw_normals(lane, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-            logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of);
-        }
-        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s2);
+        rng_time_loop(
+            lane, step_offset, nb_steps, tab, c.z1_shift,
+            [&](double z0, double z1) { logsv_step_acc<DRIFT_IN_Z1>(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
+            [&](int t) {
+                if (t >= next_stage_t) {                   // wave-uniform
+                    progress_priority(stage++);
+                    next_stage_t += quarter;
+                }
+            });
+        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s * s);
         x[p] = xv;
         sigma[p] = s;
         qvar[p] = q;
@@ -230,7 +236,8 @@ struct ChainSlices {
     int m, total_steps;
 };
 
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(72))) void logsv_chain_rng_kernel(
+template <bool DRIFT_IN_Z1>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_chain_rng_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials)
@@ -257,16 +264,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
             double L = log(s) * LOG_UNITS_PER_NAT;                                              // :1039
             double s2 = s * s, acc = 0.0, xacc = 0.0;
             const double s2_start = s2;
-            for (int t = 0; t < nb; ++t) {
-                if (tg + t == next_stage_t) {              // wave-uniform
-                    progress_priority(stage++);
-                    next_stage_t += quarter;
-                }
-                double z0, z1;
-                draw_normals(lane, step_offset + static_cast<uint32_t>(tg + t), tab, z0, z1);
-                logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of);
-            }
-            logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s2);
+            rng_time_loop(
+                lane, step_offset + static_cast<uint32_t>(tg), nb, tab, c.z1_shift,
+                [&](double z0, double z1) { logsv_step_acc<DRIFT_IN_Z1>(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
+                [&](int t) {
+                    if (tg + t >= next_stage_t) {          // wave-uniform
+                        progress_priority(stage++);
+                        next_stage_t += quarter;
+                    }
+                });
+            logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s * s);
         }
         tg += nb;
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
@@ -408,10 +415,13 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
     const double sdt = sqrt(dt);
     const uint64_t gp = path_offset + p;
     double z0 = 0.0, z1 = 0.0;
+    uint32_t r[4] = {0u, 0u, 0u, 0u};
     for (int t = 0; t < nb_steps; ++t) {
         double w;
         if (RNG) {
-            if ((t & 1) == 0) draw_normals(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 1), tab, z0, z1);
+            // one Brownian per step: normal t is component t & 1 of pair (t >> 1) & 1 of call t >> 2 (stream 2)
+            if ((t & 3) == 0) philox_draw(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 2), r);
+            if ((t & 1) == 0) normals_from_words((t & 2) ? r[2] : r[0], (t & 2) ? r[3] : r[1], tab, 0.0, z0, z1);
             w = sdt * ((t & 1) ? z1 : z0);                                                      // :925
         } else {
             w = brownians[static_cast<size_t>(t) * ldb + p];
@@ -547,11 +557,8 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
         }
         if (RNG) {
             const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
-            for (int t = 0; t < nb_steps; ++t) {
-                double z0, z1;
-                draw_normals(lane, step_offset + static_cast<uint32_t>(t), tab, z0, z1);
-                rough_step<N>(c, v, ls, y, z0, z1, exp_of);
-            }
+            rng_time_loop(lane, step_offset, nb_steps, tab,
+                          [&](double z0, double z1) { rough_step<N>(c, v, ls, y, z0, z1, exp_of); });
         } else {
             const double *const w[2] = {Z0 + p, Z1 + p};
             streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1], exp_of); });
@@ -586,20 +593,18 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
-        if (SCHEME != SVMC_HESTON_QE) v = heston_euler_guard_zero(v);
-        for (int t = 0; t < nb_steps; ++t) {
-            const uint32_t step = step_offset + static_cast<uint32_t>(t);
-            double w0, w1;
-            if (SCHEME == SVMC_HESTON_QE) {
-                double u;
-                draw_qe(lane, step, tab, w0, w1, u);
+        if (SCHEME == SVMC_HESTON_QE) {
+            for (int t = 0; t < nb_steps; ++t) {
+                double w0, w1, u;
+                draw_qe(lane, step_offset + static_cast<uint32_t>(t), tab, w0, w1, u);
                 heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
-            } else {
-                draw_normals(lane, step, tab, w0, w1);
-                heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);
             }
+        } else {
+            v = heston_euler_guard_zero(v);
+            rng_time_loop(lane, step_offset, nb_steps, tab,
+                          [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
+            heston_fold_acc(ef, xv, q, xacc, vacc);
         }
-        if (SCHEME != SVMC_HESTON_QE) heston_fold_acc(ef, xv, q, xacc, vacc);
         x[p] = xv;
         var[p] = v;
         qvar[p] = q;
@@ -643,19 +648,18 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
             const QeConsts qc = cs.qc[i];
             const HestonEulerFast ef = make_heston_euler_fast(c);
             double xacc = 0.0, vacc = 0.0;
-            if (SCHEME != SVMC_HESTON_QE) v = heston_euler_guard_zero(v);
-            for (int t = 0; t < nb; ++t) {
-                double w0, w1;
-                if (SCHEME == SVMC_HESTON_QE) {
-                    double u;
+            if (SCHEME == SVMC_HESTON_QE) {
+                for (int t = 0; t < nb; ++t) {
+                    double w0, w1, u;
                     draw_qe(lane, step + static_cast<uint32_t>(t), tab, w0, w1, u);
                     heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
-                } else {
-                    draw_normals(lane, step + static_cast<uint32_t>(t), tab, w0, w1);
-                    heston_euler_step_acc(ef, xacc, v, vacc, w0, w1);
                 }
+            } else {
+                v = heston_euler_guard_zero(v);
+                rng_time_loop(lane, step, nb, tab,
+                              [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
+                heston_fold_acc(ef, xv, q, xacc, vacc);
             }
-            if (SCHEME != SVMC_HESTON_QE) heston_fold_acc(ef, xv, q, xacc, vacc);
         }
         step += static_cast<uint32_t>(nb);
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
@@ -935,10 +939,14 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (int rc = check_state(fn, x, sigma, qvar, nb_steps, dt)) return rc;
     if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
     if (n_path == 0) return SVMC_OK;
-    const LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
+    LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
-    hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
+    if (logsv_fold_drift(c))
+        hipLaunchKernelGGL(logsv_rng_kernel<true>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x,
+                           sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
+    else
+        hipLaunchKernelGGL(logsv_rng_kernel<false>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x,
+                           sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
     return check_launch(fn);
 }
 
@@ -1010,18 +1018,26 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
         if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
             return fail(SVMC_ERR_WORKSPACE, "svmc_logsv_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
         cs.total_steps = 0;
+        bool fold = false;                                 // volvol != 0: the same answer for every slice
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
             const int j = (i < cs.m) ? i0 + i : i0;        // unused entries repeat a valid one
             cs.c[i] = logsv_fast_in_log_units(make_logsv_fast(make_logsv_consts(
                 dts_host[j], theta, kappa1, kappa2, beta, volvol, etas_host ? etas_host[j] : 1.0, is_spot_measure)));
+            fold = logsv_fold_drift(cs.c[i]);
             cs.forward[i] = forwards_host[j];
             cs.nb_steps[i] = (i < cs.m) ? nb_steps_host[j] : 0;
             cs.total_steps += cs.nb_steps[i];
         }
-        hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar, n_path,
-                           cs, seed, make_c3(call_id), path_offset, step_offset, x_snapshots + static_cast<size_t>(i0) * n_path,
-                           qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr,
-                           static_cast<double *>(workspace));
+        double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
+        double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
+        if (fold)
+            hipLaunchKernelGGL(logsv_chain_rng_kernel<true>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
+                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
+                               static_cast<double *>(workspace));
+        else
+            hipLaunchKernelGGL(logsv_chain_rng_kernel<false>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
+                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
+                               static_cast<double *>(workspace));
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;

@@ -256,11 +256,13 @@ struct alignas(16) LogTabEntry {
     double inv_c, neg_log_c;
 };
 
+// EXP2_SCALE: returns -ln(u 2^EXP2_SCALE) -- the scale only shifts the integer exponent, so it is free
+template <int EXP2_SCALE = 0>
 SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
 {
     uint32_t hx = double_hi(u);
     hx += 0x3ff00000u - 0x3fe6a09eu;
-    const int k = static_cast<int>(hx >> 20) - 0x3ff;
+    const int k = static_cast<int>(hx >> 20) - (0x3ff - EXP2_SCALE);
     const uint32_t frac = hx & 0x000fffffu;
     const LogTabEntry e = tab[frac >> 11];
     const double m = bits_to_double(double_lo(u), frac + 0x3fe6a09eu);
@@ -346,6 +348,31 @@ SVMC_HD void cossin_diag_tab(uint32_t sgn, uint32_t lo, uint32_t hi, const DiagT
     const double bm = fma(e.a, sn, e.b * cs);      // in [0, sqrt2)
     a = bits_to_double(double_lo(am), double_hi(am) | (sgn << 31));
     b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((sgn << 30) & 0x80000000u));
+}
+
+// The same direction from ONE 32-bit word (stream version 2): w[31:24] picks the interval j, w[23:2] is the offset
+// inside it, d = ((w & 0x00FFFFFC) + 2) 2^-32 - 2^-9 exactly (|d| < 2^-9, symmetric about the interval midpoint), and
+// w[1:0] are the two sign bits.  Same table, same three-term Taylor tails, same rotation as cossin_diag_tab.
+SVMC_HD void cossin_diag_tab32(uint32_t w, const DiagTabEntry *tab, double &a, double &b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(w));                    // a plain register value (see cossin_diag_tab)
+#endif
+    const DiagTabEntry e = tab[w >> 24];
+    // D = 2^32 d = (w & 0x00FFFFFC) + 2 - 2^23, an exact integer-valued double; the 2^-32 lives in the coefficients
+    const double D = static_cast<double>(w & 0x00FFFFFCu) - (0x1.0p+23 - 2.0);
+    const double z = D * D;
+    double ps = 0x1.466bc6775aae2p-164;            //  (pi/2)^5 / 120   2^-160
+    ps = fma_k(ps, z, -0x1.4abbce625be53p-97);     // -(pi/2)^3 / 6     2^-96
+    ps = fma_k(ps, z, 0x1.921fb54442d18p-32);      //   pi/2            2^-32
+    const double sn = D * ps;                      // sin y,  y = (pi/2) d
+    double pc = 0x1.03c1f081b5ac4p-130;            //  (pi/2)^4 / 24    2^-128
+    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep-64);     // -(pi/2)^2 / 2     2^-64
+    const double cs = fma_k(pc, z, 1.0);           // cos y
+    const double am = fma(-e.b, sn, e.a * cs);     // in (0, sqrt2]
+    const double bm = fma(e.a, sn, e.b * cs);      // in [0, sqrt2)
+    a = bits_to_double(double_lo(am), double_hi(am) | (w << 31));
+    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((w << 30) & 0x80000000u));
 }
 
 }  // namespace svmc

@@ -1,20 +1,30 @@
 // svmc_rng.h -- counter-based randoms for the gfx950 kernels.
 //
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) keyed by the seed and indexed by
-// (global path id, chain-global step id, stream, call id): a lane owns a path, so it derives every
-// increment it needs in registers, no generator state lives in memory and the result is independent of
-// how paths are sharded over GPUs.  Replaces the reference's serial MT19937+polar draw of two
-// [nb_steps, nb_path] arrays (pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370).
+// Philox4x32-7 (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11: seven rounds is
+// the smallest Crush-resistant count of the 4x32 variant, ten the paper's safety default) keyed by the seed and
+// indexed by (global path id, call index, stream, call id): a lane owns a path, so it derives every increment it
+// needs in registers, no generator state lives in memory and the result is independent of how paths are sharded over
+// GPUs.  Replaces the reference's serial MT19937+polar draw of two [nb_steps, nb_path] arrays
+// (pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370).
 //
-// Stream definition (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals):
-//   (r0, r1, r2, r3) = philox4x32_10(ctr = (path_lo, path_hi, step, stream | call_id << 8), key = seed)
-//   u1 = double(1.m) - (1 - 2^-53),  m = top 52 bits of r1:r0          in (0,1), exact
-//   rr = double(1.m) - 1.5,          m = top 52 bits of r3:r2          in [-1/2, 1/2), exact
-//   s0 = -1 if r2 & 1 else +1,  s1 = -1 if r2 & 2 else +1               two sign bits (not used by rr)
-//   stream 0:  R = sqrt(-ln u1), x = (pi/2) rr,  (w0, w1) = R (s0 (cos x - sin x), s1 (cos x + sin x))
+// Stream definition, version 2 (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals).  One call yields
+// four 32-bit words = the Box-Muller pairs of TWO consecutive time steps:
+//   (r0, r1, r2, r3) = philox4x32_7(ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8), key = seed)
+//   (ra, rb) = (r0, r1) for an even chain-global step index, (r2, r3) for an odd one
+//   u1 = (ra + 1/2) 2^-32                                   in (0,1), exact; R = sqrt(-ln u1) <= 4.78 (|z| <= 6.76)
+//   j  = rb >> 24                                           the 256-entry direction table interval
+//   d  = ((rb & 0x00FFFFFC) + 2) 2^-32 - 2^-9               the offset inside it, |d| < 2^-9, 22 bits, symmetric
+//   s0 = -1 if rb & 1 else +1,  s1 = -1 if rb & 2 else +1   two sign bits
+//   x = (pi/2) ((j + 1/2)/256 - 1/2 + d);  (w0, w1) = R (s0 (cos x - sin x), s1 (cos x + sin x))
 //              = sqrt(-2 ln u1) (s0 cos(x + pi/4), s1 sin(x + pi/4)):  a Box-Muller pair whose angle is uniform on the
 //              circle by construction (x + pi/4 uniform on the first quadrant, independent signs)
-//   stream 1:  uniform = u1
+//   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  stream 4 (Heston QE): one call per step, pair from
+//   (r0, r1), the exponential branch's uniform (r2 + 1/2) 2^-32.
+// Resolution: a pair carries 64 random bits (32 radius, 30 angle, 2 signs) where version 1 spent 128 -- the price of
+// halving the generator's share of the VALU-issue-bound stepping loop.  The radius is capped at sqrt(33 ln 2) = 4.78,
+// i.e. |z| <= 6.76: the truncated mass is 1.4e-11 per normal (about 30 draws in 2^41, none expected in one C2 call
+// of 2^31 normals); lattice spacings are 2^-32 in u1 and (pi/2) 2^-30 in the angle -- far below the 1e-4 relative
+// Monte Carlo error of any chain priced here.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -72,12 +82,17 @@ __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&ld
     return RngTables{lds.log, lds.diag};
 }
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&r)[4])
+#ifndef SVMC_PHILOX_ROUNDS
+#define SVMC_PHILOX_ROUNDS 7
+#endif
+constexpr int PHILOX_ROUNDS = SVMC_PHILOX_ROUNDS;
+
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t (&r)[4])
 {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < PHILOX_ROUNDS; ++i) {
         // one v_mad_u64_u32 per 32x32->64 product, one v_bitop3_b32 (xor3) per mixed word
         const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(M1) * c2;
@@ -94,7 +109,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // The same function with the work that does not depend on the step taken out of the time loop.  The counter is
-// (path_lo, path_hi, step, c3): in round 1 the product M0 * path_lo, the word path_hi ^ k0 and the whole new third word
+// (path_lo, path_hi, call index, c3): in round 1 the product M0 * path_lo, the word path_hi ^ k0 and the whole new third word
 // hi(M0 path_lo) ^ c3 ^ k1 are per-lane constants, M1 * step is wave-uniform (scalar unit), and round 2's product
 // M1 * (third word) is a per-lane constant again.  Left to the compiler the xor3's of rounds 1-2 each needed a
 // v_mov to get a second scalar operand in; here round 1 is one v_xor and round 2 one v_xor + one xor3.
@@ -136,6 +151,10 @@ __device__ __forceinline__ void philox_draw(const PhiloxLane &l, uint32_t step, 
     // round 2
     const uint64_t p0 = static_cast<uint64_t>(M0) * c0;
     uint32_t k0 = l.k0, k1 = l.k1;
+    // the round keys are re-derived from (k0, k1) with scalar adds on every call: hoisted out of the time loop (what the
+    // compiler does by itself) they would occupy a dozen SGPRs of a budget the loop already fills, and the spills come
+    // back as v_readlane_b32 -- VALU instructions on the one port this loop is bound by
+    asm volatile("" : "+s"(k0), "+s"(k1));
     c0 = l.hi_b ^ __builtin_amdgcn_readfirstlane(c1_r1 ^ k0);              // (uniform ^ uniform) stays on the scalar unit
     uint32_t c2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), l.lo0, k1, 0x96);
     uint32_t c1 = l.lo_b;
@@ -143,7 +162,7 @@ __device__ __forceinline__ void philox_draw(const PhiloxLane &l, uint32_t step, 
     k0 += W0;
     k1 += W1;
 #pragma unroll
-    for (int i = 2; i < 10; ++i) {
+    for (int i = 2; i < PHILOX_ROUNDS; ++i) {
         const uint64_t q0 = static_cast<uint64_t>(M0) * c0;
         const uint64_t q1 = static_cast<uint64_t>(M1) * c2;
         const uint32_t n0 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(q1 >> 32), c1, k0, 0x96);
@@ -166,46 +185,86 @@ __device__ __forceinline__ double mantissa_1_2(uint32_t lo, uint32_t hi)
     return __hiloint2double(static_cast<int>(mhi), static_cast<int>(mlo));
 }
 
-__device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step, uint32_t (&r)[4])
+__device__ __forceinline__ void philox_draw(uint64_t seed, uint32_t c3, uint64_t path, uint32_t index, uint32_t (&r)[4])
 {
-    philox4x32_10(static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32), step, c3,
-                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+    philox4x32(static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32), index, c3,
+               static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
 }
 
-// the pair from the four words of one Philox call: radius from r1:r0, direction from r3:r2 (+ the sign bits r2 & 3)
-__device__ __forceinline__ void normals_from_words(const uint32_t (&r)[4], const RngTables &t, double &w0, double &w1)
+// (k + 1/2) 2^-32 for a 32-bit word k: exact in fp64, in (0, 1)
+__device__ __forceinline__ double uniform_32(uint32_t k)
 {
-    const double u1 = mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53);
-    const double R = sqrt_pos_1g(neg_log_tab(u1, t.log));  // sqrt(-ln u1): the sqrt2 lives in (a, b)
+    return fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
+}
+
+// One Box-Muller pair from two words: radius from ra, direction (+ the two sign bits) from rb.  `shift1` is added to
+// the second normal inside its final FMA (a model whose update has a constant term beside a multiple of z1 folds the
+// constant in here for free: LogSV's per-step drift constant); 0.0 gives the plain pair.
+__device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double shift1,
+                                                   double &w0, double &w1)
+{
+    // u1 = (ra + 1/2) 2^-32: the half is an inline constant of the add and the 2^-32 an exponent offset of the logarithm
+    const double R = sqrt_pos_1g(neg_log_tab<-32>(static_cast<double>(ra) + 0.5, t.log));  // sqrt(-ln u1): the sqrt2 lives in (a, b)
     double a, b;
-    cossin_diag_tab(r[2], r[2], r[3], t.diag, a, b);
+    cossin_diag_tab32(rb, t.diag, a, b);
     w0 = R * a;
-    w1 = R * b;
+    w1 = fma(R, b, shift1);
 }
 
-// stream 4 (Heston QE): the Box-Muller pair AND the uniform of the exponential branch from ONE Philox call.
-// u1 and the angle keep 42 mantissa bits each (r1 / r3 + the top 10 bits of r0 / r2), the two direction signs are r2 & 1 and r2 & 2, and
-// the 32 bits left over (r0[21:0] : r2[11:2]) make u = (k + 0.5) 2^-32 -- exact in fp64, so the CPU twin gets the
-// same bits.  42-bit radii reach 7.6 sigma; a 32-bit uniform truncates the exponential branch at e^-22.
-__device__ __forceinline__ void qe_from_words(const uint32_t (&r)[4], const RngTables &t, double &w0, double &w1, double &u)
+// The time loop of every on-device-RNG generator: time steps [0, nb) of a lane whose first step has the chain-global
+// index step0.  One Philox call serves the two steps 2c, 2c + 1, so the loop runs over CALLS and each half is guarded by
+// a wave-uniform (scalar) test -- a slice that starts or ends on an odd step simply uses one half of its edge call,
+// and slicing a chain differently never changes which randoms a (path, step) sees.
+// step(z0, z1) advances the model by one time step on UNSCALED N(0,1); tick(t) runs once per call, before it, with
+// the local index of the call's first step in this range (the progress priorities).
+template <class Step, class Tick>
+__device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                              double shift1, Step &&step, Tick &&tick)
 {
-    const double u1 = mantissa_1_2(r[0] & 0xFFC00000u, r[1]) - (1.0 - 0x1.0p-53);
-    const uint32_t k = ((r[0] & 0x3FFFFFu) << 10) | ((r[2] >> 2) & 0x3FFu);
-    u = fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
-    const double R = sqrt_pos_1g(neg_log_tab(u1, t.log));
-    double a, b;
-    cossin_diag_tab(r[2], r[2] & 0xFFC00000u, r[3], t.diag, a, b);
-    w0 = R * a;
-    w1 = R * b;
+    if (nb <= 0) return;
+    const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
+    for (uint32_t c = first >> 1; c <= (last >> 1); ++c) {
+        tick(static_cast<int>(2u * c - first));
+        uint32_t r[4];
+        philox_draw(lane, c, r);
+        double z0, z1;
+        if (2u * c >= first) {
+            normals_from_words(r[0], r[1], tab, shift1, z0, z1);
+            step(z0, z1);
+        }
+        if (2u * c + 1u <= last) {
+            normals_from_words(r[2], r[3], tab, shift1, z0, z1);
+            step(z0, z1);
+        }
+    }
 }
 
-// stream 0: Box-Muller pair of UNSCALED N(0,1)
+template <class Step>
+__device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                              Step &&step)
+{
+    rng_time_loop(lane, step0, nb, tab, 0.0, step, [](int) {});
+}
+
+// stream 0 for a single (path, step), from scratch: Box-Muller pair of UNSCALED N(0,1)  (svmc_fill_normals)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
                                              const RngTables &t, double &w0, double &w1)
 {
     uint32_t r[4];
-    philox_draw(seed, c3, path, step, r);
-    normals_from_words(r, t, w0, w1);
+    philox_draw(seed, c3, path, step >> 1, r);
+    const bool odd = (step & 1u) != 0u;
+    normals_from_words(odd ? r[2] : r[0], odd ? r[3] : r[1], t, 0.0, w0, w1);
+}
+
+// stream 4 (Heston QE): one call per step -- the pair from (r0, r1), the exponential branch's uniform from r2
+// (32 bits: the branch is truncated at e^-22), r3 unused.
+__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
+                                        double &w1, double &u)
+{
+    uint32_t r[4];
+    philox_draw(lane, step, r);
+    normals_from_words(r[0], r[1], t, 0.0, w0, w1);
+    u = uniform_32(r[2]);
 }
 
 __device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
@@ -213,28 +272,11 @@ __device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t pat
 {
     uint32_t r[4];
     philox_draw(seed, c3 | 4u, path, step, r);
-    qe_from_words(r, t, w0, w1, u);
+    normals_from_words(r[0], r[1], t, 0.0, w0, w1);
+    u = uniform_32(r[2]);
 }
 
-// the same pair from a prepared lane state (philox_prepare outside the time loop)
-__device__ __forceinline__ void draw_normals(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
-                                             double &w1)
-{
-    uint32_t r[4];
-    philox_draw(lane, step, r);
-    normals_from_words(r, t, w0, w1);
-}
-
-// draw_qe from a prepared lane state (prepare it with the stream-4 tag: philox_prepare(seed, c3 | 4u, path))
-__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
-                                        double &w1, double &u)
-{
-    uint32_t r[4];
-    philox_draw(lane, step, r);
-    qe_from_words(r, t, w0, w1, u);
-}
-
-// stream 1: one uniform in (0,1)
+// stream 1: one uniform in (0,1) with 52 random bits
 __device__ __forceinline__ double draw_uniform(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step)
 {
     uint32_t r[4];

@@ -17,3 +17,17 @@ ROUGH_CASE = dict(
     strikes_ttms=(_KK, 1.01 * _KK), optiontypes_ttms=(np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"])),
     sigma0=0.377, theta=0.347, kappa1=1.29, kappa2=1.93, beta=2.45, orthog_vol=1.81,
     weights=np.array([0.777, 1.554, 8.516]), nodes=np.array([0.0772, 5.19, 108.46]))
+
+
+def bounded_put_check(x, strikes, types, ref_prices, forward=1.0):
+    """Monte Carlo puts WITHOUT the reference's forward recentring against reference prices (calls mapped through
+    put-call parity, discount factor 1): (|mc - ref| / stderr per strike, stderr).  A put payoff is bounded, so its
+    standard error is honest even where E[S^2] is infinite (Feller-violating Heston sets) -- the recentred estimator of
+    utils/mc_payoffs.py:61-63 subtracts a sample mean of S_T whose variance does not exist there, noise that the
+    per-strike stderr it reports cannot see."""
+    import numpy as np
+    strikes = np.asarray(strikes, dtype=float)
+    ref_put = np.where(np.asarray(types) == "P", ref_prices, ref_prices - (forward - strikes))
+    pay = np.maximum(strikes[None, :] - forward * np.exp(np.asarray(x))[:, None], 0.0)
+    sd = pay.std(axis=0) / np.sqrt(pay.shape[0])
+    return np.abs(pay.mean(axis=0) - ref_put), sd

@@ -204,7 +204,11 @@ def test_payoff_errors(oracle):
 
 
 def test_heston_qe_matches_analytic(oracle, golden):
-    """QE is new relative to the reference: oracle = the reference's analytic Heston price."""
+    """QE is new relative to the reference: oracle = the reference's analytic Heston price, met
+    within 4 standard errors, no additive terms.  Both parameter sets of config C3; BTC_HESTON_PARAMS (volvol 2,
+    rho 0, Feller-violating) has E[S_T^2] = inf around T ~ 1, so the comparison uses puts without the forward
+    recentring (cases.bounded_put_check), whose stderr is honest there; QE-M keeps E[S_T] = F by construction."""
+    from cases import bounded_put_check
     g = golden("analytic")
     n, nb = 1 << 16, 32
     for tag in ("base", "btc"):
@@ -213,13 +217,12 @@ def test_heston_qe_matches_analytic(oracle, golden):
         for i, ttm in enumerate(g["ttms"]):
             x, v, q = oracle.heston_terminal_rng(x, v, q, nb, 0.25 / nb, theta, kappa, rho, volvol, 777,
                                                  scheme=oracle.HESTON_QE, step_offset=i * nb)
-            pr, sd = oracle.payoff(x, q, float(ttm), 1.0, g["strikes"], g["types"])
-            # BTC_HESTON_PARAMS (volvol 2, rho 0): E[S^2] explodes around T ~ 1, the forward recentring is a sample
-            # mean of a variable without variance and the reference's stderr does not see that noise -- one seed in
-            # three lands 6-9 "stderr" (2-6 % of the price) off there; the first three expiries stay tight
-            slack = 0.08 * g[f"heston_{tag}_prices"][i] if (tag == "btc" and i == 3) else 0.0
-            assert np.all(np.abs(pr - g[f"heston_{tag}_prices"][i]) <= 4.0 * sd + 2e-4 + slack), (tag, i)
-            assert abs(np.mean(np.exp(x)) - 1.0) <= 4 * np.std(np.exp(x)) / np.sqrt(n)
+            diff, sd = bounded_put_check(x, g["strikes"], g["types"], g[f"heston_{tag}_prices"][i])
+            assert np.all(diff <= 4.0 * sd + 1e-6), (tag, i, diff / sd)     # 1e-6: deep strikes no sampled path reaches (mc = sd = 0)
+            if tag == "base":     # finite variance: the reference's own recentred estimator meets the same criterion
+                pr, sd = oracle.payoff(x, q, float(ttm), 1.0, g["strikes"], g["types"])
+                assert np.all(np.abs(pr - g[f"heston_{tag}_prices"][i]) <= 4.0 * sd + 1e-6), (tag, i)
+                assert abs(np.mean(np.exp(x)) - 1.0) <= 4 * np.std(np.exp(x)) / np.sqrt(n)
         assert v.min() >= 0.0
 
 

@@ -1,0 +1,59 @@
+"""A/B of the generator kernels between builds of libsvmc on the SAME box, raw ctypes, one library per process:
+
+    python tools/ubench/ab_kernels.py <lib.so> [tag]
+
+Times (HIP events, 12 launches after 3 warm-ups): LogSV on-device RNG at C2 (2^20 x 1024), Heston Euler and QE at C3's
+shape (2^22 x 512, both parameter sets), and the chain-wide payoff pass at C3's shape (2^22 paths x 4 x 21 strikes).
+Only symbols every build since round 1 exports are used."""
+import ctypes as C, json, os, sys
+L = C.CDLL(os.path.abspath(sys.argv[1]))
+tag = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
+vp, f64, sz, i32, u64, u32 = C.c_void_p, C.c_double, C.c_size_t, C.c_int, C.c_uint64, C.c_uint32
+L.svmc_malloc.argtypes = [C.POINTER(vp), sz]
+L.svmc_fill_state.argtypes = [vp, vp, vp, sz, f64, f64, f64, vp]
+L.svmc_logsv_terminal_rng.argtypes = [vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp]
+L.svmc_heston_terminal_rng.argtypes = [vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp]
+L.svmc_event_create.argtypes = [C.POINTER(vp)]
+L.svmc_event_record.argtypes = [vp, vp]
+L.svmc_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+L.svmc_stream_synchronize.argtypes = [vp]
+
+
+def bufs(n, k=3):
+    out = [vp() for _ in range(k)]
+    for x in out:
+        assert L.svmc_malloc(C.byref(x), 8 * n) == 0
+    return out
+
+
+def timed(launch, prep, reps=12, warm=3):
+    for _ in range(warm):
+        prep(); launch()
+    L.svmc_stream_synchronize(None)
+    ts = []
+    for _ in range(reps):
+        prep()
+        e0, e1 = vp(), vp()
+        L.svmc_event_create(C.byref(e0)); L.svmc_event_create(C.byref(e1))
+        L.svmc_event_record(e0, None)
+        assert launch() == 0
+        L.svmc_event_record(e1, None)
+        L.svmc_stream_synchronize(None)
+        ms = C.c_float(); L.svmc_event_elapsed_ms(e0, e1, C.byref(ms)); ts.append(ms.value)
+    return sum(ts) / len(ts), min(ts)
+
+
+res = {"lib": tag}
+n = 1 << 20
+b = bufs(n)
+m, lo = timed(lambda: L.svmc_logsv_terminal_rng(b[0], b[1], b[2], n, 1024, 1 / 1024, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1.0, 1, 7, 0, 0, 0, None),
+              lambda: L.svmc_fill_state(b[0], b[1], b[2], n, 0.0, 0.8376, 0.0, None))
+res["logsv_c2_ms"], res["logsv_c2_min_ms"] = round(m, 4), round(lo, 4)
+n = 1 << 22
+h = bufs(n)
+for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("btc", (0.8, 1.0, 2.0, 0.0, 2.0))):
+    for sname, scheme in (("euler", 0), ("qe", 1)):
+        m, lo = timed(lambda: L.svmc_heston_terminal_rng(h[0], h[1], h[2], n, 512, 1 / 512, th, ka, rho, vv, scheme, 7, 0, 0, 0, None),
+                      lambda: L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, v0, 0.0, None), reps=6, warm=2)
+        res[f"heston_{name}_{sname}_ms"] = round(m, 4)
+print(json.dumps(res), flush=True)
