@@ -353,6 +353,15 @@ def main():
 
     extra = {}
     single = svdist.SingleComm()
+    if world > 1 and isinstance(comm, svdist.TorchComm):
+        # the stream-ordering shortcut of TorchComm (no host synchronisation around the all-reduces) against the
+        # host-synchronised fallback, with real peers: the bits must be identical
+        os.environ["SVMC_DIST_STRICT_SYNC"] = "1"
+        p_strict, _ = step(424242)
+        os.environ["SVMC_DIST_STRICT_SYNC"] = "0"
+        p_ordered, _ = step(424242)
+        extra["stream_ordered_equals_strict_sync"] = bool(all(np.array_equal(a, b) for a, b in zip(p_strict, p_ordered)))
+    extra["comm"] = type(comm).__name__
     if not args.no_extra_legs and (world > 1 or cfg == "c4"):
         # (a) this rank's shard WITHOUT the group: same kernels, no collectives -- the N = 1 rate the weak-scaling ratio
         #     is formed from (all ranks run it concurrently, each on its own GPU; the slowest rank's figure is reported)

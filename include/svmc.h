@@ -44,6 +44,7 @@ extern "C" {
 #define SVMC_ERR_UNKNOWN_PAYOFF 3       /* reference: ValueError("unknown option payoff code"), utils/mc_payoffs.py:84 */
 #define SVMC_ERR_UNSUPPORTED_VARIABLE 4 /* reference: NotImplementedError for VariableType.SIGMA, utils/mc_payoffs.py:69-70 */
 #define SVMC_ERR_WORKSPACE 5
+#define SVMC_ERR_RCCL 6                 /* RCCL missing at run time, or a collective / communicator call failed */
 
 #define SVMC_CALL 0
 #define SVMC_PUT 1
@@ -60,6 +61,7 @@ extern "C" {
 typedef void *svmc_stream_t;  /* hipStream_t */
 typedef void *svmc_session_t; /* opaque: one GPU's resident chain-pricing buffers */
 typedef void *svmc_event_t;  /* hipEvent_t */
+typedef void *svmc_comm_t;   /* ncclComm_t (RCCL) */
 
 /* ---- library / device plumbing (no reference counterpart: the reference is single-process NumPy) -- */
 SVMC_API int svmc_version(void);
@@ -260,8 +262,9 @@ SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_
  * expiries with strike_offsets[n_expiries + 1] delimiting each slice; prices / stderrs come back in the same
  * concatenated layout.  nb_steps_per_year is the reference's rule nb_steps_i = int((T_i - T_{i-1}) * spy) + 1
  * (utils/funcs.py:44).  vol_backbone_etas_host may be NULL (ones).  svmc_session_state copies the terminal state out
- * (x, sigma | variance, qvar; any pointer may be NULL).  The multi-GPU case is driven from the host mirror
- * (stochvolmodels_amd/mc_chain.py), which places the two all-reduces between the same kernels. */
+ * (x, sigma | variance, qvar; any pointer may be NULL).  Multi-GPU: give the session a communicator
+ * (svmc_session_set_comm, below) and the same calls shard the job; the Python host mirror
+ * (stochvolmodels_amd/mc_chain.py) places the same two all-reduces between the same kernels. */
 SVMC_API int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total);
 SVMC_API int svmc_session_destroy(svmc_session_t session);
 SVMC_API int svmc_session_state(svmc_session_t session, double *x_host, double *vol_host, double *qvar_host);
@@ -296,6 +299,36 @@ SVMC_API int svmc_heston_chain_price(svmc_session_t session, const double *ttms_
                                      double theta, double kappa, double rho, double volvol, int scheme,
                                      int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
                                      double *prices_host, double *stderrs_host);
+
+/* ---- multi-GPU below the host language: RCCL over xGMI ----------------------------------------------------------
+ * One process (or thread) per GPU.  Paths are independent, so rank r holds the global path ids
+ * [path_offset, path_offset + n_path) of a job of n_path_total paths in its own session; the counter-based randoms
+ * are indexed by the GLOBAL path id, so the job's result does not depend on how it is sharded.  The only cross-rank
+ * couplings are the two reductions of compute_mc_vars_payoff -- the forward recentring's [sum F exp(x), count] per
+ * expiry (utils/mc_payoffs.py:61-63) and [sum d, sum d^2, count] per strike (:85-86): with a communicator attached,
+ * svmc_logsv_chain_price / svmc_heston_chain_price / svmc_logsv_chain_price_fixed issue them as two in-place fp64
+ * ncclAllReduce(SUM) calls on the session's stream (2 M and 3 sum K_i doubles: a few KB, latency-bound on xGMI),
+ * stream-ordered between the kernels, and every rank returns the job's prices and standard errors.
+ * This is SURVEY.md 8b's design target `svmc_chain_price(... optional RCCL comm handle)`.
+ *
+ * RCCL is resolved at run time: the copy already mapped into the process if there is one (PyTorch-ROCm carries its
+ * own), else librccl.so.1.  A communicator must be driven by the library that created it: create it with
+ * svmc_rccl_comm_create, or make sure a foreign ncclComm_t comes from that same copy (svmc_rccl_origin says which).
+ *   rank 0:     svmc_rccl_unique_id(id, sizeof id)  -> ship the SVMC_RCCL_UNIQUE_ID_BYTES to the other ranks
+ *   every rank: svmc_set_device(r); svmc_rccl_comm_create(&comm, id, sizeof id, world, r);
+ *               svmc_session_create(&s, n_local, ...); svmc_session_set_comm(s, comm, r, world, n_total, offset);
+ *               svmc_logsv_chain_price(s, ...)      -> identical prices on every rank
+ * svmc_session_set_comm(session, NULL, ...) detaches.  Graph replay of the fixed-randoms driver is bypassed while a
+ * communicator is attached. */
+#define SVMC_RCCL_UNIQUE_ID_BYTES 128
+SVMC_API int svmc_rccl_available(void);              /* 1 when an RCCL could be resolved, else 0 (svmc_rccl_origin: why) */
+SVMC_API const char *svmc_rccl_origin(void);         /* where RCCL was resolved from, or the reason it was not */
+SVMC_API int svmc_rccl_unique_id(void *id_out, size_t bytes);
+SVMC_API int svmc_rccl_comm_create(svmc_comm_t *comm, const void *id_bytes, size_t bytes, int world, int rank);
+SVMC_API int svmc_rccl_comm_destroy(svmc_comm_t comm);
+SVMC_API int svmc_rccl_all_reduce_sum(svmc_comm_t comm, double *buf, size_t n, svmc_stream_t stream);
+SVMC_API int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int rank, int world,
+                                   uint64_t n_path_total, uint64_t path_offset);
 
 /* ---- analytic side: affine-expansion MGF + Fourier inversion ------------------
  * Complex arrays are interleaved (re, im) doubles, i.e. numpy.complex128 / C99 double complex, on the device.

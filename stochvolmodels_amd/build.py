@@ -17,7 +17,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libsvmc.so")
-SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip")
+SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip", "svmc_comm.hip")
 HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h", "svmc_log_table.h")
 ARCH = "gfx950"
 

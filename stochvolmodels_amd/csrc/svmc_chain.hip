@@ -28,6 +28,11 @@ struct FixedGraph {
 };
 
 struct Session {
+    // multi-GPU (svmc_session_set_comm): this session holds the paths [path_offset, path_offset + n_path) of a job of
+    // n_total paths spread over `world` ranks; `comm` is the ncclComm_t the two reductions of a chain go through
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+    uint64_t n_total = 0, path_offset = 0;
     bool use_graphs = true;
     size_t graph_launches = 0;
     FixedGraph fixed;
@@ -122,23 +127,36 @@ static int enqueue_payoff_sums(Session *s, const ChainView &c, int variable_type
                                   s->ws, s->ws_bytes, s->stream);
 }
 
-// phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88)
+// phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88); the standard error divides by the
+// path count of the WHOLE job
 static int finalize_prices(const Session *s, const ChainView &c, const double *sums, const std::vector<double> &shifts,
                            double *prices, double *stderrs)
 {
+    const double n_all = static_cast<double>(s->comm != nullptr ? s->n_total : s->n_path);
     for (int i = 0; i < c.m; ++i) {
         const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
-        if (int rc = svmc_payoff_finalize(sums + 3 * k0, shifts.data() + k0, k, c.discfactors[i],
-                                          static_cast<double>(s->n_path), prices + k0, stderrs + k0))
+        if (int rc = svmc_payoff_finalize(sums + 3 * k0, shifts.data() + k0, k, c.discfactors[i], n_all, prices + k0,
+                                          stderrs + k0))
             return rc;
     }
     return SVMC_OK;
 }
 
+// The two cross-rank couplings of compute_mc_vars_payoff, as in-place fp64 sum all-reduces on the session's stream,
+// stream-ordered against the kernels on either side (no host synchronisation): phase 2 = [sum F exp(x), count] per
+// expiry (utils/mc_payoffs.py:61-63), phase 3' = [sum d, sum d^2, count] per strike (:85-86).  No-ops without a comm.
+static int all_reduce(Session *s, double *buf, size_t n)
+{
+    if (s->comm == nullptr || n == 0) return SVMC_OK;
+    return svmc_rccl_all_reduce_sum(s->comm, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
+}
+
 static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type, double *prices, double *stderrs)
 {
+    if (int rc = all_reduce(s, s->spot, 2 * static_cast<size_t>(c.m))) return rc;
     std::vector<double> shifts;
     if (int rc = enqueue_payoff_sums(s, c, variable_type, shifts)) return rc;
+    if (int rc = all_reduce(s, s->sums, 3 * c.offsets[c.m])) return rc;
     std::vector<double> sums(3 * c.offsets[c.m]);
     SVMC_HIP_TRY(hipMemcpyAsync(sums.data(), s->sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
@@ -187,6 +205,29 @@ int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries
     return SVMC_OK;
 }
 
+int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int rank, int world, uint64_t n_path_total,
+                          uint64_t path_offset)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr, "svmc_session_set_comm: null session");
+    if (comm == nullptr) {                     // back to a single-GPU session
+        s->comm = nullptr;
+        s->rank = 0;
+        s->world = 1;
+        s->n_total = 0;
+        s->path_offset = 0;
+        return SVMC_OK;
+    }
+    SVMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "svmc_session_set_comm: need 0 <= rank < world");
+    SVMC_REQUIRE(path_offset + s->n_path <= n_path_total, "svmc_session_set_comm: the session's paths exceed the job");
+    s->comm = comm;
+    s->rank = rank;
+    s->world = world;
+    s->n_total = n_path_total;
+    s->path_offset = path_offset;
+    return SVMC_OK;
+}
+
 int svmc_session_destroy(svmc_session_t session)
 {
     session_release(reinterpret_cast<Session *>(session));
@@ -217,15 +258,15 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
     if (c.m == 1) {       // a single expiry: the plain slice kernel (same bits, and the one bench.py profiles)
         if (int rc = svmc_logsv_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
                                           vol_backbone_etas_host ? vol_backbone_etas_host[0] : 1.0, is_spot_measure, seed,
-                                          call_id, 0, 0, c.forwards[0], s->snap,
+                                          call_id, s->path_offset, 0, c.forwards[0], s->snap,
                                           (variable_type == SVMC_Q_VAR) ? s->snap + n : nullptr, s->spot, s->ws, s->ws_bytes,
                                           s->stream))
             return rc;
         return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
     }
     if (int rc = svmc_logsv_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
-                                      c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id, 0, 0,
-                                      s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
+                                      c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                                      s->path_offset, 0, s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
                                       s->spot, s->ws, s->ws_bytes, s->stream))
         return rc;
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
@@ -245,7 +286,7 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
     if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
     SVMC_REQUIRE(W0s && W1s && nb_steps_host && dts_host, "svmc_logsv_chain_price_fixed: null randoms / grids");
     const size_t n = s->n_path;
-    if (s->use_graphs) {
+    if (s->use_graphs && s->comm == nullptr) {
         // ---- replay path: the launch structure is captured once per (chain, randoms) and replayed per parameter set
         std::vector<unsigned char> key;
         key_append(key, &c.m, 1);
@@ -362,11 +403,11 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
     double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
     if (c.m == 1) {
         if (int rc = svmc_heston_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
-                                           call_id, 0, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
+                                           call_id, s->path_offset, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
                                            s->stream))
             return rc;
     } else if (int rc = svmc_heston_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
-                                              rho, volvol, scheme, seed, call_id, 0, 0, s->snap, qsnap, s->spot, s->ws,
+                                              rho, volvol, scheme, seed, call_id, s->path_offset, 0, s->snap, qsnap, s->spot, s->ws,
                                               s->ws_bytes, s->stream)) {
         return rc;
     }

@@ -96,6 +96,62 @@ class TorchComm:
         return handle[:n].detach().cpu().numpy().copy()
 
 
+class RcclComm:
+    """RCCL through libsvmc's own C ABI (include/svmc.h svmc_rccl_*): the reduction buffers are plain libsvmc device
+    allocations and the collectives are issued by libsvmc on the engine's stream, stream-ordered against its kernels
+    -- no torch tensor and no torch.distributed call in the data path.  The second route beside TorchComm; the one a
+    C / C++ host takes (examples/price_chain_rccl.c) driven from Python.
+
+    `id_bytes`: the SVMC_RCCL_UNIQUE_ID_BYTES of rank 0's svmc_rccl_unique_id(), identical on all ranks (ship them
+    by any means; init_from_env(comm="rccl") broadcasts them over a gloo group)."""
+
+    def __init__(self, rank: int, world: int, id_bytes: bytes):
+        import ctypes as C
+
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.rank, self.world = int(rank), int(world)
+        L = _lib.load()
+        if not L.svmc_rccl_available():
+            raise _lib.SvmcError("RCCL unavailable: " + L.svmc_rccl_origin().decode())
+        buf = C.create_string_buffer(bytes(id_bytes), len(id_bytes))
+        comm = C.c_void_p()
+        _lib.check(L.svmc_rccl_comm_create(C.byref(comm), buf, len(id_bytes), self.world, self.rank))
+        self.handle = comm
+        # RCCL builds its rings lazily at the first collective: do that here, not inside the first chain priced
+        warm = C.c_void_p()
+        _lib.check(L.svmc_malloc(C.byref(warm), 8))
+        _lib.check(L.svmc_memset(warm, 0, 8, None))
+        _lib.check(L.svmc_rccl_all_reduce_sum(self.handle, warm, 1, None))
+        _lib.check(L.svmc_stream_synchronize(None))
+        _lib.check(L.svmc_free(warm))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().svmc_rccl_unique_id(buf, 128))
+        return bytes(buf.raw)
+
+    def alloc(self, engine, n_doubles: int, tag: str):
+        ptr, _owner = engine.alloc_sums(max(int(n_doubles), 1), "rccl_" + tag)
+        return ptr, (ptr, int(n_doubles))
+
+    def all_reduce_sum(self, engine, handle) -> None:
+        ptr, n = handle
+        self._lib.check(self._lib.load().svmc_rccl_all_reduce_sum(self.handle, ptr, n, engine.stream))
+
+    def to_host(self, engine, ptr, handle, n: int):
+        return engine.download(ptr, n)
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self._lib.load().svmc_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
 _default_comm = SingleComm()
 
 
@@ -108,9 +164,16 @@ def set_default_comm(comm) -> None:
     _default_comm = comm if comm is not None else SingleComm()
 
 
-def init_from_env(backend: Optional[str] = None):
+def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
     """one process per GPU launched by torch.distributed.run: bind LOCAL_RANK's GPU, create the process
-    group over RCCL and make it the default communicator of the chain pricers."""
+    group over RCCL and make it the default communicator of the chain pricers.
+
+    comm = "torch" (default): the collectives go through torch.distributed (backend "nccl" = RCCL);
+    comm = "rccl" (or SVMC_DIST_COMM=rccl): they go through libsvmc's own RCCL entry points (RcclComm); the torch
+    process group is then only the bootstrap (a gloo group is enough) that ships rank 0's unique id."""
+    comm = comm or os.environ.get("SVMC_DIST_COMM") or "torch"
+    if comm == "rccl" and backend is None and os.environ.get("SVMC_DIST_BACKEND") is None:
+        backend = "gloo"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 and os.environ.get("SVMC_DIST_SINGLE_RANK_GROUP") != "1":
         set_default_comm(None)
@@ -143,9 +206,14 @@ def init_from_env(backend: Optional[str] = None):
         dist.all_reduce(warm)
         if warm.is_cuda:
             torch.cuda.synchronize(warm.device)
-    comm = TorchComm()
-    _share_rng_seed(comm)
-    set_default_comm(comm)
+    tcomm = TorchComm()
+    _share_rng_seed(tcomm)
+    if comm == "rccl":
+        box = [RcclComm.unique_id() if tcomm.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        set_default_comm(RcclComm(tcomm.rank, tcomm.world, box[0]))
+    else:
+        set_default_comm(tcomm)
     return get_default_comm()
 
 

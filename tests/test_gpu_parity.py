@@ -465,6 +465,135 @@ def test_rccl_group_on_one_rank(oracle, tmp_path):
         np.testing.assert_array_equal(runs[0][key], runs[1][key], err_msg=key)
 
 
+def _run_dist_workers(tmp_path, tag, world, port, extra_env, timeout=300):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / tag)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_dist_worker.py"), out],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=timeout)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            logs.append(p.communicate()[0].decode() + "\n[timeout]")
+    ok = all(p.returncode == 0 for p in procs)
+    return ok, "\n".join(logs), [out + f".rank{r}.npz" for r in range(world)]
+
+
+def test_rccl_through_the_c_abi_one_rank(oracle, tmp_path):
+    """RCCL below Python: a lone rank prices through RcclComm -- libsvmc's own svmc_rccl_* entry points, plain device
+    buffers, collectives issued by libsvmc on the engine's stream -- and must return the single-process oracle
+    result, bit-identical to the torch.distributed route (test_rccl_group_on_one_rank)."""
+    from test_dist_gloo import _expected
+    exp = _expected(oracle)
+    ok, log, files = _run_dist_workers(tmp_path, "cabi", 1, 29741, dict(
+        SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_DIST_COMM="rccl", SVMC_EXPECT_BACKEND="gloo", SVMC_EXPECT_COMM="RcclComm"))
+    assert ok, log
+    got = np.load(files[0])
+    for key in got.files:
+        np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=key)
+    ok, log, files2 = _run_dist_workers(tmp_path, "torch", 1, 29742, dict(
+        SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_EXPECT_BACKEND="nccl"))
+    assert ok, log
+    ref = np.load(files2[0])
+    for key in got.files:
+        np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+
+
+@pytest.mark.parametrize("route", ["rccl", "torch"])
+def test_two_rccl_ranks_on_one_gpu(oracle, tmp_path, route):
+    """a REAL two-rank RCCL communicator, both ranks on this box's single GPU, through either route (libsvmc's C ABI /
+    torch.distributed "nccl").  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then there is
+    nothing to test on a 1-GPU box and the case is skipped; where it is allowed, both ranks must return the
+    single-process oracle result and the stream-ordered and host-synchronised runs must agree bit for bit."""
+    from test_dist_gloo import _expected
+    exp = _expected(oracle)
+    runs = []
+    for k, strict in enumerate(("0", "1")):
+        extra = dict(SVMC_DIST_STRICT_SYNC=strict)
+        extra.update(dict(SVMC_DIST_COMM="rccl", SVMC_EXPECT_COMM="RcclComm") if route == "rccl"
+                     else dict(SVMC_EXPECT_BACKEND="nccl"))
+        ok, log, files = _run_dist_workers(tmp_path, f"{route}{strict}", 2, 29751 + 2 * k + (10 if route == "torch" else 0),
+                                           extra, timeout=180)
+        if not ok:
+            low = log.lower()
+            if "duplicate gpu" in low or "invalid usage" in low or "[timeout]" in low or "nccl" in low or "rccl" in low:
+                pytest.skip("RCCL does not run two ranks on one device here: " + log.strip().splitlines()[-1][:200])
+            assert ok, log
+        got = [np.load(f) for f in files]
+        for r in range(2):
+            for key in got[r].files:
+                np.testing.assert_allclose(got[r][key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} rank {r}")
+        runs.append({k_: got[0][k_] for k_ in got[0].files})
+        if route == "rccl":
+            break                                # the C-ABI route is always stream-ordered: one run
+    if len(runs) == 2:
+        for key in runs[0]:
+            np.testing.assert_array_equal(runs[0][key], runs[1][key], err_msg=key)
+
+
+def test_c_host_rccl_example(sv, tmp_path):
+    """examples/price_chain_rccl.c: a plain-C host drives the multi-GPU path -- its own RCCL communicator, the fused
+    chain drivers issuing the two all-reduces (svmc_session_set_comm).  One rank with a real communicator must match
+    the Python host bit for bit; two ranks on this GPU (where RCCL allows it) must agree with each other and with the
+    one-rank result to reduction-order rounding."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "price_chain_rccl")
+    libdir = os.path.join(root, "stochvolmodels_amd")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "price_chain_rccl.c"),
+                    "-o", exe, "-L" + libdir, "-lsvmc", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"],
+                   check=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    n, seed = 65536, 123
+    one = json.loads(subprocess.run([exe, "1", "0", str(tmp_path / "id1"), str(n), str(seed)], check=True,
+                                    capture_output=True, text=True, env=env, timeout=300).stdout)
+    P_ = sv.LOGSV_BTC_PARAMS
+    ttms, fw, df = np.array([0.1, 0.25]), np.array([1.0, 1.01]), np.array([0.99, 0.98])
+    kk = np.array([0.8, 1.0, 1.2])
+    strikes = (kk, 1.01 * kk)
+    types = (np.array(["P", "C", "C"]), np.array(["IP", "IC", "C"]))
+    pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes, optiontypes_ttms=types,
+                                      v0=P_.sigma0, theta=P_.theta, kappa1=P_.kappa1, kappa2=P_.kappa2, beta=P_.beta,
+                                      volvol=P_.volvol, vol_backbone_etas=np.ones(2), nb_path=n, nb_steps_per_year=120,
+                                      seed=seed)
+    np.testing.assert_array_equal(np.concatenate(pr), one["logsv_prices"])
+    np.testing.assert_array_equal(np.concatenate(sd), one["logsv_stderrs"])
+    pr, sd = sv.heston_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes, optiontypes_ttms=types,
+                                       v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4, nb_path=n, scheme="qe",
+                                       seed=seed)
+    np.testing.assert_array_equal(np.concatenate(pr), one["heston_qe_prices"])
+    np.testing.assert_array_equal(np.concatenate(sd), one["heston_qe_stderrs"])
+    # two ranks, one GPU
+    idf = str(tmp_path / "id2")
+    procs = [subprocess.Popen([exe, "2", str(r), idf, str(n), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.skip("two RCCL ranks on one device did not complete here")
+    if any(p.returncode != 0 for p in procs):
+        pytest.skip("RCCL does not run two ranks on one device here: " + outs[0][1].strip()[-200:] + outs[1][1].strip()[-200:])
+    two = [json.loads(o[0]) for o in outs]
+    for key in ("logsv_prices", "logsv_stderrs", "heston_qe_prices", "heston_qe_stderrs"):
+        np.testing.assert_array_equal(two[0][key], two[1][key], err_msg=key)          # every rank: the job's result
+        np.testing.assert_allclose(two[0][key], one[key], rtol=1e-12, atol=1e-15, err_msg=key)
+
+
 def test_vol_paths(sv, oracle, golden):
     """simulate_vol_paths: reference outputs on supplied brownians; on-device draw vs the CPU twin; the reference's
     own shape / first-row / measure checks (tests/test_logsv_characterization.py:638-673)"""
