@@ -294,10 +294,8 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8)
  *   r0..r3 = philox4x32_7(ctr, key);  (ra, rb) = (r0, r1) for an even step, (r2, r3) for an odd one
  *   u1 = (ra + 1/2) 2^-32                                  in (0,1), exact in fp64
- *   j  = rb >> 24;  d = ((rb & 0x00FFFFFC) + 2) 2^-32 - 2^-9;  x = (pi/2) ((j + 1/2)/256 - 1/2 + d)
- *   s0, s1 = signs from rb & 1, rb & 2
- *   streams 0, 3:  R = sqrt(-ln u1);  w0 = s0 R (cos x - sin x);  w1 = s1 R (cos x + sin x)
- *              (= sqrt(-2 ln u1) (s0 cos, s1 sin)(x + pi/4))
+ *   t  = 2 pi (rb + 1/2) 2^-32                             the angle, uniform on the full circle
+ *   streams 0, 3:  R = sqrt(-ln u1);  w0 = R sqrt2 cos t;  w1 = R sqrt2 sin t    (= sqrt(-2 ln u1) (cos t, sin t))
  *   stream 1:  one call per draw, uniform = ((r0 | r1<<32) >> 12) 2^-52 + 2^-53
  *   stream 2 (vol paths, one Brownian per step): normal t = component t & 1 of pair (t >> 1) & 1 of call t >> 2
  *   stream 4 (Heston QE): one call per step, pair from (r0, r1), uniform (r2 + 1/2) 2^-32
@@ -341,15 +339,11 @@ static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, u
 /* the pair of one (ra, rb) word pair */
 static inline void pair_from_words(uint32_t ra, uint32_t rb, double *w0, double *w1)
 {
-    static const double HALF_PI = 1.57079632679489661923;
+    static const double TWO_PI = 6.28318530717958647693, SQRT2 = 1.41421356237309504880;
     double u1 = ((double)ra + 0.5) * 0x1.0p-32;
-    double d = (double)((rb & 0x00FFFFFCu) + 2u) * 0x1.0p-32 - 0x1.0p-9;
-    double rr = (((double)(rb >> 24) + 0.5) * 0x1.0p-8 - 0.5) + d;    /* exact: in [-1/2, 1/2) */
+    double t = TWO_PI * (((double)rb + 0.5) * 0x1.0p-32);    /* (rb + 1/2) 2^-32 is exact; t in (0, 2 pi) */
     double R = sqrt(-log(u1));                               /* the sqrt2 of sqrt(-2 ln u) lives in (a, b) */
-    double s = sin(HALF_PI * rr), c = cos(HALF_PI * rr);     /* |angle| <= pi/4: no reduction error */
-    double a = c - s, b = c + s;                             /* sqrt2 (cos, sin)(x + pi/4) */
-    if (rb & 1u) a = -a;
-    if (rb & 2u) b = -b;
+    double a = SQRT2 * cos(t), b = SQRT2 * sin(t);
     *w0 = R * a;
     *w1 = R * b;
 }

@@ -8,8 +8,7 @@
 //   neg_log_tab     same, 512-entry table        -> no reciprocal, cubic tail (the RNG's radius)
 //   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
 //   sqrt_pos_1g     same, Goldschmidt step only  -> 2^-47 (the RNG's radius)
-//   cossin_diag_tab raw angle bits + 2 sign bits -> no range reduction, no quadrant swap, 256-entry table
-//   cossin_diag     the same direction, table-free (two 7-term polynomials; kept as the reference form)
+//   cossin_circle_tab32  a raw 32-bit angle   -> no range reduction, no quadrant logic, 256-entry table
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
 //   exp_tab(x)      log-volatilities             -> 256-entry table, quadratic tail, one reduction constant
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
@@ -279,100 +278,39 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
     return fma(-dk, 0x1.62e42fefa39efp-1, nl);
 }
 
-// The direction of a Box-Muller pair, scaled by sqrt2: with x = (pi/2) r, |r| <= 1/2, returns
-//     a = s0 (cos x - sin x) = s0 sqrt2 cos(x + pi/4),    b = s1 (cos x + sin x) = s1 sqrt2 sin(x + pi/4),
-// s0 = -1 if q & 1, s1 = -1 if q & 2.  x + pi/4 is uniform on [0, pi/2) and the two signs are independent fair bits, so
-// (a, b)/sqrt2 is uniform on the circle -- without the quadrant swap (four 32-bit selects) a rotation by q quarter
-// turns needs; the sqrt2 is absorbed by taking the radius as sqrt(-ln u) instead of sqrt(-2 ln u).  Two 7-term
-// even/odd polynomials in r (degree 13 / 14), two FMAs, two sign xors.
-SVMC_HD void cossin_diag(uint32_t q, double r, double &a, double &b)
-{
-    const double z = r * r;
-    double ps = 0x1.e3f38399551bfp-25;
-    ps = fma_k(ps, z, -0x1.e30071afc3e59p-19);
-    ps = fma_k(ps, z, 0x1.50782fda12d96p-13);
-    ps = fma_k(ps, z, -0x1.32d2cce2e5b19p-8);
-    ps = fma_k(ps, z, 0x1.466bc677587f8p-4);
-    ps = fma_k(ps, z, -0x1.4abbce625be41p-1);
-    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);      // sin((pi/2) r) = r ps
-    double pc = -0x1.b2f3eb054afcdp-28;
-    pc = fma_k(pc, z, 0x1.f9ce245cada0bp-22);
-    pc = fma_k(pc, z, -0x1.a6d1eef479be1p-16);
-    pc = fma_k(pc, z, 0x1.e1f5068688d5bp-11);
-    pc = fma_k(pc, z, -0x1.55d3c7e3cb241p-6);
-    pc = fma_k(pc, z, 0x1.03c1f081b5ac0p-2);
-    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);
-    const double c0 = fma_k(pc, z, 1.0);          // cos((pi/2) r)
-    const double am = fma(-ps, r, c0);            // cos - sin = sqrt2 cos(x + pi/4)   in (0, sqrt2]
-    const double bm = fma(ps, r, c0);             // cos + sin = sqrt2 sin(x + pi/4)   in [0, sqrt2)
-    a = bits_to_double(double_lo(am), double_hi(am) ^ (q << 31));
-    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((q << 30) & 0x80000000u));
-}
-
-// The same direction from the raw random words and a table: the angle's 52 mantissa bits are hi[31:0] : lo[31:12]
-// (r = 1.m - 3/2 in [-1/2, 1/2)); the top 8 bits pick the interval j with midpoint r_j = (j + 1/2)/256 - 1/2 and the
-// other 44 give d = r - r_j exactly, |d| <= 2^-9.  With {A_j, B_j} = {cos - sin, cos + sin}((pi/2) r_j) from the table
-// (4 KB, staged in LDS on the device: one ds_read_b128 beside the VALU stream),
-//     a = A_j cos y - B_j sin y,   b = B_j cos y + A_j sin y,   y = (pi/2) d,  |y| <= 0.0031,
-// where sin y needs three Taylor terms and cos y three (next terms 2e-19 / 1e-18 relative): 10 fp64 instructions
-// instead of the 16 of the two degree-13/14 polynomials.  Signs: s0 = -1 if sgn & 1, s1 = -1 if sgn & 2; a > 0 and
-// b >= 0 before the signs go in, so s0 is a plain OR of the sign bit (one v_lshl_or_b32).  Absolute accuracy 5e-16.
-struct alignas(16) DiagTabEntry {
-    double a, b;
+struct alignas(32) CircleTabEntry {
+    double a, b;      // sqrt2 (cos, sin) at the interval midpoint
+    double c;         // the midpoint in units of 2^-32 turns: j 2^24 + 2^23 - 1/2
+    double pad;
 };
 
-SVMC_HD void cossin_diag_tab(uint32_t sgn, uint32_t lo, uint32_t hi, const DiagTabEntry *tab, double &a, double &b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    // keep hi a plain register value: left to itself the compiler re-derives its bit fields from a split of the
-    // Philox multiply that produced it (one more 32-bit multiply per step)
-    asm volatile("" : "+v"(hi));
-    const DiagTabEntry e = tab[hi >> 24];
-    const uint32_t mhi = __builtin_amdgcn_alignbit(0x3ffu, hi, 12) & 0xfff00fffu;
-    const uint32_t mlo = __builtin_amdgcn_alignbit(hi, lo, 12);
-#else
-    const DiagTabEntry e = tab[hi >> 24];
-    const uint32_t mhi = (0x3ff00000u | (hi >> 12)) & 0xfff00fffu;
-    const uint32_t mlo = (hi << 20) | (lo >> 12);
-#endif
-    const double d = bits_to_double(mlo, mhi) - (1.0 + 0x1.0p-9);
-    const double z = d * d;
-    double ps = 0x1.466bc6775aae2p-4;              //  (pi/2)^5 / 120
-    ps = fma_k(ps, z, -0x1.4abbce625be53p-1);      // -(pi/2)^3 / 6
-    ps = fma_k(ps, z, 0x1.921fb54442d18p+0);       //   pi/2
-    const double sn = d * ps;                      // sin y
-    double pc = 0x1.03c1f081b5ac4p-2;              //  (pi/2)^4 / 24
-    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep+0);      // -(pi/2)^2 / 2
-    const double cs = fma_k(pc, z, 1.0);           // cos y
-    const double am = fma(-e.b, sn, e.a * cs);     // in (0, sqrt2]
-    const double bm = fma(e.a, sn, e.b * cs);      // in [0, sqrt2)
-    a = bits_to_double(double_lo(am), double_hi(am) | (sgn << 31));
-    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((sgn << 30) & 0x80000000u));
-}
-
-// The same direction from ONE 32-bit word (stream version 2): w[31:24] picks the interval j, w[23:2] is the offset
-// inside it, d = ((w & 0x00FFFFFC) + 2) 2^-32 - 2^-9 exactly (|d| < 2^-9, symmetric about the interval midpoint), and
-// w[1:0] are the two sign bits.  Same table, same three-term Taylor tails, same rotation as cossin_diag_tab.
-SVMC_HD void cossin_diag_tab32(uint32_t w, const DiagTabEntry *tab, double &a, double &b)
+// The direction of a Box-Muller pair from ONE 32-bit word (stream version 2): the word IS the angle,
+// t = 2 pi (w + 1/2) 2^-32 on the full circle -- no sign bits, no quadrant logic.  w[31:24] picks one of 256 intervals
+// with midpoint t_j = 2 pi (j + 1/2)/256; D = w - (j 2^24 + 2^23 - 1/2) = cvt(w) - center[j] is the offset from it in
+// units of 2^-32 turns, an exact double with |D| < 2^23, and with y = (2 pi 2^-32) D, |y| <= 0.01227:
+//     a = sqrt2 cos t = A_j cos y - B_j sin y,    b = sqrt2 sin t = B_j cos y + A_j sin y,
+// {A_j, B_j, c_j} = {sqrt2 cos t_j, sqrt2 sin t_j, the midpoint} from one 256-entry table of 32-byte entries (8 KB, LDS on
+// the device: a ds_read_b128 and a ds_read_b64 off ONE address, beside the VALU stream).  sin y: three Taylor terms (next: 8e-18 absolute); cos y:
+// four (next: 1e-20); the 2 pi 2^-32 scale lives in the coefficients.  12 VALU instructions + the index.
+// Absolute accuracy 5e-16 on values up to sqrt2.
+SVMC_HD void cossin_circle_tab32(uint32_t w, const CircleTabEntry *tab, double &a, double &b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(w));                    // a plain register value (see cossin_diag_tab)
 #endif
-    const DiagTabEntry e = tab[w >> 24];
-    // D = 2^32 d = (w & 0x00FFFFFC) + 2 - 2^23, an exact integer-valued double; the 2^-32 lives in the coefficients
-    const double D = static_cast<double>(w & 0x00FFFFFCu) - (0x1.0p+23 - 2.0);
+    const CircleTabEntry &e = tab[w >> 24];
+    const double D = static_cast<double>(w) - e.c;
     const double z = D * D;
-    double ps = 0x1.466bc6775aae2p-164;            //  (pi/2)^5 / 120   2^-160
-    ps = fma_k(ps, z, -0x1.4abbce625be53p-97);     // -(pi/2)^3 / 6     2^-96
-    ps = fma_k(ps, z, 0x1.921fb54442d18p-32);      //   pi/2            2^-32
-    const double sn = D * ps;                      // sin y,  y = (pi/2) d
-    double pc = 0x1.03c1f081b5ac4p-130;            //  (pi/2)^4 / 24    2^-128
-    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep-64);     // -(pi/2)^2 / 2     2^-64
+    double ps = 0x1.466bc6775aae2p-154;            //  (2 pi 2^-32)^5 / 120
+    ps = fma_k(ps, z, -0x1.4abbce625be53p-91);     // -(2 pi 2^-32)^3 / 6
+    ps = fma_k(ps, z, 0x1.921fb54442d18p-30);      //   2 pi 2^-32
+    const double sn = D * ps;                      // sin y
+    double pc = -0x1.55d3c7e3cbffap-186;           // -(2 pi 2^-32)^6 / 720
+    pc = fma_k(pc, z, 0x1.03c1f081b5ac4p-122);     //  (2 pi 2^-32)^4 / 24
+    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep-60);     // -(2 pi 2^-32)^2 / 2
     const double cs = fma_k(pc, z, 1.0);           // cos y
-    const double am = fma(-e.b, sn, e.a * cs);     // in (0, sqrt2]
-    const double bm = fma(e.a, sn, e.b * cs);      // in [0, sqrt2)
-    a = bits_to_double(double_lo(am), double_hi(am) | (w << 31));
-    b = bits_to_double(double_lo(bm), double_hi(bm) ^ ((w << 30) & 0x80000000u));
+    a = fma(-e.b, sn, e.a * cs);
+    b = fma(e.a, sn, e.b * cs);
 }
 
 }  // namespace svmc

@@ -12,18 +12,14 @@
 //   (r0, r1, r2, r3) = philox4x32_7(ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8), key = seed)
 //   (ra, rb) = (r0, r1) for an even chain-global step index, (r2, r3) for an odd one
 //   u1 = (ra + 1/2) 2^-32                                   in (0,1), exact; R = sqrt(-ln u1) <= 4.78 (|z| <= 6.76)
-//   j  = rb >> 24                                           the 256-entry direction table interval
-//   d  = ((rb & 0x00FFFFFC) + 2) 2^-32 - 2^-9               the offset inside it, |d| < 2^-9, 22 bits, symmetric
-//   s0 = -1 if rb & 1 else +1,  s1 = -1 if rb & 2 else +1   two sign bits
-//   x = (pi/2) ((j + 1/2)/256 - 1/2 + d);  (w0, w1) = R (s0 (cos x - sin x), s1 (cos x + sin x))
-//              = sqrt(-2 ln u1) (s0 cos(x + pi/4), s1 sin(x + pi/4)):  a Box-Muller pair whose angle is uniform on the
-//              circle by construction (x + pi/4 uniform on the first quadrant, independent signs)
+//   t  = 2 pi (rb + 1/2) 2^-32                              the angle, uniform on the full circle
+//   (w0, w1) = sqrt(-2 ln u1) (cos t, sin t) = R (sqrt2 cos t, sqrt2 sin t):  the Box-Muller pair
 //   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  stream 4 (Heston QE): one call per step, pair from
 //   (r0, r1), the exponential branch's uniform (r2 + 1/2) 2^-32.
-// Resolution: a pair carries 64 random bits (32 radius, 30 angle, 2 signs) where version 1 spent 128 -- the price of
+// Resolution: a pair carries 64 random bits (32 radius, 32 angle) where version 1 spent 128 -- the price of
 // halving the generator's share of the VALU-issue-bound stepping loop.  The radius is capped at sqrt(33 ln 2) = 4.78,
 // i.e. |z| <= 6.76: the truncated mass is 1.4e-11 per normal (about 30 draws in 2^41, none expected in one C2 call
-// of 2^31 normals); lattice spacings are 2^-32 in u1 and (pi/2) 2^-30 in the angle -- far below the 1e-4 relative
+// of 2^31 normals); lattice spacings are 2^-32 in u1 and 2 pi 2^-32 in the angle -- far below the 1e-4 relative
 // Monte Carlo error of any chain priced here.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,21 +30,21 @@
 
 namespace svmc {
 
-// The tables of the draw, constant memory -> LDS once per block: 8 KB for neg_log_tab() and 4 KB for cossin_diag_tab()
-// (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 2 KB
+// The tables of the draw, constant memory -> LDS once per block: 8 KB for neg_log_tab() and 8 KB for
+// cossin_circle_tab32() (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 2 KB
 // with them behind the same barrier.
 __constant__ LogTabEntry g_log_table[512] = {SVMC_LOG_TABLE_INIT};
-__constant__ DiagTabEntry g_diag_table[256] = {SVMC_DIAG_TABLE_INIT};
+__constant__ CircleTabEntry g_circle_table[256] = {SVMC_CIRCLE_TABLE_INIT};   // sqrt2 (cos, sin) and the midpoint of 256 intervals
 __constant__ double g_exp_table[256] = {SVMC_EXP_TABLE_INIT};
 
 struct RngTables {
     const LogTabEntry *log;
-    const DiagTabEntry *diag;
+    const CircleTabEntry *circle;
 };
 
 struct RngTablesLds {
     LogTabEntry log[512];
-    DiagTabEntry diag[256];
+    CircleTabEntry circle[256];
 };
 
 // the log table alone (the streamed Heston QE kernel: its martingale correction takes logs, it draws nothing)
@@ -64,10 +60,10 @@ __device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
         lds.log[i] = g_log_table[i];
         lds.log[i + 256u] = g_log_table[i + 256u];
-        lds.diag[i] = g_diag_table[i];
+        lds.circle[i] = g_circle_table[i];
     }
     __syncthreads();
-    return RngTables{lds.log, lds.diag};
+    return RngTables{lds.log, lds.circle};
 }
 
 __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&lds_exp)[256])
@@ -75,11 +71,11 @@ __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&ld
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
         lds.log[i] = g_log_table[i];
         lds.log[i + 256u] = g_log_table[i + 256u];
-        lds.diag[i] = g_diag_table[i];
+        lds.circle[i] = g_circle_table[i];
     }
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
     __syncthreads();
-    return RngTables{lds.log, lds.diag};
+    return RngTables{lds.log, lds.circle};
 }
 
 #ifndef SVMC_PHILOX_ROUNDS
@@ -197,7 +193,7 @@ __device__ __forceinline__ double uniform_32(uint32_t k)
     return fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
 }
 
-// One Box-Muller pair from two words: radius from ra, direction (+ the two sign bits) from rb.  `shift1` is added to
+// One Box-Muller pair from two words: radius from ra, direction from rb.  `shift1` is added to
 // the second normal inside its final FMA (a model whose update has a constant term beside a multiple of z1 folds the
 // constant in here for free: LogSV's per-step drift constant); 0.0 gives the plain pair.
 __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double shift1,
@@ -206,7 +202,7 @@ __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, con
     // u1 = (ra + 1/2) 2^-32: the half is an inline constant of the add and the 2^-32 an exponent offset of the logarithm
     const double R = sqrt_pos_1g(neg_log_tab<-32>(static_cast<double>(ra) + 0.5, t.log));  // sqrt(-ln u1): the sqrt2 lives in (a, b)
     double a, b;
-    cossin_diag_tab32(rb, t.diag, a, b);
+    cossin_circle_tab32(rb, t.circle, a, b);
     w0 = R * a;
     w1 = fma(R, b, shift1);
 }

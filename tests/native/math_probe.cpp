@@ -4,7 +4,7 @@
 #include "svmc_math.h"
 static const svmc::LogTabEntry LOG_TAB[512] = {SVMC_LOG_TABLE_INIT};
 static const double EXP_TAB[256] = {SVMC_EXP_TABLE_INIT};
-static const svmc::DiagTabEntry DIAG_TAB[256] = {SVMC_DIAG_TABLE_INIT};
+static const svmc::CircleTabEntry CIRCLE_TAB[256] = {SVMC_CIRCLE_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
 void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_tab(x[i], EXP_TAB); }
@@ -14,13 +14,9 @@ void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }
 void probe_sqrt_1g(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos_1g(x[i]); }
 void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
-void probe_sincos(const uint32_t *q, const double *r, double *s, double *c, size_t n)
+// the table-assisted direction from one raw 32-bit angle word
+void probe_circle_tab32(const uint32_t *w, double *a, double *b, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) svmc::cossin_diag(q[i], r[i], c[i], s[i]);   // c <- a = s0 (cos - sin), s <- b = s1 (cos + sin)
-}
-// the table-assisted direction from raw words: sgn carries the two sign bits, hi:lo the 52 angle bits (lo[11:0] unused)
-void probe_diag_tab(const uint32_t *sgn, const uint32_t *lo, const uint32_t *hi, double *a, double *b, size_t n)
-{
-    for (size_t i = 0; i < n; ++i) svmc::cossin_diag_tab(sgn[i], lo[i], hi[i], DIAG_TAB, a[i], b[i]);
+    for (size_t i = 0; i < n; ++i) svmc::cossin_circle_tab32(w[i], CIRCLE_TAB, a[i], b[i]);
 }
 }

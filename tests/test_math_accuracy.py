@@ -137,61 +137,32 @@ def test_sqrt_and_rcp(probe):
     assert float(rel.max()) <= 2.0 ** -45
 
 
-def test_cossin_diag(probe):
-    """the Box-Muller direction: a = s0 (cos x - sin x), b = s1 (cos x + sin x), x = (pi/2) r, signs from two bits
-    of q (other bits of q must not matter): absolute accuracy 3e-16 (values up to sqrt2), i.e. sqrt2 (cos, sin) of
-    x + pi/4 with independent signs"""
-    rng = np.random.default_rng(3)
-    r = np.concatenate([rng.uniform(-0.5, 0.5, N), [-0.5, 0.0, 0.5 - 2.0 ** -53]])
-    n = r.size
-    pi = np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16)
-    x = pi / 2 * r.astype(np.longdouble)
-    for q in (0, 1, 2, 3, 0xFFFFFFFC, 0x80000001, 0x7FFFFFFE):
-        qq = np.full(n, q, dtype=np.uint32)
-        b, a = np.empty(n), np.empty(n)
-        probe.probe_sincos(qq.ctypes.data_as(C.POINTER(C.c_uint32)), r.ctypes.data_as(DP), b.ctypes.data_as(DP),
-                           a.ctypes.data_as(DP), C.c_size_t(n))
-        s0 = -1.0 if q & 1 else 1.0
-        s1 = -1.0 if q & 2 else 1.0
-        assert np.max(np.abs(a - s0 * (np.cos(x) - np.sin(x)))) <= 3e-16
-        assert np.max(np.abs(b - s1 * (np.cos(x) + np.sin(x)))) <= 3e-16
-        np.testing.assert_allclose(np.float64(a * a + b * b), 2.0, rtol=0, atol=1e-15)     # on the circle of radius sqrt2
-
-
-def test_cossin_diag_table(probe):
-    """the table-assisted Box-Muller direction of the stepping kernels, fed with raw random words: r = 1.m - 3/2 with m
-    the top 52 bits of hi:lo, a = s0 (cos x - sin x), b = s1 (cos x + sin x), x = (pi/2) r; signs from sgn & 1, sgn & 2
-    only; absolute accuracy 5e-16 on values up to sqrt2, on the circle of radius sqrt2"""
+def test_cossin_circle_table(probe):
+    """the table-assisted Box-Muller direction of the stepping kernels, fed with raw 32-bit angle words:
+    (a, b) = sqrt2 (cos t, sin t), t = 2 pi (w + 1/2) 2^-32; absolute accuracy 5e-16 on values up to sqrt2, on the
+    circle of radius sqrt2; every table interval probed at both ends"""
     rng = np.random.default_rng(13)
     U32 = C.POINTER(C.c_uint32)
-    hi = rng.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
-    lo = rng.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
+    w = rng.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
     edge = np.arange(256, dtype=np.uint32) << np.uint32(24)                  # both ends of every table interval
-    hi = np.concatenate([hi, edge, edge | np.uint32(0x00FFFFFF), [0, 0xFFFFFFFF]]).astype(np.uint32)
-    lo = np.concatenate([lo, np.zeros(256, np.uint32), np.full(256, 0xFFFFFFFF, np.uint32), [0, 0xFFFFFFFF]]).astype(np.uint32)
-    n = hi.size
-    m = ((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(12)
-    r = m.astype(np.longdouble) * np.longdouble(2.0) ** -52 - np.longdouble(0.5)
+    w = np.concatenate([w, edge, edge | np.uint32(0x00FFFFFF), edge | np.uint32(0x00800000), [0, 0xFFFFFFFF]]).astype(np.uint32)
+    n = w.size
+    a, b = np.empty(n), np.empty(n)
+    probe.probe_circle_tab32(w.ctypes.data_as(U32), a.ctypes.data_as(DP), b.ctypes.data_as(DP), C.c_size_t(n))
+    turn = (w.astype(np.longdouble) + np.longdouble(0.5)) * np.longdouble(2.0) ** -32
+    # reduce in turns before multiplying by 2 pi (80-bit): the argument of cos / sin stays below pi/4 in magnitude
     pi = np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16)
-    x = pi / 2 * r
-    for q in (0, 1, 2, 3, 0xFFFFFFFC, 0x80000001, 0x7FFFFFFE):
-        sgn = np.full(n, q, dtype=np.uint32)
-        a, b = np.empty(n), np.empty(n)
-        probe.probe_diag_tab(sgn.ctypes.data_as(U32), lo.ctypes.data_as(U32), hi.ctypes.data_as(U32),
-                             a.ctypes.data_as(DP), b.ctypes.data_as(DP), C.c_size_t(n))
-        s0 = -1.0 if q & 1 else 1.0
-        s1 = -1.0 if q & 2 else 1.0
-        ea = float(np.max(np.abs(a - s0 * (np.cos(x) - np.sin(x)))))
-        eb = float(np.max(np.abs(b - s1 * (np.cos(x) + np.sin(x)))))
-        assert ea <= 5e-16 and eb <= 5e-16, (ea, eb)
-        np.testing.assert_allclose(np.float64(a * a + b * b), 2.0, rtol=0, atol=1.5e-15)
-    # the low 12 bits of lo are not part of the angle
-    a2, b2 = np.empty(n), np.empty(n)
-    lo2 = (lo & np.uint32(0xFFFFF000)) | np.uint32(0x5A5)
-    probe.probe_diag_tab(sgn.ctypes.data_as(U32), lo2.ctypes.data_as(U32), hi.ctypes.data_as(U32),
-                         a2.ctypes.data_as(DP), b2.ctypes.data_as(DP), C.c_size_t(n))
-    lo3 = lo & np.uint32(0xFFFFF000)
-    a3, b3 = np.empty(n), np.empty(n)
-    probe.probe_diag_tab(sgn.ctypes.data_as(U32), lo3.ctypes.data_as(U32), hi.ctypes.data_as(U32),
-                         a3.ctypes.data_as(DP), b3.ctypes.data_as(DP), C.c_size_t(n))
-    assert np.array_equal(a2, a3) and np.array_equal(b2, b3)
+    q = np.floor(turn * 8 + np.longdouble(0.5))                                  # nearest eighth of a turn
+    y = 2 * pi * (turn - q / 8)
+    cq, sq = np.cos((q / 8 * 2 * pi)), np.sin((q / 8 * 2 * pi))
+    ct = cq * np.cos(y) - sq * np.sin(y)
+    st = sq * np.cos(y) + cq * np.sin(y)
+    r2 = np.sqrt(np.longdouble(2.0))
+    ea = float(np.max(np.abs(a - r2 * ct)))
+    eb = float(np.max(np.abs(b - r2 * st)))
+    assert ea <= 5e-16 and eb <= 5e-16, (ea, eb)
+    np.testing.assert_allclose(np.float64(a * a + b * b), 2.0, rtol=0, atol=1.5e-15)
+    # the direction is uniform on the circle: the eight octants are hit evenly by uniform words
+    octant = (np.arctan2(b[:N], a[:N]) // (np.pi / 4)).astype(int) % 8
+    counts = np.bincount(octant, minlength=8)
+    assert np.all(np.abs(counts - N / 8) < 5 * np.sqrt(N / 8))

@@ -34,6 +34,26 @@ def test_normal_stream_moments(oracle):
     assert abs((a ** 4).mean() - 3) < 4 * np.sqrt(96 / n)
     assert abs(np.corrcoef(W0.ravel(), W1.ravel())[0, 1]) < 4 / np.sqrt(n / 2)
     assert abs(np.corrcoef(W0[:-1].ravel(), W0[1:].ravel())[0, 1]) < 4 / np.sqrt(n / 2)
+    # stream version 2 serves two consecutive steps from ONE Philox call (words r0 r1 | r2 r3) and adjacent lanes from
+    # adjacent counters: lag-1 serial correlation across steps -- inside a call (even -> odd step) and across calls
+    # (odd -> even) separately, for both components and crosswise -- and across adjacent paths
+    bound = 4 / np.sqrt(W0[0::2].size)
+    for A, B in ((W0, W0), (W1, W1), (W0, W1), (W1, W0)):
+        assert abs(np.corrcoef(A[0::2].ravel(), B[1::2].ravel())[0, 1]) < bound          # same call
+        assert abs(np.corrcoef(A[1:-1:2].ravel(), B[2::2].ravel())[0, 1]) < bound        # next call
+        assert abs(np.corrcoef(A[:, :-1].ravel(), B[:, 1:].ravel())[0, 1]) < 4 / np.sqrt(A[:, 1:].size)   # next path
+    # squares too (a generator that leaks magnitude leaks volatility clustering into the paths)
+    assert abs(np.corrcoef((W0[0::2] ** 2).ravel(), (W0[1::2] ** 2).ravel())[0, 1]) < bound
+    assert abs(np.corrcoef((W0[0::2] ** 2).ravel(), (W1[1::2] ** 2).ravel())[0, 1]) < bound
+    # the marginal law, against the exact N(0,1) cdf (Kolmogorov-Smirnov at 1e-3), radius and angle separately
+    from scipy import stats
+    sub = a[:: max(1, n // 400000)]
+    assert stats.kstest(sub, "norm").pvalue > 1e-3
+    r2 = 0.5 * (W0 ** 2 + W1 ** 2).ravel()[::8]                                          # -ln u1: Exp(1)
+    assert stats.kstest(r2, "expon").pvalue > 1e-3
+    ang = (np.arctan2(W1, W0).ravel()[::8] + np.pi) / (2 * np.pi)                       # uniform on the circle
+    assert stats.kstest(ang, "uniform").pvalue > 1e-3
+    assert np.abs(a).max() <= 6.76                                                       # |z| <= sqrt(2 * 33 ln 2)
     U = oracle.fill_uniforms(99, 1 << 15, 8)
     assert 0.0 < U.min() and U.max() < 1.0
     assert abs(U.mean() - 0.5) < 4 / np.sqrt(12 * U.size)
