@@ -15,9 +15,6 @@ namespace svmc {
 
 constexpr int BLOCK = 256;             // 4 waves of 64 lanes
 constexpr int MAX_REDUCE_GRID = 1024;  // 256 CUs x 4 blocks: cap for grid-stride reductions
-constexpr int KC = 8;                  // strikes per payoff block (register accumulators: 3 doubles per strike)
-constexpr int KMAX = 32;               // strikes per payoff launch (grid.y = ceil(k / KC) chunks)
-constexpr int CHAIN_CHUNKS = 20;       // strike chunks (of any expiries) per chain-wide payoff launch: 20 x 192 B of kernarg
 
 // block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
 // 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
@@ -96,9 +93,9 @@ __device__ __forceinline__ void butterfly_halve(const double *v, double *w, int 
     }
 }
 
-// every thread of the block calls; thread j < NV ends up writing the block total of v[j] to out[j]
-template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * NV] */, double *out, int n_out)
+// every thread of the block calls; thread j < n_out ends up with the block total of v[j] and hands it to store(j, total)
+template <int NV, class Store>
+__device__ __forceinline__ void block_sum_apply(double (&v)[NV], double *lds /* [4 * NV] */, int n_out, Store &&store)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     if constexpr (NV % 8 == 0) {
@@ -133,8 +130,15 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* 
         const int j = threadIdx.x;
         double t = lds[j];
         for (int w = 1; w < n_waves; ++w) t += lds[w * NV + j];      // fixed order: wave 0, 1, 2, 3
-        out[j] = t;
+        store(j, t);
     }
+}
+
+// thread j < n_out writes the block total of v[j] to out[j]
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * NV] */, double *out, int n_out)
+{
+    block_sum_apply<NV>(v, lds, n_out, [&](int j, double t) { out[j] = t; });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -574,8 +578,11 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
 // ---------------------------------------------------------------------------------------------------
 // Heston generators (pricers/heston_pricer.py:334-381; QE is new)
 // ---------------------------------------------------------------------------------------------------
+#ifndef SVMC_HESTON_ATTR
+#define SVMC_HESTON_ATTR               // A/B hook (tools/ubench/build_variants.sh): e.g. __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 template <int SCHEME>
-__global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+__global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
                                                            double *__restrict__ qvar, size_t n, int nb_steps,
                                                            HestonConsts c, QeConsts qc, uint64_t seed,
                                                            uint32_t c3, uint64_t path_offset,
@@ -594,11 +601,14 @@ __global__ __launch_bounds__(BLOCK) void heston_rng_kernel(double *__restrict__ 
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
         if (SCHEME == SVMC_HESTON_QE) {
+            double vsum = 0.0;
+            const double v_first = v;
             for (int t = 0; t < nb_steps; ++t) {
                 double w0, w1, u;
                 draw_qe(lane, step_offset + static_cast<uint32_t>(t), tab, w0, w1, u);
-                heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
+                heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return u; });
             }
+            heston_qe_fold(qc, q, vsum, v_first, v);
         } else {
             v = heston_euler_guard_zero(v);
             rng_time_loop(lane, step_offset, nb_steps, tab,
@@ -622,7 +632,7 @@ struct HestonChainSlices {
 };
 
 template <int SCHEME>
-__global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+__global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
                                                                  double *__restrict__ qvar, size_t n,
                                                                  HestonChainSlices cs, uint64_t seed, uint32_t c3,
                                                                  uint64_t path_offset, uint32_t step_offset,
@@ -649,11 +659,14 @@ __global__ __launch_bounds__(BLOCK) void heston_chain_rng_kernel(double *__restr
             const HestonEulerFast ef = make_heston_euler_fast(c);
             double xacc = 0.0, vacc = 0.0;
             if (SCHEME == SVMC_HESTON_QE) {
+                double vsum = 0.0;
+                const double v_first = v;
                 for (int t = 0; t < nb; ++t) {
                     double w0, w1, u;
                     draw_qe(lane, step + static_cast<uint32_t>(t), tab, w0, w1, u);
-                    heston_qe_step(qc, tab.log, xv, v, q, w0, w1, [&]() { return u; });
+                    heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return u; });
                 }
+                heston_qe_fold(qc, q, vsum, v_first, v);
             } else {
                 v = heston_euler_guard_zero(v);
                 rng_time_loop(lane, step, nb, tab,
@@ -701,11 +714,13 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
     const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
-    double xv = x[p], v = var[p], q = qvar[p];
+    double xv = x[p], v = var[p], q = qvar[p], vsum = 0.0;
+    const double v_first = v;
     const double *const w[3] = {Z0 + p, Z1 + p, U + p};
     streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) {
-        heston_qe_step(qc, tab, xv, v, q, z[0], z[1], [&]() { return z[2]; });
+        heston_qe_step(qc, tab, xv, v, vsum, z[0], z[1], [&]() { return z[2]; });
     });
+    heston_qe_fold(qc, q, vsum, v_first, v);
     x[p] = xv;
     var[p] = v;
     qvar[p] = q;
@@ -732,129 +747,128 @@ __global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restri
     block_sum_store<2>(v, lds, partials + 2 * static_cast<size_t>(blockIdx.x), 2);
 }
 
-struct PayoffArgs {
-    double strikes[KMAX];
-    double shifts[KMAX];  // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
-    int8_t types[KMAX];
-    int k;
-};
+// ---- per-strike payoff sums: ONE pass over the terminal values of an expiry for all of its strikes ---------------
+// One block column (blockIdx.y) = one GROUP: up to KT strikes of ONE expiry (an expiry with more strikes is split
+// into several groups); the group descriptor carries that expiry's snapshot pointers, forward and recentring sums.  A
+// thread reads a path's x ONCE and exponentiates it ONCE for all the strikes of the group (round 1 took a pass and an
+// exp per chunk of 8 strikes: three passes for the 21 strikes of the BASELINE chains).
+//   plain payoffs (C / P):  pay = max(sg (u - K), 0), sg = +1 call / -1 put, computed as max(fma(sg, u, -sg K), 0) with sg
+//     a wave-uniform (SGPR) operand of the FMA: fmax returns 0 for a NaN underlying, which is np.where(u > K, u - K, 0)
+//     (:75-82) -- a plain payoff is never NaN, so nanmean / nanstd count EVERY path and the count column is the block's
+//     path count, not an accumulator: 5 VALU instructions per strike per path (fma, max, subtract the shift, two
+//     accumulates) and 4 doubles of vector state per strike (two accumulators, two constants: 192 VGPRs at 24
+//     strikes).  The time loop has NO per-strike condition: the unused strikes of a group carry c = -inf.
+//   inverse payoffs (IC / IP, HAS_INV): pay / spot can be NaN (0/0, inf/inf): per-strike NaN test and count kept.
+constexpr int PAYOFF_GROUPS = 6;       // groups per launch: 6 x 632 B of descriptors stay inside the 4 KB kernarg segment
+constexpr int PAYOFF_KT = 24;          // strikes per group (the BASELINE chains have 21 per expiry)
 
-// grid = (path blocks, strike chunks of KC): every block owns KC strikes of a path range, so the per-strike
-// accumulators stay in 48 VGPRs (8 waves/SIMD) and all strikes of a slice run in ONE launch.  The block's strikes,
-// types and shifts are read from the kernel arguments ONCE, before the path loop (left to the compiler they were
-// re-fetched with a scalar load + wait per strike per path).  HAS_INV = false drops the per-strike division.
-template <bool HAS_INV>
-__global__ __launch_bounds__(BLOCK) void payoff_sums_kernel(const double *__restrict__ x,
-                                                            const double *__restrict__ qvar, size_t n,
-                                                            double forward, double ttm,
-                                                            const double *__restrict__ spot_sums,
-                                                            PayoffArgs pa, int variable_type,
-                                                            double *__restrict__ partials)
-{
-    __shared__ double lds[4 * 3 * KC];
-    const int k0 = blockIdx.y * KC;
-    const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
-    const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
-    double acc[3 * KC], K[KC], shift[KC];
-    bool is_call[KC], is_inv[KC], live[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-        live[k] = k0 + k < pa.k;
-        const int kk = live[k] ? k0 + k : 0;
-        K[k] = pa.strikes[kk];
-        shift[k] = pa.shifts[kk];
-        const int ty = pa.types[kk];
-        is_call[k] = ty == SVMC_CALL || ty == SVMC_INV_CALL;
-        is_inv[k] = ty == SVMC_INV_CALL || ty == SVMC_INV_PUT;
-    }
-#pragma unroll
-    for (int j = 0; j < 3 * KC; ++j) acc[j] = 0.0;
-    const bool need_q = variable_type != SVMC_LOG_RETURN;
-
-    for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
-        const double spot = forward * exp(x[i]) - corr;                                         // :61-63
-        const double u = need_q ? qvar[i] / ttm : spot;                                         // :65-68
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            if (live[k]) {                                                                      // block-uniform
-                double pay = is_call[k] ? ((u > K[k]) ? (u - K[k]) : 0.0)                       // :75-78
-                                        : ((u < K[k]) ? (K[k] - u) : 0.0);                      // :79-82
-                if (HAS_INV && is_inv[k]) pay = pay / spot;
-                if (pay == pay) {                                                               // nanmean/nanstd
-                    const double d = pay - shift[k];
-                    acc[3 * k + 0] += d;
-                    acc[3 * k + 1] = fma(d, d, acc[3 * k + 1]);
-                    acc[3 * k + 2] += 1.0;
-                }
-            }
-        }
-    }
-    const int n_out = 3 * ((pa.k - k0 < KC) ? (pa.k - k0) : KC);
-    block_sum_store<3 * KC>(acc, lds, partials + static_cast<size_t>(blockIdx.x) * (3 * KMAX) + 3 * k0, n_out);
-}
-
-// ---- all expiries of a chain in one launch ----------------------------------------------------------------------
-// One block column (blockIdx.y) = one chunk of <= KC strikes of ONE expiry; the chunk descriptor carries that expiry's
-// snapshot pointers, forward and recentring sums.  Same per-lane path order, block reduction and column reduce as
-// payoff_sums_kernel, hence the same bits -- but 2 launches per chain instead of 2 per expiry.
-struct PayoffChunk {
+struct PayoffGroup {
     const double *x, *qvar, *spot_sums;
     double forward, ttm;
-    double strikes[KC], shifts[KC];
-    int8_t types[KC];
-    int k;      // live strikes in this chunk
-    int col;    // first output column of the chunk within this launch (in strikes)
+    double sg[PAYOFF_KT];      // +1 call, -1 put: pay = max(fma(sg, u, c), 0)
+    double c[PAYOFF_KT];       // -sg K; -inf for the unused strikes of a group (their payoff is 0 and their sums are dropped)
+    double shift[PAYOFF_KT];   // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
+    uint32_t inv_mask;         // bit k set: divide by the recentred spot (IC / IP)
+    int k;                     // live strikes in this group
+    int col;                   // first output column of the group within this launch (in strikes)
 };
-struct PayoffChunkPack {
-    PayoffChunk c[CHAIN_CHUNKS];
+struct PayoffGroupPack {
+    PayoffGroup g[PAYOFF_GROUPS];
 };
 
-template <bool HAS_INV>
-__global__ __launch_bounds__(BLOCK) void payoff_chain_kernel(PayoffChunkPack pack, size_t n, int variable_type,
+// number of indices i < n visited by block b of a grid-stride loop (stride = grid * BLOCK, BLOCK consecutive per block)
+__device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigned grid)
+{
+    const size_t stride = static_cast<size_t>(grid) * BLOCK, lo = static_cast<size_t>(b) * BLOCK;
+    const size_t full = n / stride, rem = n % stride;
+    const size_t part = (rem > lo) ? ((rem - lo < static_cast<size_t>(BLOCK)) ? rem - lo : BLOCK) : 0;
+    return static_cast<double>(full * BLOCK + part);
+}
+
+template <int KT, bool HAS_INV>
+__global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pack, size_t n, int variable_type,
                                                              double *__restrict__ partials, int ld)
 {
-    __shared__ double lds[4 * 3 * KC];
-    const PayoffChunk &d = pack.c[blockIdx.y];
+    constexpr int NACC = HAS_INV ? 3 : 2;
+    __shared__ double lds[4 * NACC * KT];
+    const PayoffGroup &d = pack.g[blockIdx.y];
     const double *__restrict__ x = d.x;
     const double *__restrict__ qvar = d.qvar;
-    const double forward = d.forward, ttm = d.ttm;
+    const double forward = d.forward, inv_ttm_arg = d.ttm;
     const double corr = d.spot_sums[0] / d.spot_sums[1] - forward;                              // :62
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
     const int nk = d.k;
-    double acc[3 * KC], K[KC], shift[KC];
-    bool is_call[KC], is_inv[KC], live[KC];
+    const uint32_t inv_mask = d.inv_mask;
+    double acc[NACC * KT], sg[KT], c[KT], shift[KT];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) {
-        live[k] = k < nk;
-        K[k] = d.strikes[k];
-        shift[k] = d.shifts[k];
-        const int ty = d.types[k];
-        is_call[k] = ty == SVMC_CALL || ty == SVMC_INV_CALL;
-        is_inv[k] = ty == SVMC_INV_CALL || ty == SVMC_INV_PUT;
+    for (int k = 0; k < KT; ++k) {
+        sg[k] = d.sg[k];                                   // stays wave-uniform: the scalar operand of the FMA
+        c[k] = d.c[k];
+        shift[k] = d.shift[k];
+        // these two live in VECTOR registers: left wave-uniform the compiler keeps all three constants in SGPRs, runs
+        // out (3 x 24 doubles) and re-reads the spills with v_readlane_b32 -- VALU instructions on top of the five
+        // per strike per path that do the work
+        asm volatile("" : "+v"(c[k]), "+v"(shift[k]));
     }
 #pragma unroll
-    for (int j = 0; j < 3 * KC; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NACC * KT; ++j) acc[j] = 0.0;
     const bool need_q = variable_type != SVMC_LOG_RETURN;
 
-    for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
-        const double spot = forward * exp(x[i]) - corr;                                         // :61-63
-        const double u = need_q ? qvar[i] / ttm : spot;                                         // :65-68
+    // one path's contribution to every strike of the group
+    const auto add_path = [&](double xi, double qi) {
+        const double spot = forward * exp(xi) - corr;                                           // :61-63
+        const double u = need_q ? qi / inv_ttm_arg : spot;                                      // :65-68
 #pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            if (live[k]) {
-                double pay = is_call[k] ? ((u > K[k]) ? (u - K[k]) : 0.0)                       // :75-78
-                                        : ((u < K[k]) ? (K[k] - u) : 0.0);                      // :79-82
-                if (HAS_INV && is_inv[k]) pay = pay / spot;
+        for (int k = 0; k < KT; ++k) {
+            double pay = fmax(fma(sg[k], u, c[k]), 0.0);                                        // :75-82
+            if (HAS_INV) {
+                if (inv_mask & (1u << k)) pay = pay / spot;
                 if (pay == pay) {                                                               // nanmean/nanstd
                     const double dd = pay - shift[k];
-                    acc[3 * k + 0] += dd;
-                    acc[3 * k + 1] = fma(dd, dd, acc[3 * k + 1]);
-                    acc[3 * k + 2] += 1.0;
+                    acc[k] += dd;
+                    acc[KT + k] = fma(dd, dd, acc[KT + k]);
+                    acc[2 * KT + k] += 1.0;
                 }
+            } else {
+                const double dd = pay - shift[k];
+                acc[k] += dd;
+                acc[KT + k] = fma(dd, dd, acc[KT + k]);
             }
         }
+    };
+#ifdef SVMC_PAYOFF_PAIRS
+    // two paths per trip: their loads are issued together and their two independent exp / payoff chains interleave
+    size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    for (; i + stride < n; i += 2 * stride) {
+        const double x0 = x[i], x1 = x[i + stride];
+        const double q0 = need_q ? qvar[i] : 0.0, q1 = need_q ? qvar[i + stride] : 0.0;
+        add_path(x0, q0);
+        add_path(x1, q1);
     }
-    block_sum_store<3 * KC>(acc, lds, partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col, 3 * nk);
+    if (i < n) add_path(x[i], need_q ? qvar[i] : 0.0);
+#else
+    size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    double xn = (i < n) ? x[i] : 0.0, qn = (need_q && i < n) ? qvar[i] : 0.0;
+    for (; i < n; i += stride) {
+        const double xi = xn, qi = qn;
+        if (i + stride < n) {                              // the next path's loads fly while this one is worked on
+            xn = x[i + stride];
+            if (need_q) qn = qvar[i + stride];
+        }
+        add_path(xi, qi);
+    }
+#endif
+    (void)nk;
+    // output row layout: [sum d, sum d^2, count] per strike, interleaved, at column 3 (col + k)
+    double *row = partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col;
+    const double cnt = block_path_count(n, blockIdx.x, gridDim.x);
+    block_sum_apply<NACC * KT>(acc, lds, NACC * KT, [&](int j, double t) {
+        const int which = j / KT, k = j - which * KT;
+        if (k < nk) {
+            row[3 * k + which] = t;
+            if (!HAS_INV && which == 0) row[3 * k + 2] = cnt;
+        }
+    });
 }
 
 // out[j] = sum_r partials[r * ld + j]; one block per column j
@@ -1361,7 +1375,7 @@ int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_pat
 int svmc_payoff_workspace_bytes(size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_payoff_workspace_bytes: null output");
-    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * CHAIN_CHUNKS * sizeof(double);   // >= 3 * KMAX columns too
+    *bytes = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double);
     return SVMC_OK;
 }
 
@@ -1369,7 +1383,7 @@ int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
     const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
-    const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * KC * CHAIN_CHUNKS * sizeof(double);
+    const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;
 }
@@ -1388,6 +1402,96 @@ int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_
     return check_launch("svmc_spot_sums");
 }
 
+}  // extern "C"
+
+// the launches of svmc_payoff_sums / svmc_payoff_sums_chain: groups of <= PAYOFF_KT strikes of one expiry, <= PAYOFF_GROUPS
+// groups per launch, every launch followed by its column reduce
+template <bool HAS_INV>
+static void launch_payoff_groups(int kt, dim3 grid, hipStream_t st, const PayoffGroupPack &pack, size_t n, int variable_type,
+                                 double *partials, int ld)
+{
+    if (kt <= 8)
+        hipLaunchKernelGGL((payoff_group_kernel<8, HAS_INV>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials, ld);
+    else if (kt <= 16)
+        hipLaunchKernelGGL((payoff_group_kernel<16, HAS_INV>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials, ld);
+    else if (!HAS_INV)      // inverse chains are grouped by 16 (payoff_sums_impl): their third accumulator would not fit
+        hipLaunchKernelGGL((payoff_group_kernel<PAYOFF_KT, false>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials,
+                           ld);
+}
+
+static int payoff_sums_impl(const char *fn, const double *const *xs, const double *const *qs, size_t n_path,
+                            const double *forwards, const double *ttms, const double *spot_sums, int n_expiries,
+                            const double *strikes, const int8_t *types, const double *shifts, const size_t *offsets,
+                            int variable_type, double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    const size_t total = offsets[n_expiries];
+    bool any_inv = false;
+    for (size_t k = 0; k < total; ++k) {
+        if (types[k] < SVMC_CALL || types[k] > SVMC_INV_PUT)
+            return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
+        any_inv = any_inv || types[k] >= SVMC_INV_CALL;
+    }
+    // strikes per group: 24 for plain chains (two accumulators per strike); 16 when the chain holds inverse options
+    // (three accumulators per strike: 24 of them would leave one wave per SIMD)
+    const size_t KG = any_inv ? 16 : PAYOFF_KT;
+    const unsigned g = reduce_grid(n_path);
+    if (workspace_bytes < static_cast<size_t>(g) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_payoff_workspace_bytes)");
+    if (n_path == 0 || total == 0) return SVMC_OK;
+    double *partials = static_cast<double *>(workspace);
+    PayoffGroupPack pack;
+    memset(&pack, 0, sizeof(pack));
+    int n_groups = 0, cols = 0, kt = 0;         // groups, strike columns and widest group of the pending launch
+    size_t first_strike = 0;                    // global index of the pending launch's first strike
+    bool has_inv = false;
+    auto flush = [&]() -> int {
+        if (n_groups == 0) return SVMC_OK;
+        const dim3 grid(g, static_cast<unsigned>(n_groups));
+        if (has_inv)
+            launch_payoff_groups<true>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
+        else
+            launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
+                           static_cast<int>(g), 3 * cols, sums + 3 * first_strike);
+        first_strike += static_cast<size_t>(cols);
+        n_groups = cols = kt = 0;
+        has_inv = false;
+        return check_launch(fn);
+    };
+    for (int i = 0; i < n_expiries; ++i) {
+        if (xs[i] == nullptr) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot");
+        for (size_t k0 = offsets[i]; k0 < offsets[i + 1]; k0 += KG) {
+            PayoffGroup &d = pack.g[n_groups];
+            d.x = xs[i];
+            d.qvar = (variable_type == SVMC_Q_VAR) ? qs[i] : nullptr;
+            d.spot_sums = spot_sums + 2 * i;
+            d.forward = forwards[i];
+            d.ttm = ttms[i];
+            const size_t left = offsets[i + 1] - k0;
+            d.k = static_cast<int>(left < KG ? left : KG);
+            d.col = cols;
+            d.inv_mask = 0u;
+            for (int k = 0; k < PAYOFF_KT; ++k) {
+                const bool on = k < d.k;
+                const int ty = on ? types[k0 + k] : SVMC_CALL;
+                const double sgn = (ty == SVMC_CALL || ty == SVMC_INV_CALL) ? 1.0 : -1.0;
+                d.sg[k] = sgn;
+                d.c[k] = on ? -sgn * strikes[k0 + k] : -__builtin_huge_val();      // unused: pay = max(u - inf, 0) = 0
+                d.shift[k] = (on && shifts != nullptr) ? shifts[k0 + k] : 0.0;
+                if (on && (ty == SVMC_INV_CALL || ty == SVMC_INV_PUT)) d.inv_mask |= 1u << k;
+            }
+            has_inv = has_inv || d.inv_mask != 0u;
+            cols += d.k;
+            kt = (d.k > kt) ? d.k : kt;
+            if (++n_groups == PAYOFF_GROUPS)
+                if (int rc = flush()) return rc;
+        }
+    }
+    return flush();
+}
+
+extern "C" {
+
 int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double forward, double ttm,
                      const double *spot_sums, const double *strikes_host, const int8_t *types_host,
                      const double *shifts_host, size_t n_strikes, int variable_type, double *sums, void *workspace,
@@ -1398,34 +1502,9 @@ int svmc_payoff_sums(const double *x, const double *qvar, size_t n_path, double 
     SVMC_REQUIRE(x && spot_sums && sums && workspace, "svmc_payoff_sums: null pointer");
     SVMC_REQUIRE(variable_type != SVMC_Q_VAR || qvar != nullptr, "svmc_payoff_sums: Q_VAR needs qvar");
     SVMC_REQUIRE(n_strikes == 0 || (strikes_host && types_host), "svmc_payoff_sums: null strikes/types");
-    for (size_t k = 0; k < n_strikes; ++k)
-        if (types_host[k] < SVMC_CALL || types_host[k] > SVMC_INV_PUT)
-            return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
-    const unsigned g = reduce_grid(n_path);
-    if (workspace_bytes < static_cast<size_t>(g) * 3 * KMAX * sizeof(double))
-        return fail(SVMC_ERR_WORKSPACE, "svmc_payoff_sums: workspace too small (svmc_payoff_workspace_bytes)");
-    double *partials = static_cast<double *>(workspace);
-    for (size_t k0 = 0; k0 < n_strikes; k0 += KMAX) {
-        PayoffArgs pa;
-        pa.k = static_cast<int>((n_strikes - k0 < static_cast<size_t>(KMAX)) ? (n_strikes - k0) : KMAX);
-        for (int k = 0; k < KMAX; ++k) {
-            pa.strikes[k] = (k < pa.k) ? strikes_host[k0 + k] : 0.0;
-            pa.shifts[k] = (k < pa.k && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
-            pa.types[k] = (k < pa.k) ? types_host[k0 + k] : 0;
-        }
-        const unsigned chunks = static_cast<unsigned>((pa.k + KC - 1) / KC);
-        bool has_inv = false;
-        for (int k = 0; k < pa.k; ++k) has_inv = has_inv || pa.types[k] == SVMC_INV_CALL || pa.types[k] == SVMC_INV_PUT;
-        if (has_inv)
-            hipLaunchKernelGGL(payoff_sums_kernel<true>, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar,
-                               n_path, forward, ttm, spot_sums, pa, variable_type, partials);
-        else
-            hipLaunchKernelGGL(payoff_sums_kernel<false>, dim3(g, chunks), dim3(BLOCK), 0, as_stream(stream), x, qvar,
-                               n_path, forward, ttm, spot_sums, pa, variable_type, partials);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * pa.k), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(g), 3 * KMAX, sums + 3 * k0);
-    }
-    return check_launch("svmc_payoff_sums");
+    const size_t offsets[2] = {0, n_strikes};
+    return payoff_sums_impl("svmc_payoff_sums", &x, &qvar, n_path, &forward, &ttm, spot_sums, 1, strikes_host, types_host,
+                            shifts_host, offsets, variable_type, sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
@@ -1434,7 +1513,6 @@ int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const double *
                            const double *shifts_host, const size_t *strike_offsets_host, int variable_type,
                            double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
-    const char *fn = "svmc_payoff_sums_chain";
     if (variable_type != SVMC_LOG_RETURN && variable_type != SVMC_Q_VAR)
         return fail(SVMC_ERR_UNSUPPORTED_VARIABLE, "svmc_payoff_sums_chain: variable_type must be LOG_RETURN or Q_VAR");
     SVMC_REQUIRE(x_snapshots_host && forwards_host && ttms_host && spot_sums && strike_offsets_host && sums && workspace,
@@ -1443,59 +1521,9 @@ int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const double *
     SVMC_REQUIRE(variable_type != SVMC_Q_VAR || qvar_snapshots_host != nullptr, "svmc_payoff_sums_chain: Q_VAR needs qvar");
     const size_t total = strike_offsets_host[n_expiries];
     SVMC_REQUIRE(total == 0 || (strikes_host && types_host), "svmc_payoff_sums_chain: null strikes/types");
-    for (size_t k = 0; k < total; ++k)
-        if (types_host[k] < SVMC_CALL || types_host[k] > SVMC_INV_PUT)
-            return fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
-    const unsigned g = reduce_grid(n_path);
-    if (workspace_bytes < static_cast<size_t>(g) * 3 * KC * CHAIN_CHUNKS * sizeof(double))
-        return fail(SVMC_ERR_WORKSPACE, "svmc_payoff_sums_chain: workspace too small (svmc_payoff_workspace_bytes)");
-    if (n_path == 0 || total == 0) return SVMC_OK;
-    double *partials = static_cast<double *>(workspace);
-    PayoffChunkPack pack;
-    int n_chunks = 0, cols = 0;                 // chunks and strike columns gathered for the pending launch
-    size_t first_strike = 0;                    // global index of the pending launch's first strike
-    bool has_inv = false;
-    auto flush = [&]() -> int {
-        if (n_chunks == 0) return SVMC_OK;
-        const dim3 grid(g, static_cast<unsigned>(n_chunks));
-        if (has_inv)
-            hipLaunchKernelGGL(payoff_chain_kernel<true>, grid, dim3(BLOCK), 0, as_stream(stream), pack, n_path,
-                               variable_type, partials, 3 * cols);
-        else
-            hipLaunchKernelGGL(payoff_chain_kernel<false>, grid, dim3(BLOCK), 0, as_stream(stream), pack, n_path,
-                               variable_type, partials, 3 * cols);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(g), 3 * cols, sums + 3 * first_strike);
-        first_strike += static_cast<size_t>(cols);
-        n_chunks = cols = 0;
-        has_inv = false;
-        return check_launch(fn);
-    };
-    for (int i = 0; i < n_expiries; ++i) {
-        SVMC_REQUIRE(x_snapshots_host[i] != nullptr, "svmc_payoff_sums_chain: null snapshot");
-        for (size_t k0 = strike_offsets_host[i]; k0 < strike_offsets_host[i + 1]; k0 += KC) {
-            PayoffChunk &d = pack.c[n_chunks];
-            d.x = x_snapshots_host[i];
-            d.qvar = (variable_type == SVMC_Q_VAR) ? qvar_snapshots_host[i] : nullptr;
-            d.spot_sums = spot_sums + 2 * i;
-            d.forward = forwards_host[i];
-            d.ttm = ttms_host[i];
-            const size_t left = strike_offsets_host[i + 1] - k0;
-            d.k = static_cast<int>(left < static_cast<size_t>(KC) ? left : KC);
-            d.col = cols;
-            for (int k = 0; k < KC; ++k) {
-                const bool on = k < d.k;
-                d.strikes[k] = on ? strikes_host[k0 + k] : 0.0;
-                d.shifts[k] = (on && shifts_host != nullptr) ? shifts_host[k0 + k] : 0.0;
-                d.types[k] = on ? types_host[k0 + k] : 0;
-                has_inv = has_inv || (on && (d.types[k] == SVMC_INV_CALL || d.types[k] == SVMC_INV_PUT));
-            }
-            cols += d.k;
-            if (++n_chunks == CHAIN_CHUNKS)
-                if (int rc = flush()) return rc;
-        }
-    }
-    return flush();
+    return payoff_sums_impl("svmc_payoff_sums_chain", x_snapshots_host, qvar_snapshots_host, n_path, forwards_host, ttms_host,
+                            spot_sums, n_expiries, strikes_host, types_host, shifts_host, strike_offsets_host, variable_type,
+                            sums, workspace, workspace_bytes, stream);
 }
 
 int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes, double discfactor,

@@ -255,7 +255,7 @@ __device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double
 
 // ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------
 struct QeConsts {
-    double dt, theta, E, c1, c2, K1, K2, K3, K4, A, K0_plain, K13;
+    double dt, theta, E, c1, c2, K1m, K2, K3, K4, A, twoA, K0_plain, K13;
 };
 
 inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho, double volvol)
@@ -269,56 +269,114 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     c.E = E;
     c.c1 = volvol * volvol * E * (1.0 - E) / kappa;
     c.c2 = theta * volvol * volvol * (1.0 - E) * (1.0 - E) / (2.0 * kappa);
-    c.K1 = g1 * dt * kre - rho / volvol;
+    const double K1 = g1 * dt * kre - rho / volvol;
     c.K2 = g2 * dt * kre + rho / volvol;
     c.K3 = g1 * dt * (1.0 - rho * rho);
     c.K4 = g2 * dt * (1.0 - rho * rho);
     c.A = c.K2 + 0.5 * c.K4;
+    c.twoA = 2.0 * c.A;
     c.K0_plain = -rho * kappa * theta / volvol * dt;
-    c.K13 = c.K1 + 0.5 * c.K3;
+    c.K13 = K1 + 0.5 * c.K3;
+    c.K1m = K1 - c.K13;                                   // the martingale correction's -K13 v0 rides on the K1 v0 term
     return c;
 }
 
-// z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential branch (the
-// streamed kernel loads it only in waves that have a lane there; the on-device draw gets it from the same Philox call).  Quotients are reciprocal + one Newton
-// step (2^-48: far inside the 1e-9 the parity tests state), logs go through the LDS table (absolute accuracy
-// 1e-19 on arguments near 1, which is what the martingale correction feeds it), the square roots stop after the
-// Goldschmidt step (2^-47: the scheme matches two moments of the variance, not its bits); the
-// arithmetic order is the CPU twin's.
+// ln(1 - e) for the martingale correction ln(1 - 2 A a): |e| is O(volvol^2 dt) on any sane grid, where eight series
+// terms (next: e^9 / 9 <= 6e-18 at the 2^-6 switch) replace the table logarithm; larger |e| take the table.
+__device__ __forceinline__ double log_one_minus(double e, double one_minus_e, const LogTabEntry *tab)
+{
+    if (fabs(e) < 0x1.0p-6) {
+        double p = 0x1.0000000000000p-3;                  // 1/8
+        p = fma_k(p, e, 0x1.2492492492492p-3);            // 1/7
+        p = fma_k(p, e, 0x1.5555555555555p-3);            // 1/6
+        p = fma_k(p, e, 0x1.999999999999ap-3);            // 1/5
+        p = fma_k(p, e, 0x1.0000000000000p-2);            // 1/4
+        p = fma_k(p, e, 0x1.5555555555555p-2);            // 1/3
+        p = fma_k(p, e, 0x1.0000000000000p-1);            // 1/2
+        p = fma_k(p, e, 1.0);
+        return -e * p;
+    }
+    return -neg_log_tab(one_minus_e, tab);
+}
+
+// One QE-M step.  z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential
+// branch (the streamed kernel loads it only in waves that have a lane there; the on-device draw gets it from the same
+// Philox call).  The scheme's quotients are regrouped so that each branch takes ONE hardware reciprocal (two with a
+// martingale correction in the exponential branch) where the textbook form -- the CPU twin's -- takes three to five:
+//   quadratic (psi = s2/m^2 <= 3/2), with w = 2 m^2 - s2, Q = sqrt(2 m^2 w), N = w + Q = s2 b^2, T = 2 m^2 + Q = s2 (1 + b^2):
+//     a = m s2 / T,   v1 = a (b + z1)^2 = (m / T) (N + 2 sqrt(N s2) z1 + s2 z1^2),
+//     1 - 2 A a = dn / T with dn = T - 2 A m s2,   A b^2 a / (1 - 2 A a) = A m N / dn;   1/T and 1/dn from rcp(T dn)
+//   exponential, with D = s2 + m^2:  p = (s2 - m^2)/D,  1 - p = 2 m^2/D,  beta = 2 m/D,  u <= p  <=>  u D <= s2 - m^2,
+//     v1 = ln(2 m^2 / (D (1 - u))) D / (2 m);   1/(D (1 - u)) and 1/m from rcp(D (1 - u) m);
+//     p + beta (1 - p)/(beta - A) = ((s2 - m^2) e + 4 m m^2) / (D e),  e = 2 m - A D;   1/(D e) is the second reciprocal.
+// Identical in exact arithmetic to the twin; reciprocals are seed + one Newton step (2^-48), square roots stop after the
+// Goldschmidt step (2^-47: the scheme matches two moments of the variance, not its bits), logs go through the LDS
+// table.  The quadratic variance is dt (sum of the new variances + (v_first - v_last)/2): the caller keeps `vsum` and
+// folds it in (heston_qe_fold); x carries the martingale correction with its -K13 v0 term folded into K1m.
 template <class DrawU>
 __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEntry *tab, double &x, double &var,
-                                               double &qvar, double z0, double z1, DrawU &&draw_u)
+                                               double &vsum, double z0, double z1, DrawU &&draw_u)
 {
     const double v0 = var;
-    const double m = c.theta + (v0 - c.theta) * c.E;
-    const double s2 = v0 * c.c1 + c.c2;
+    const double m = fma(v0 - c.theta, c.E, c.theta);
+    const double s2 = fma(v0, c.c1, c.c2);
     const double m2 = m * m;
-    double v1, K0;
-    if (s2 <= 1.5 * m2) {                                 // psi = s2/m^2 <= psi_c, decided without the divide
-        const double ip = 2.0 * m2 * rcp_1n(s2);          // 2/psi >= 4/3
-        const double b2 = ip - 1.0 + sqrt_pos_1g(ip * (ip - 1.0));
-        const double a = m * rcp_1n(1.0 + b2);
-        const double b = sqrt_pos_1g(b2);
-        v1 = a * (b + z1) * (b + z1);
+    double v1, K0;                                        // K0 without its -K13 v0 term
+    if (s2 <= 1.5 * m2) {                                 // psi <= psi_c, decided without the divide
+        const double tm2 = m2 + m2;
+        const double w = tm2 - s2;                        // >= m^2 / 2
+        const double Q = sqrt_pos_1g(tm2 * w);
+        const double N = w + Q, T = tm2 + Q;
+        const double g = sqrt_pos_1g(N * s2);
+        const double t = fma(z1, fma(s2, z1, g + g), N);  // (sqrt N + sqrt s2 z1)^2 up to rounding: clamped at 0 below
         if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
-            K0 = -c.K13 * v0;
+            v1 = fmax((m * rcp_1n(T)) * t, 0.0);
+            K0 = 0.0;
         } else {
-            const double den = 1.0 - 2.0 * c.A * a;
-            K0 = (den > 0.0) ? (-c.A * b2 * a * rcp_1n(den) - 0.5 * neg_log_tab(den, tab) - c.K13 * v0) : c.K0_plain;
+            const double ams2 = (c.twoA * m) * s2;
+            const double dn = T - ams2;                   // T (1 - 2 A a)
+            if (dn > 0.0) {
+                const double r = rcp_1n(T * dn);
+                const double invT = dn * r, invD = T * r;
+                v1 = fmax((m * invT) * t, 0.0);
+                const double ln_den = log_one_minus(ams2 * invT, dn * invT, tab);
+                K0 = fma(-(c.A * m) * N, invD, 0.5 * ln_den);
+            } else {
+                v1 = fmax((m * rcp_1n(T)) * t, 0.0);
+                K0 = fma(c.K13, v0, c.K0_plain);          // the plain drift: cancels the folded -K13 v0
+            }
         }
     } else {
         const double u = draw_u();
-        const double p = (s2 - m2) * rcp_1n(s2 + m2);     // (psi - 1)/(psi + 1)
-        const double bt = (1.0 - p) * rcp_1n(m);
-        v1 = (u <= p) ? 0.0 : -neg_log_tab((1.0 - p) * rcp_1n(1.0 - u), tab) * rcp_1n(bt);
-        if (c.A == 0.0)
-            K0 = -c.K13 * v0;
-        else
-            K0 = (c.A < bt) ? (neg_log_tab(p + bt * (1.0 - p) * rcp_1n(bt - c.A), tab) - c.K13 * v0) : c.K0_plain;
+        const double D = s2 + m2, dm = s2 - m2;
+        const bool zero = (u * D <= dm);                  // u <= p
+        const double q1 = D * (1.0 - u);
+        const double r = rcp_1n(q1 * m);
+        const double iq1 = m * r, im = q1 * r;            // 1/(D (1 - u)),  1/m
+        const double lg = neg_log_tab((m2 + m2) * iq1, tab);   // -ln((1 - p)/(1 - u)): <= 0 wherever u > p
+        v1 = zero ? 0.0 : (-lg) * ((0.5 * D) * im);
+        if (c.A == 0.0) {
+            K0 = 0.0;
+        } else {
+            const double e = fma(-c.A, D, m + m);         // D (beta - A)
+            if (e > 0.0) {
+                const double r2 = rcp_1n(D * e);
+                K0 = neg_log_tab(fma(dm, e, 4.0 * m * m2) * r2, tab);
+            } else {
+                K0 = fma(c.K13, v0, c.K0_plain);
+            }
+        }
     }
-    x = x + K0 + c.K1 * v0 + c.K2 * v1 + sqrt_pos0_1g(c.K3 * v0 + c.K4 * v1) * z0;
-    qvar = qvar + 0.5 * c.dt * (v0 + v1);
+    const double sq = sqrt_pos0_1g(fma(c.K4, v1, c.K3 * v0));
+    x = fma(sq, z0, fma(c.K2, v1, fma(c.K1m, v0, x + K0)));
+    vsum = vsum + v1;
     var = v1;
+}
+
+// qvar += dt * sum_t (v_{t-1} + v_t)/2 over the steps since vsum was zero (v_first = the variance they started from)
+__device__ __forceinline__ void heston_qe_fold(const QeConsts &c, double &qvar, double vsum, double v_first, double v_last)
+{
+    qvar = fma(c.dt, fma(0.5, v_first - v_last, vsum), qvar);
 }
 
 }  // namespace svmc

@@ -56,4 +56,31 @@ for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("bt
         m, lo = timed(lambda: L.svmc_heston_terminal_rng(h[0], h[1], h[2], n, 512, 1 / 512, th, ka, rho, vv, scheme, 7, 0, 0, 0, None),
                       lambda: L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, v0, 0.0, None), reps=6, warm=2)
         res[f"heston_{name}_{sname}_ms"] = round(m, 4)
+# ---- the chain-wide payoff pass at C3's shape: 4 expiries x 21 strikes over 2^22 paths each (P below 1, C at/above) ----
+import numpy as np
+pd, pi8, psz = C.POINTER(C.c_double), C.POINTER(C.c_int8), C.POINTER(C.c_size_t)
+L.svmc_slice_workspace_bytes.argtypes = [sz, psz]
+L.svmc_spot_sums.argtypes = [vp, sz, f64, vp, vp, sz, vp]
+L.svmc_memcpy_d2d.argtypes = [vp, vp, sz, vp]
+L.svmc_payoff_sums_chain.argtypes = [C.POINTER(vp), C.POINTER(vp), sz, pd, pd, vp, i32, pd, pi8, pd, psz, i32, vp, vp, sz, vp]
+wsb = C.c_size_t()
+assert L.svmc_slice_workspace_bytes(n, C.byref(wsb)) == 0
+ws, spot, sums = vp(), vp(), vp()
+assert L.svmc_malloc(C.byref(ws), wsb.value) == 0 and L.svmc_malloc(C.byref(spot), 64) == 0 and L.svmc_malloc(C.byref(sums), 8 * 3 * 84) == 0
+L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, 0.04, 0.0, None)
+L.svmc_heston_terminal_rng(h[0], h[1], h[2], n, 64, 1 / 256, 0.04, 4.0, -0.5, 0.4, 0, 7, 0, 0, 0, None)
+snaps = bufs(n, 4)
+for i in range(4):
+    L.svmc_memcpy_d2d(snaps[i], h[0], 8 * n, None)
+    assert L.svmc_spot_sums(snaps[i], n, 1.0, vp(spot.value + 16 * i), ws, wsb.value, None) == 0
+kk = np.tile(np.linspace(0.5, 1.5, 21), 4)
+ty = np.where(kk >= 1.0, 0, 1).astype(np.int8)
+sh = np.where(ty == 0, np.maximum(1.0 - kk, 0), np.maximum(kk - 1.0, 0))
+offs = (C.c_size_t * 5)(0, 21, 42, 63, 84)
+fw, tt = np.ones(4), np.array([0.25, 0.5, 0.75, 1.0])
+xs = (vp * 4)(*[b_.value for b_ in snaps])
+m, lo = timed(lambda: L.svmc_payoff_sums_chain(xs, None, n, fw.ctypes.data_as(pd), tt.ctypes.data_as(pd), spot, 4,
+                                               kk.ctypes.data_as(pd), ty.ctypes.data_as(pi8), sh.ctypes.data_as(pd), offs, 1,
+                                               sums, ws, wsb.value, None), lambda: None, reps=20, warm=3)
+res["payoff_c3_us"], res["payoff_c3_min_us"] = round(1e3 * m, 2), round(1e3 * lo, 2)
 print(json.dumps(res), flush=True)

@@ -7,13 +7,13 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -fno-gpu-rdc -mllvm --align-all-blocks=4 -DSVMC_BUILDING=1 -Wno-unused-function"
 build() {  # name, source root, extra flags
   local name=$1 root=$2; shift 2
-  /opt/rocm/bin/hipcc $FLAGS -I$root/include -I$root/stochvolmodels_amd/csrc "$@" $root/stochvolmodels_amd/csrc/svmc_runtime.hip \
-     $root/stochvolmodels_amd/csrc/svmc_kernels.hip $root/stochvolmodels_amd/csrc/svmc_analytic.hip $root/stochvolmodels_amd/csrc/svmc_chain.hip -o $OUT/libsvmc_$name.so &
+  /opt/rocm/bin/hipcc $FLAGS -I$root/include -I$root/stochvolmodels_amd/csrc "$@" $root/stochvolmodels_amd/csrc/svmc_*.hip -o $OUT/libsvmc_$name.so &
 }
-if [ -n "$BASE_REF" ]; then            # a previous commit as the A side
-  rm -rf /tmp/svmc_base && mkdir -p /tmp/svmc_base && git -C $R archive $BASE_REF include stochvolmodels_amd/csrc | tar -x -C /tmp/svmc_base
-  build base /tmp/svmc_base
-fi
+for b in ${BASES:-}; do                # previous commits as A sides: BASES="r1=f00a54f preqe=db02c7b"
+  name=${b%%=*}; ref=${b#*=}
+  rm -rf /tmp/svmc_$name && mkdir -p /tmp/svmc_$name && git -C $R archive $ref include stochvolmodels_amd/csrc | tar -x -C /tmp/svmc_$name
+  build $name /tmp/svmc_$name
+done
 build cur $R
 for v in "$@"; do                      # name=flags...   e.g. r10=-DSVMC_PHILOX_ROUNDS=10
   name=${v%%=*}; fl=${v#*=}
