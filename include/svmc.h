@@ -346,6 +346,19 @@ SVMC_API int svmc_logsv_mgf_grid(const double *phi, const double *psi, size_t n_
                                  double theta, double kappa1, double kappa2, double beta, double volvol,
                                  int is_spot_measure, int expansion_order, double vol_backbone_eta, double *a,
                                  double *log_mgf, double rtol, double atol, svmc_stream_t stream);
+/* Batched over parameter sets: n_sets independent LogSV models advance their transform grids over the same interval in
+ * ONE launch (the five sets of config C5; the bumped parameter vectors of a finite-difference gradient).  Set s has its
+ * own grid phi / psi [s][n_grid] (the grid scale follows sigma0), coefficients a [s][n_grid][n_coef] and output log_mgf
+ * [s][n_grid]; params_host [s][SVMC_LOGSV_SET_DOUBLES] = {sigma0, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta,
+ * reserved}.  svmc_mgf_vanilla_slice_batch: the strike sums of every set for one (forward, strikes) slice, capped
+ * [s][n_strikes].  Results are bit-identical to n_sets single calls. */
+#define SVMC_LOGSV_SET_DOUBLES 8
+SVMC_API int svmc_logsv_mgf_grid_batch(const double *phi, const double *psi, size_t n_grid, int n_sets, double ttm,
+                                       const double *params_host, int is_spot_measure, int expansion_order, double *a,
+                                       double *log_mgf, double rtol, double atol, svmc_stream_t stream);
+SVMC_API int svmc_mgf_vanilla_slice_batch(const double *phi, const double *log_mgf, size_t n_grid, int n_sets,
+                                          double forward, const double *strikes_host, size_t n_strikes, double *capped,
+                                          svmc_stream_t stream);
 SVMC_API int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double v0,
                                   double theta, double kappa, double volvol, double rho, double *a, double *b,
                                   int have_t0, double *log_mgf, svmc_stream_t stream);

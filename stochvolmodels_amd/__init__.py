@@ -41,6 +41,7 @@ _EXPORTS = {
     "CalibrationEngine": "pricers.logsv_pricer",
     "CalibrationError": "utils.calibration",
     "logsv_chain_pricer": "pricers.logsv_pricer", "set_vol_scaler": "pricers.logsv_pricer",
+    "logsv_chain_pricer_batch": "pricers.logsv_pricer",
     "ExpansionOrder": "pricers.logsv.affine_expansion", "compute_logsv_a_mgf_grid": "pricers.logsv.affine_expansion",
     "heston_chain_pricer": "pricers.heston_pricer", "compute_heston_mgf_grid": "pricers.heston_pricer",
     "HestonPricer": "pricers.heston_pricer", "HestonParams": "pricers.heston_pricer",

@@ -80,6 +80,8 @@ def _declare(L: C.CDLL) -> None:
                                     sz, vp], i32),
         "svmc_payoff_sums": ([vp, vp, sz, f64, f64, vp, pf64, pi8, pf64, sz, i32, vp, vp, sz, vp], i32),
         "svmc_logsv_mgf_grid": ([vp, vp, sz, f64, f64, f64, f64, f64, f64, f64, i32, i32, f64, vp, vp, f64, f64, vp], i32),
+        "svmc_logsv_mgf_grid_batch": ([vp, vp, sz, i32, f64, pf64, i32, i32, vp, vp, f64, f64, vp], i32),
+        "svmc_mgf_vanilla_slice_batch": ([vp, vp, sz, i32, f64, pf64, sz, vp, vp], i32),
         "svmc_heston_mgf_grid": ([vp, vp, sz, f64, f64, f64, f64, f64, f64, vp, vp, i32, vp, vp], i32),
         "svmc_mgf_qvar_slice": ([vp, vp, sz, f64, pf64, sz, vp, vp], i32),
         "svmc_mgf_vanilla_slice": ([vp, vp, sz, f64, pf64, sz, vp, vp], i32),

@@ -105,6 +105,58 @@ class AnalyticGrid:
                 b.free()
 
 
+class AnalyticGridBatch:
+    """the transform grids of SEVERAL LogSV parameter sets resident on the device, advanced expiry by expiry in one
+    launch per expiry (svmc_logsv_mgf_grid_batch) and inverted in one launch per expiry (svmc_mgf_vanilla_slice_batch):
+    config C5's five sets, or the bumped parameter vectors of a finite-difference gradient, side by side.  Bit-identical
+    to one AnalyticGrid per set."""
+
+    def __init__(self, phis: Sequence[np.ndarray], psis: Sequence[np.ndarray], n_coef: int):
+        self.lib = _lib.load()
+        self.n_sets = len(phis)
+        self.n = int(np.asarray(phis[0]).size)
+        self.n_coef = int(n_coef)
+        phi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in phis]))
+        psi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in psis]))
+        assert phi.shape == psi.shape == (self.n_sets, self.n)
+        self.phi, self.psi = DeviceBuffer(2 * phi.size), DeviceBuffer(2 * psi.size)
+        for buf, z in ((self.phi, phi), (self.psi, psi)):
+            _lib.check(self.lib.svmc_memcpy_h2d(buf.ptr, z.ctypes.data, z.nbytes, None))
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        self.a = DeviceBuffer(2 * self.n_sets * self.n * self.n_coef)
+        self.log_mgf = DeviceBuffer(2 * self.n_sets * self.n)
+        _lib.check(self.lib.svmc_memset(self.a.ptr, 0, self.a.nbytes, None))
+        self._capped: Optional[DeviceBuffer] = None
+
+    def logsv_advance(self, ttm: float, params_rows: np.ndarray, is_spot_measure: bool, expansion_order: int) -> None:
+        """params_rows [n_sets][8] = (sigma0, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, 0)"""
+        rows = np.ascontiguousarray(params_rows, dtype=np.float64)
+        assert rows.shape == (self.n_sets, 8)
+        _lib.check(self.lib.svmc_logsv_mgf_grid_batch(self.phi.ptr, self.psi.ptr, self.n, self.n_sets, float(ttm),
+                                                      rows.ctypes.data_as(C.POINTER(C.c_double)), int(bool(is_spot_measure)),
+                                                      int(expansion_order), self.a.ptr, self.log_mgf.ptr, ODE_RTOL,
+                                                      ODE_ATOL, None))
+
+    def capped_sums(self, forward: float, strikes: np.ndarray) -> np.ndarray:
+        """-> [n_sets][n_strikes]"""
+        strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+        k = strikes.size
+        if self._capped is None or self._capped.n < k * self.n_sets:
+            self._capped = DeviceBuffer(max(k * self.n_sets, 32))
+        _lib.check(self.lib.svmc_mgf_vanilla_slice_batch(self.phi.ptr, self.log_mgf.ptr, self.n, self.n_sets, float(forward),
+                                                         strikes.ctypes.data_as(C.POINTER(C.c_double)), k, self._capped.ptr,
+                                                         None))
+        out = np.empty((self.n_sets, k))
+        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, out.nbytes, None))
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        return out
+
+    def close(self) -> None:
+        for b in (self.phi, self.psi, self.a, self.log_mgf, self._capped):
+            if b is not None:
+                b.free()
+
+
 def vanilla_prices_from_capped(capped: np.ndarray, forward: float, strikes: np.ndarray, optiontypes: Sequence,
                                discfactor: float, is_spot_measure: bool) -> np.ndarray:
     """the payoff algebra of vanilla_slice_pricer_with_mgf_grid, reference utils/mgf_pricer.py:199-219"""

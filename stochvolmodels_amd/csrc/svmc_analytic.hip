@@ -172,26 +172,39 @@ __device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
 }
 
 constexpr int AB = 64;  // one wave per block: 1000 grid points spread over 16 CUs
+constexpr int MAX_ODE_SETS = 16;       // parameter sets per launch (kernel-argument block: 16 x 112 B)
+
+// The parameter sets of one launch: blockIdx.y picks the set, every set has its own transform grid (the grid scale
+// follows sigma0), coefficients and output.  One set's 1000 lanes occupy 16 of the chip's 1024 SIMDs for the latency
+// of its slowest lane; independent sets -- the five of config C5, the bumps of a finite-difference gradient -- cost
+// nothing extra side by side.
+struct OdeBatch {
+    OdeConsts c[MAX_ODE_SETS];
+    double y0[MAX_ODE_SETS];           // sigma0 - theta
+};
 
 __global__ __launch_bounds__(AB) void logsv_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
-                                                            size_t n_grid, double ttm, OdeConsts c, double y0,
+                                                            size_t n_grid, double ttm, OdeBatch sets,
                                                             cd *__restrict__ a, cd *__restrict__ log_mgf, double rtol,
                                                             double atol)
 {
     const size_t j = static_cast<size_t>(blockIdx.x) * AB + threadIdx.x;
     if (j >= n_grid) return;
+    const OdeConsts c = sets.c[blockIdx.y];
+    const double y0 = sets.y0[blockIdx.y];
+    const size_t g = static_cast<size_t>(blockIdx.y) * n_grid + j;     // this set's grid point
     const int n = c.second ? 5 : 3;
     cd A[5] = {C(0.0), C(0.0), C(0.0), C(0.0), C(0.0)};
-    for (int k = 0; k < n; ++k) A[k] = a[j * n + k];
-    dopri5(c, phi[j], psi[j], ttm, A, rtol, atol);
+    for (int k = 0; k < n; ++k) A[k] = a[g * n + k];
+    dopri5(c, phi[g], psi[g], ttm, A, rtol, atol);
     cd lm = C(0.0);
     double yk = 1.0;
     for (int k = 0; k < n; ++k) {
-        a[j * n + k] = A[k];
+        a[g * n + k] = A[k];
         lm = lm + yk * A[k];                                          // affine_expansion.py:674-685
         yk *= y0;
     }
-    log_mgf[j] = lm;
+    log_mgf[g] = lm;
 }
 
 __global__ __launch_bounds__(AB) void heston_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
@@ -232,10 +245,14 @@ struct StrikeArgs {
 
 // one block per strike; legacy Simpson weights (utils/mgf_pricer.py:158-171): 1,4,2,...,  every odd index 4
 __global__ __launch_bounds__(256) void mgf_vanilla_slice_kernel(const cd *__restrict__ phi, const cd *__restrict__ log_mgf,
-                                                                int n_grid, StrikeArgs sa, double *__restrict__ capped)
+                                                                int n_grid, StrikeArgs sa, double *__restrict__ capped,
+                                                                int capped_ld)
 {
     __shared__ double lds[4];
     const double PI = 3.14159265358979323846;
+    phi += static_cast<size_t>(blockIdx.y) * n_grid;                 // blockIdx.y: the parameter set of a batched call
+    log_mgf += static_cast<size_t>(blockIdx.y) * n_grid;
+    capped += static_cast<size_t>(blockIdx.y) * capped_ld;
     const double x = sa.x[blockIdx.x];
     const double h = phi[1].im - phi[0].im;
     double s = 0.0;
@@ -294,20 +311,43 @@ using namespace svmc;
 
 extern "C" {
 
+int svmc_logsv_mgf_grid_batch(const double *phi, const double *psi, size_t n_grid, int n_sets, double ttm,
+                              const double *params_host, int is_spot_measure, int expansion_order, double *a,
+                              double *log_mgf, double rtol, double atol, svmc_stream_t stream)
+{
+    const char *fn = "svmc_logsv_mgf_grid_batch";
+    SVMC_REQUIRE(phi && psi && a && log_mgf && params_host, "svmc_logsv_mgf_grid_batch: null pointer");
+    SVMC_REQUIRE(expansion_order == 1 || expansion_order == 2, "svmc_logsv_mgf_grid_batch: expansion_order must be 1 or 2");
+    SVMC_REQUIRE(ttm > 0.0 && rtol > 0.0 && atol > 0.0, "svmc_logsv_mgf_grid_batch: ttm, rtol, atol must be positive");
+    SVMC_REQUIRE(n_sets >= 1, "svmc_logsv_mgf_grid_batch: n_sets < 1");
+    if (n_grid == 0) return SVMC_OK;
+    const int n_coef = (expansion_order == 2) ? 5 : 3;
+    for (int s0 = 0; s0 < n_sets; s0 += MAX_ODE_SETS) {
+        const int m = (n_sets - s0 < MAX_ODE_SETS) ? (n_sets - s0) : MAX_ODE_SETS;
+        OdeBatch sets;
+        for (int i = 0; i < MAX_ODE_SETS; ++i) {
+            const double *p = params_host + static_cast<size_t>(SVMC_LOGSV_SET_DOUBLES) * (s0 + (i < m ? i : 0));
+            // p = {sigma0, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta}
+            sets.c[i] = make_ode_consts(p[1], p[2], p[3], p[4], p[5], is_spot_measure, expansion_order, p[6]);
+            sets.y0[i] = p[0] - p[1];
+        }
+        const size_t off = static_cast<size_t>(s0) * n_grid;
+        hipLaunchKernelGGL(logsv_mgf_grid_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB), static_cast<unsigned>(m)),
+                           dim3(AB), 0, as_stream(stream), reinterpret_cast<const cd *>(phi) + off,
+                           reinterpret_cast<const cd *>(psi) + off, n_grid, ttm, sets, reinterpret_cast<cd *>(a) + off * n_coef,
+                           reinterpret_cast<cd *>(log_mgf) + off, rtol, atol);
+    }
+    return check_launch_a(fn);
+}
+
 int svmc_logsv_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double sigma0, double theta,
                         double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
                         int expansion_order, double vol_backbone_eta, double *a, double *log_mgf, double rtol,
                         double atol, svmc_stream_t stream)
 {
-    SVMC_REQUIRE(phi && psi && a && log_mgf, "svmc_logsv_mgf_grid: null pointer");
-    SVMC_REQUIRE(expansion_order == 1 || expansion_order == 2, "svmc_logsv_mgf_grid: expansion_order must be 1 or 2");
-    SVMC_REQUIRE(ttm > 0.0 && rtol > 0.0 && atol > 0.0, "svmc_logsv_mgf_grid: ttm, rtol, atol must be positive");
-    if (n_grid == 0) return SVMC_OK;
-    const OdeConsts c = make_ode_consts(theta, kappa1, kappa2, beta, volvol, is_spot_measure, expansion_order, vol_backbone_eta);
-    hipLaunchKernelGGL(logsv_mgf_grid_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB)), dim3(AB), 0,
-                       as_stream(stream), reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(psi), n_grid, ttm,
-                       c, sigma0 - theta, reinterpret_cast<cd *>(a), reinterpret_cast<cd *>(log_mgf), rtol, atol);
-    return check_launch_a("svmc_logsv_mgf_grid");
+    const double set[SVMC_LOGSV_SET_DOUBLES] = {sigma0, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, 0.0};
+    return svmc_logsv_mgf_grid_batch(phi, psi, n_grid, 1, ttm, set, is_spot_measure, expansion_order, a, log_mgf, rtol, atol,
+                                     stream);
 }
 
 int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, double ttm, double v0, double theta,
@@ -323,21 +363,28 @@ int svmc_heston_mgf_grid(const double *phi, const double *psi, size_t n_grid, do
     return check_launch_a("svmc_heston_mgf_grid");
 }
 
-int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_grid, double forward,
-                           const double *strikes_host, size_t n_strikes, double *capped, svmc_stream_t stream)
+int svmc_mgf_vanilla_slice_batch(const double *phi, const double *log_mgf, size_t n_grid, int n_sets, double forward,
+                                 const double *strikes_host, size_t n_strikes, double *capped, svmc_stream_t stream)
 {
     SVMC_REQUIRE(phi && log_mgf && capped, "svmc_mgf_vanilla_slice: null pointer");
     SVMC_REQUIRE(n_grid >= 3 && n_grid < (1u << 30), "svmc_mgf_vanilla_slice: grid too short or too long");
     SVMC_REQUIRE(n_strikes == 0 || strikes_host, "svmc_mgf_vanilla_slice: null strikes");
+    SVMC_REQUIRE(n_sets >= 1 && n_sets <= 65535, "svmc_mgf_vanilla_slice: n_sets out of range");
     for (size_t k0 = 0; k0 < n_strikes; k0 += 32) {
         StrikeArgs sa;
         sa.k = static_cast<int>((n_strikes - k0 < 32) ? (n_strikes - k0) : 32);
         for (int k = 0; k < 32; ++k) sa.x[k] = (k < sa.k) ? log(forward / strikes_host[k0 + k]) : 0.0;    // :199
-        hipLaunchKernelGGL(mgf_vanilla_slice_kernel, dim3(sa.k), dim3(256), 0, as_stream(stream),
-                           reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(log_mgf),
-                           static_cast<int>(n_grid), sa, capped + k0);
+        hipLaunchKernelGGL(mgf_vanilla_slice_kernel, dim3(sa.k, static_cast<unsigned>(n_sets)), dim3(256), 0,
+                           as_stream(stream), reinterpret_cast<const cd *>(phi), reinterpret_cast<const cd *>(log_mgf),
+                           static_cast<int>(n_grid), sa, capped + k0, static_cast<int>(n_strikes));
     }
     return check_launch_a("svmc_mgf_vanilla_slice");
+}
+
+int svmc_mgf_vanilla_slice(const double *phi, const double *log_mgf, size_t n_grid, double forward,
+                           const double *strikes_host, size_t n_strikes, double *capped, svmc_stream_t stream)
+{
+    return svmc_mgf_vanilla_slice_batch(phi, log_mgf, n_grid, 1, forward, strikes_host, n_strikes, capped, stream);
 }
 
 int svmc_mgf_qvar_slice(const double *psi, const double *log_mgf, size_t n_grid, double ttm, const double *strikes_host,

@@ -119,7 +119,45 @@ FUSED_FIXED_RANDOMS_DRIVER = True
 LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
 
 
+def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,
+                             discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
+                             optiontypes_ttms: Sequence[np.ndarray], is_spot_measure: bool = True,
+                             expansion_order: ExpansionOrder = ExpansionOrder.SECOND) -> List[List[np.ndarray]]:
+    """logsv_chain_pricer (LOG_RETURN, numerical ODE route) for SEVERAL parameter sets on one chain, all sets advanced
+    by one launch per expiry and inverted by one launch per expiry: [set][expiry] -> prices.  Each set keeps its own
+    transform grid (set_vol_scaler follows its sigma0, reference :664-666); results are bit-identical to one
+    logsv_chain_pricer call per set.  Not in the reference API: the batched form of its per-set loop (config C5's five
+    sets; the bumped vectors of a finite-difference gradient)."""
+    from ..analytic import AnalyticGridBatch
+    order = _order_code(expansion_order)
+    grids = [mgfp.get_transform_var_grid(variable_type=VariableType.LOG_RETURN, is_spot_measure=is_spot_measure,
+                                         vol_scaler=set_vol_scaler(sigma0=p.sigma0, ttm=np.min(ttms))) for p in params_list]
+    batch = AnalyticGridBatch([g[0] for g in grids], [g[1] for g in grids], 5 if order == 2 else 3)
+    try:
+        out, ttm0 = [[] for _ in params_list], 0.0
+        for ttm, forward, strikes, types, discfactor in zip(ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors):
+            rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, p.get_vol_backbone_eta(tau=ttm), 0.0]
+                             for p in params_list])
+            batch.logsv_advance(ttm - ttm0, rows, is_spot_measure, order)
+            capped = batch.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
+            for s in range(len(params_list)):
+                out[s].append(vanilla_prices_from_capped(capped[s], float(forward), strikes, types, float(discfactor),
+                                                         is_spot_measure))
+            ttm0 = ttm
+        return out
+    finally:
+        batch.close()
+
+
 class LogSVPricer(ModelPricer):
+
+    def price_chain_batch(self, option_chain: OptionChain, params_list: Sequence[LogSvParams], is_spot_measure: bool = True,
+                          **kwargs) -> List[List[np.ndarray]]:
+        """price_chain for several parameter sets in one batch of launches (logsv_chain_pricer_batch)"""
+        return logsv_chain_pricer_batch(params_list=params_list, ttms=option_chain.ttms, forwards=option_chain.forwards,
+                                        discfactors=option_chain.discfactors, strikes_ttms=option_chain.strikes_ttms,
+                                        optiontypes_ttms=option_chain.optiontypes_ttms, is_spot_measure=is_spot_measure,
+                                        **kwargs)
 
     def price_chain(self, option_chain: OptionChain, params: LogSvParams, is_spot_measure: bool = True, **kwargs
                     ) -> List[np.ndarray]:

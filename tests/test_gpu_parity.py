@@ -685,11 +685,22 @@ def test_analytic_heston_and_c5_sweep(sv, golden):
         np.testing.assert_allclose(np.stack(sv.HestonPricer().price_chain(chain, hp)), np.stack(pr), rtol=0, atol=0)
     chain = sv.OptionChain(ttms=ttms, forwards=one, strikes_ttms=(kk,) * 4, optiontypes_ttms=(types,) * 4, ids=None)
     pricer = sv.LogSVPricer()
+    sets, single = [], []
     for tag in ("btc", "readme", "quick", "test", "fig3"):
         v = [float(a) for a in g[f"logsv_{tag}_params"]]
         params = sv.LogSvParams(sigma0=v[0], theta=v[1], kappa1=v[2], kappa2=v[3], beta=v[4], volvol=v[5])
         analytic = pricer.price_chain(chain, params)
         np.testing.assert_allclose(np.stack(analytic), g[f"logsv_{tag}_prices"], rtol=0, atol=2e-6)
+        sets.append(params)
+        single.append(np.stack(analytic))
+    # the five sets in one batch of launches: the same bits as five chains one after the other, both orders and measures
+    for a, b in zip(pricer.price_chain_batch(chain, sets), single):
+        np.testing.assert_array_equal(np.stack(a), b)
+    from stochvolmodels_amd.pricers.logsv.affine_expansion import ExpansionOrder
+    batch = pricer.price_chain_batch(chain, sets, is_spot_measure=False, expansion_order=ExpansionOrder.FIRST)
+    for a, p_ in zip(batch, sets):
+        one_by_one = pricer.price_chain(chain, p_, is_spot_measure=False, expansion_order=ExpansionOrder.FIRST)
+        np.testing.assert_array_equal(np.stack(a), np.stack(one_by_one))
 
 
 def test_c5_reference_criterion_at_reference_scale(sv, golden):
