@@ -345,10 +345,13 @@ def main():
     if os.environ.get("SVMC_BENCH_NO_KERNEL_EVENTS") != "1":     # diagnostics: the HIP events around the stepping launches
         eng.start_kernel_timing()
     t0 = time.perf_counter()
+    step_ends = []
     for i in range(args.steps):
         prices, stderrs = step(i)
+        step_ends.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step_ms = 1e3 * np.diff(np.array([t0] + step_ends))
     kernel_ms = (eng.stop_kernel_timing() if eng._prof is not None else {}).get(kernel, [float("nan")])
     elapsed = max_over_ranks(elapsed)
     value = float(n_total) * nb * args.steps / elapsed
@@ -422,6 +425,9 @@ def main():
         result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, pmc, clock_mhz))
         result.update(extra)
         result["device_prewarm_steps"] = PREWARM
+        result["ms_per_step_profile"] = {"first5": [round(float(v), 3) for v in per_step_ms[:5]],
+                                         "last5": [round(float(v), 3) for v in per_step_ms[-5:]],
+                                         "median": round(float(np.median(per_step_ms)), 3)}
         result["prices_head"] = [float(v) for v in prices[0][:3]]
         result["stderr_head"] = [float(v) for v in stderrs[0][:3]]
         if world == 1 and cfg == "c2" and not args.no_streamed:

@@ -836,17 +836,6 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
             }
         }
     };
-#ifdef SVMC_PAYOFF_PAIRS
-    // two paths per trip: their loads are issued together and their two independent exp / payoff chains interleave
-    size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    for (; i + stride < n; i += 2 * stride) {
-        const double x0 = x[i], x1 = x[i + stride];
-        const double q0 = need_q ? qvar[i] : 0.0, q1 = need_q ? qvar[i + stride] : 0.0;
-        add_path(x0, q0);
-        add_path(x1, q1);
-    }
-    if (i < n) add_path(x[i], need_q ? qvar[i] : 0.0);
-#else
     size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     double xn = (i < n) ? x[i] : 0.0, qn = (need_q && i < n) ? qvar[i] : 0.0;
     for (; i < n; i += stride) {
@@ -857,8 +846,6 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
         }
         add_path(xi, qi);
     }
-#endif
-    (void)nk;
     // output row layout: [sum d, sum d^2, count] per strike, interleaved, at column 3 (col + k)
     double *row = partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col;
     const double cnt = block_path_count(n, blockIdx.x, gridDim.x);
