@@ -49,7 +49,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6
 N_SIMD = 256 * 4
 MAX_CLOCK_HZ = 2.4e9
 VALU_ISSUE_PEAK = N_SIMD * MAX_CLOCK_HZ / 4.0          # full-rate wave-instructions per second, whole chip
-PREWARM = 10                    # untimed steps ahead of the caller's warm-up: the GPU clock ramp (see main)
+# Untimed steps ahead of the caller's warm-up (disclosed as device_prewarm_steps).  Two things have to be behind the
+# process before K steps of 2-6 ms can be timed: the GPU's clock ramp (the first ~10 launches run 20-25 % slow) and a
+# ONE-TIME stall of the ROCm runtime -- a single call of ~60 ms observed at the ~150th chain call of a process for C2
+# and the ~41st for C4 (profiles/r02_runtime_stall.txt: 400-step runs, one slow step each, none afterwards) -- which a
+# 50-step window would otherwise swallow whole.  `ms_per_step_profile` in the output shows the timed steps one by one.
+PREWARM = 200
 # SURVEY.md 8(d)'s ESTIMATE of the algorithmic work per LogSV path-step in fp64 op-equivalents (34 simple flops + div 10
 # + sqrt 10 + exp/log/sincos 25 each + Philox/conversion ~ 11): a model of the reference's arithmetic, not a count
 LOGSV_FLOP_EQ_PER_PATH_STEP = 140.0
@@ -332,9 +337,6 @@ def main():
     def step(i):
         return price(sv, wl, P, n_total, 20240602 + i)
 
-    # The first launches after the process starts run 20-25 % slow while the GPU's clocks come up.  PREWARM untimed
-    # steps (disclosed as device_prewarm_steps) bring the device to its steady state before the W warm-up steps the
-    # caller asked for, so that a small W does not time the ramp.
     for i in range(PREWARM):
         step(-1000 - i)
     for i in range(args.warmup):
@@ -349,8 +351,10 @@ def main():
     for i in range(args.steps):
         prices, stderrs = step(i)
         step_ends.append(time.perf_counter())
+    t_b = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    final_barrier_ms = 1e3 * (time.perf_counter() - t_b)
     per_step_ms = 1e3 * np.diff(np.array([t0] + step_ends))
     kernel_ms = (eng.stop_kernel_timing() if eng._prof is not None else {}).get(kernel, [float("nan")])
     elapsed = max_over_ranks(elapsed)
@@ -427,7 +431,10 @@ def main():
         result["device_prewarm_steps"] = PREWARM
         result["ms_per_step_profile"] = {"first5": [round(float(v), 3) for v in per_step_ms[:5]],
                                          "last5": [round(float(v), 3) for v in per_step_ms[-5:]],
-                                         "median": round(float(np.median(per_step_ms)), 3)}
+                                         "median": round(float(np.median(per_step_ms)), 3),
+                                         "final_barrier_ms": round(final_barrier_ms, 3),
+                                         "slowest": [[int(i), round(float(per_step_ms[i]), 3)]
+                                                     for i in np.argsort(per_step_ms)[::-1][:4]]}
         result["prices_head"] = [float(v) for v in prices[0][:3]]
         result["stderr_head"] = [float(v) for v in stderrs[0][:3]]
         if world == 1 and cfg == "c2" and not args.no_streamed:

@@ -240,8 +240,11 @@ struct ChainSlices {
     int m, total_steps;
 };
 
+#ifndef SVMC_CHAIN_WAVES
+#define SVMC_CHAIN_WAVES 8, 8          // A/B hook: residency of the whole-chain kernel (7, 8 lifts the 64-VGPR cap)
+#endif
 template <bool DRIFT_IN_Z1>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_chain_rng_kernel(
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAIN_WAVES), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_chain_rng_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials)

@@ -49,6 +49,26 @@ b = bufs(n)
 m, lo = timed(lambda: L.svmc_logsv_terminal_rng(b[0], b[1], b[2], n, 1024, 1 / 1024, 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1.0, 1, 7, 0, 0, 0, None),
               lambda: L.svmc_fill_state(b[0], b[1], b[2], n, 0.0, 0.8376, 0.0, None))
 res["logsv_c2_ms"], res["logsv_c2_min_ms"] = round(m, 4), round(lo, 4)
+# the whole-chain kernel at C4's rank share: 2^21 paths, 8 x 128 steps (svmc_logsv_chain_rng, fused epilogues)
+import numpy as np
+n = 1 << 21
+cb = bufs(n)
+pd_ = C.POINTER(C.c_double)
+L.svmc_slice_workspace_bytes.argtypes = [sz, C.POINTER(C.c_size_t)]
+L.svmc_logsv_chain_rng.argtypes = [vp, vp, vp, sz, i32, C.POINTER(i32), pd_, pd_, pd_, f64, f64, f64, f64, f64, i32, u64, u32,
+                                   u64, u32, vp, vp, vp, vp, sz, vp]
+wsb_c = C.c_size_t()
+assert L.svmc_slice_workspace_bytes(n, C.byref(wsb_c)) == 0
+ws_c, spot_c, snap_c = vp(), vp(), vp()
+assert L.svmc_malloc(C.byref(ws_c), wsb_c.value) == 0 and L.svmc_malloc(C.byref(spot_c), 256) == 0
+assert L.svmc_malloc(C.byref(snap_c), 8 * 8 * n) == 0
+nbs = (i32 * 8)(*([128] * 8))
+dts = np.full(8, 1.0 / 1024); etas = np.ones(8); fws = 67000.0 * np.exp(0.05 * np.arange(1, 9) / 8)
+m, lo = timed(lambda: L.svmc_logsv_chain_rng(cb[0], cb[1], cb[2], n, 8, nbs, dts.ctypes.data_as(pd_), etas.ctypes.data_as(pd_),
+                                             fws.ctypes.data_as(pd_), 1.0413, 3.1844, 3.058, 0.1514, 1.8458, 1, 7, 0, 0, 0,
+                                             snap_c, None, spot_c, ws_c, wsb_c.value, None),
+              lambda: L.svmc_fill_state(cb[0], cb[1], cb[2], n, 0.0, 0.8376, 0.0, None), reps=8, warm=2)
+res["logsv_chain_c4_ms"], res["logsv_chain_c4_min_ms"] = round(m, 4), round(lo, 4)
 n = 1 << 22
 h = bufs(n)
 for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("btc", (0.8, 1.0, 2.0, 0.0, 2.0))):
@@ -57,7 +77,6 @@ for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("bt
                       lambda: L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, v0, 0.0, None), reps=6, warm=2)
         res[f"heston_{name}_{sname}_ms"] = round(m, 4)
 # ---- the chain-wide payoff pass at C3's shape: 4 expiries x 21 strikes over 2^22 paths each (P below 1, C at/above) ----
-import numpy as np
 pd, pi8, psz = C.POINTER(C.c_double), C.POINTER(C.c_int8), C.POINTER(C.c_size_t)
 L.svmc_slice_workspace_bytes.argtypes = [sz, psz]
 L.svmc_spot_sums.argtypes = [vp, sz, f64, vp, vp, sz, vp]
