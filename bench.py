@@ -157,6 +157,28 @@ def cpu_baseline(wl, n_sample: int, P) -> dict:
             "prices_head_chunk_scatter": [float(v) for v in np.std(pooled, axis=0)[:3]]}
 
 
+def cpu_baseline_numpy(nb_steps: int, P, n: int = 1 << 15) -> dict:
+    """SURVEY.md 8d's other CPU number: the NumPy restatement of the reference's array code (oracle.np_logsv_terminal_w:
+    the step-major loop of pricers/logsv_pricer.py:1040-1045 on whole [nb_path] vectors with NumPy temporaries, i.e.
+    what the reference executes when Numba is absent), one core, RandomState normals, a small bounded sample"""
+    from oracle import oracle
+    rng = np.random.RandomState(11)
+    t0 = time.perf_counter()
+    W0 = rng.normal(0, 1, size=(nb_steps, n))
+    W1 = rng.normal(0, 1, size=(nb_steps, n))
+    oracle.np_logsv_terminal_w(np.zeros(n), P.sigma0 * np.ones(n), np.zeros(n), 1.0 / nb_steps, P.theta, P.kappa1, P.kappa2,
+                               P.beta, P.volvol, W0, W1)
+    t = time.perf_counter() - t0
+    try:
+        import numba  # noqa: F401
+        have_numba = True
+    except Exception:
+        have_numba = False
+    return {"value": n * nb_steps / t, "unit": "path-steps/s", "cores": 1, "kind": "port (NumPy array code)",
+            "sample": f"{n} paths x {nb_steps} steps incl. RandomState normals, {t:.1f}s",
+            "numba_importable_on_this_box": have_numba}
+
+
 def cpu_baseline_all_cores(nb_steps: int, P) -> dict:
     """the same fp64 step on ALL host cores with the counter-based draw generated on the fly, OpenMP over paths
     (oracle svo_logsv_terminal_rng) -- not the reference's algorithm (which is serial), but the fairest CPU number
@@ -270,7 +292,10 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
             "clock_mhz_during_run": clock_mhz, "ms_per_launch": k_ms, "launches": launches,
             "frac_at_measured_clock": (achieved / (N_SIMD * clock_mhz * 1e6 / 4.0)) if clock_mhz else None,
             "traffic": prof.get("hbm_bytes") if prof.get("config") == {"paths": n_local, "steps": nb} else None,
+            "algorithmic_bytes": (48.0 + 8.0 * m) * n_local,
         }
+        if prof.get("note"):
+            out["roofline"]["traffic_note"] = prof["note"]
     alg_bytes = (48.0 + 8.0 * m) * n_local     # 24 B state read + 24 B write per chain, 8 B terminal-x snapshot per expiry
     hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
     hbm = {"kernel": kernel, "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -443,6 +468,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_paths, P)
             if world == 1 and not args.no_extra_legs:
                 result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(1024, P)
+                result["cpu_baseline_numpy"] = cpu_baseline_numpy(1024, P)
     if torch.distributed.is_initialized():     # world > 1, or a lone rank under SVMC_DIST_SINGLE_RANK_GROUP=1
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

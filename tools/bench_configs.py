@@ -103,6 +103,17 @@ def main():
     dt, _ = timed(lambda: pricer.price_chain(g5, P), reps=5, warm=1)
     res.append(dict(config="C5 analytic side: LogSV affine-expansion chain 4 x 21 strikes, 1000-point phi grid", ms=1e3 * dt,
                     prices_per_s=84 / dt))
+    # C5 analytic side, the five parameter sets of the sweep: one by one and in one batch of launches
+    g = np.load(os.path.join(ROOT, "tests", "golden", "analytic.npz"))
+    sets = []
+    for tag in ("btc", "readme", "quick", "test", "fig3"):
+        v = [float(a) for a in g[f"logsv_{tag}_params"]]
+        sets.append(sv.LogSvParams(sigma0=v[0], theta=v[1], kappa1=v[2], kappa2=v[3], beta=v[4], volvol=v[5]))
+    c5 = sv.OptionChain(ttms=np.array([0.25, 0.5, 0.75, 1.0]), forwards=np.ones(4), strikes_ttms=(kk,) * 4,
+                        optiontypes_ttms=(types,) * 4, ids=None)
+    dt1, _ = timed(lambda: [pricer.price_chain(c5, p_) for p_ in sets], reps=5, warm=1)
+    dtb, _ = timed(lambda: pricer.price_chain_batch(c5, sets), reps=5, warm=1)
+    res.append(dict(config="C5 analytic side, 5 parameter sets x (4 x 21 strikes)", one_by_one_ms=1e3 * dt1, batched_ms=1e3 * dtb))
     for r in res:
         print(json.dumps(r))
 

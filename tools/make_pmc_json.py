@@ -17,6 +17,14 @@ import sqlite3
 import sys
 
 KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "logsv_w_kernel")
+NOTES = {
+    "logsv_chain_rng_kernel": "traffic above the 48 + 8 M algorithmic bytes per path is register-spill scratch: at its 64-VGPR "
+                              "budget (8 waves per SIMD) the whole-chain kernel parks 132 B per lane of state that is dead inside "
+                              "the time loop (x, qvar, the path index, slice bookkeeping) in scratch at the 8 slice boundaries -- "
+                              "~0.87 GB per launch = 180 GB/s over 4.8 ms, 2 % of HBM peak and overlapped with the VALU-bound "
+                              "stepping; lifting the cap to 72 / 80 VGPRs (7 / 6 waves) keeps 96 / 68 B of it and measured the "
+                              "same time (profiles/r02_ab_chain_residency.jsonl)",
+}
 
 
 def counters(db_path):
@@ -63,6 +71,8 @@ def main():
             for extra in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS"):
                 if extra in c:
                     e[extra.lower() + "_per_dispatch"] = c[extra][0]
+            if k in NOTES:
+                e["note"] = NOTES[k]
             if k not in res or meta["config"] == "c2":
                 res[k] = e
     print(json.dumps(res, indent=1))

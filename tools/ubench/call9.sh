@@ -1,0 +1,11 @@
+set -u
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 1800 python -m pytest tests -m gpu -q -rs --durations=5 2>&1 | tail -15 > gpurun_out/pytest_gpu_r2_final.log; tail -15 gpurun_out/pytest_gpu_r2_final.log
+timeout 900 python bench.py > gpurun_out/bench_r2_final.json 2> gpurun_out/bench_r2_final.err; tail -c 600 gpurun_out/bench_r2_final.json; echo
+timeout 900 python bench.py --config c4 > gpurun_out/bench_r2_final_c4.json 2> gpurun_out/bench_r2_final_c4.err; tail -c 300 gpurun_out/bench_r2_final_c4.json; echo
+SVMC_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/bench_r2_final_2rank_gloo.json 2> gpurun_out/bench_r2_final_2rank_gloo.err; tail -c 300 gpurun_out/bench_r2_final_2rank_gloo.json; echo
+SVMC_DIST_COMM=rccl SVMC_DIST_SINGLE_RANK_GROUP=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 900 python bench.py --config c4 --no-cpu-baseline > gpurun_out/bench_r2_final_c4_rcclcomm.json 2> gpurun_out/bench_r2_final_c4_rcclcomm.err; tail -c 300 gpurun_out/bench_r2_final_c4_rcclcomm.json; echo
+timeout 900 python tools/bench_configs.py > gpurun_out/configs_r2.jsonl 2> gpurun_out/configs_r2.err; cat gpurun_out/configs_r2.jsonl
+timeout 600 python tools/bench_calibration.py 100000 > gpurun_out/calib_r2.log 2>&1; tail -8 gpurun_out/calib_r2.log
+bash tools/collect_profiles.sh
