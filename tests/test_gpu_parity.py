@@ -1403,3 +1403,17 @@ def test_reference_quickstart_known_answers(sv):
     np.testing.assert_allclose(vanilla_ivol, 0.999577, rtol=5.0e-6, atol=1.0e-8)
     np.testing.assert_allclose(chain_prices[1][2], 0.275202, rtol=5.0e-6, atol=1.0e-8)
     np.testing.assert_allclose(chain_ivols[1][2], 0.995757, rtol=5.0e-6, atol=1.0e-8)
+
+
+def test_randomised_chain_sweep(sv, oracle):
+    """tools/fuzz_parity.py inside the suite: 40 random chains -- ragged strike counts (1..11 per expiry, 1..6
+    expiries), all payoff codes, both measures, both payoff variables, vol backbones, odd path counts, LogSV / Heston
+    Euler / QE -- priced by the whole-chain kernels, slice by slice (bit-identical) and by the CPU oracle on the same
+    counter-based randoms (1e-8 relative, identical NaN / inf pattern)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.main(n_cases=40, seed=20240927) < 1e-8

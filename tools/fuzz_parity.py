@@ -45,9 +45,12 @@ def oracle_chain(model, kw, seed):
     return prices
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def main(n_cases=None, seed=None):
+    if n_cases is None:
+        n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    if seed is None:
+        seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(n_cases):
         model = ("logsv", "heston")[case % 2]
@@ -91,6 +94,7 @@ def main():
             assert err < 1e-8 and np.array_equal(np.isfinite(x), ok), (case, model, err, x, y)
         print(f"case {case:3d} {model:6s} m={m} n={kw['nb_path']:5d} {vt.name:10s} ok")
     print(f"{n_cases} cases, worst relative deviation from the CPU oracle {worst:.2e}")
+    return worst
 
 
 if __name__ == "__main__":

@@ -1,3 +1,5 @@
+# The round-2 measurement pass, run on the GPU box from the repo root (gpurun): GPU tests, the bench lines committed
+# under profiles/r02_bench_*.json, secondary configs, the calibration bench and the rocprofv3 passes.
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
