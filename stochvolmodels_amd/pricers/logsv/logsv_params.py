@@ -34,16 +34,15 @@ class LogSvParams(ModelParams):
         assert 1e-4 < self.H <= 0.5
 
     def approximate_kernel(self, T: float) -> None:
-        """nodes / weights of the Markovian approximation of the rough kernel (reference :96-118).  H in (0.49, 0.5]
-        is the reference's closed form (one node at 1e-3, weight 1).  For smaller H the reference runs a SciPy
-        optimisation of the quadrature rule (rough_logsv/rough_kernel.py, european_rule), which is calibration-side
-        host code outside the Monte Carlo path: set `nodes` and `weights` (1 to 3 entries) directly."""
+        """nodes / weights of the Markovian approximation of the rough kernel over the horizon T (reference :96-118):
+        one node at 1e-3 with weight 1 for H in (0.49, 0.5] (the standard dynamics), otherwise the quadrature rule
+        tuned for European options with 2 nodes for H in (0.4, 0.49] and 3 below (rough_logsv/rough_kernel.py)."""
         if 0.49 < self.H <= 0.5:
             self.weights = np.array([1.0])
             self.nodes = np.array([1e-3])
             return
-        raise NotImplementedError("approximate_kernel for H <= 0.49: set LogSvParams.nodes / .weights from the "
-                                  "quadrature rule of your choice (1 to 3 nodes)")
+        from ..rough_logsv.rough_kernel import european_rule
+        self.nodes, self.weights = european_rule(self.H, 2 if 0.4 < self.H <= 0.49 else 3, T)
 
     def to_dict(self) -> Dict[str, Any]:
         return asdict(self)

@@ -663,6 +663,22 @@ def g_varswap():
     save("varswap", **out)
 
 
+# -- f4 set-up: the kernel quadrature rule behind LogSvParams.approximate_kernel -------------------------
+def g_rough_kernel():
+    from stochvolmodels.pricers.rough_logsv.rough_kernel import european_rule
+    cases = [(0.1, 3, 1.0), (0.45, 2, 1.0), (0.3, 3, 0.25), (0.05, 3, 2.0), (0.41, 2, 1.0 / 12), (0.2, 3, 0.1), (0.4, 3, 0.5),
+             (0.49, 2, 3.0), (0.01, 3, 1.0), (0.25, 1, 1.0), (0.35, 2, 0.75), (0.15, 3, 1.5)]
+    out = {"cases": np.array(cases)}
+    for i, (H, N, T) in enumerate(cases):
+        nodes, weights = european_rule(H, int(N), T)
+        out[f"nodes_{i}"], out[f"weights_{i}"] = nodes, weights
+    for j, (H, T) in enumerate(((0.5, 1.0), (0.495, 0.5), (0.45, 0.25), (0.4, 1.0), (0.1, 1.0))):
+        p = LogSvParams(sigma0=0.8, theta=1.0, kappa1=3.0, kappa2=3.0, beta=0.15, volvol=1.8, H=H)
+        p.approximate_kernel(T=T)
+        out[f"params_H_T_{j}"], out[f"params_nodes_{j}"], out[f"params_weights_{j}"] = np.array([H, T]), p.nodes, p.weights
+    save("rough_kernel", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python make_golden.py g_rough g_calibration ...
         oracle.build()
@@ -683,5 +699,6 @@ if __name__ == "__main__":
     g_analytic_qvar()
     g_heston_qvar()
     g_rough()
+    g_rough_kernel()
     g_varswap()
     g_calibration()

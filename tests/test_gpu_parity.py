@@ -1048,6 +1048,18 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
     p05 = sv.LogSvParams(H=0.5)
     p05.approximate_kernel(T=1.0)
     assert p05.nodes.tolist() == [1e-3] and p05.weights.tolist() == [1.0]
+    # approximate_kernel for H <= 0.49 (the quadrature rule of rough_logsv/rough_kernel.py; host test:
+    # tests/test_host_logic.py::test_rough_kernel_quadrature_rule): a drop-in rough chain pricing from H alone
+    auto = sv.LogSvParams(sigma0=kw["sigma0"], theta=kw["theta"], kappa1=kw["kappa1"], kappa2=kw["kappa2"],
+                          beta=kw["beta"], volvol=kw["orthog_vol"], H=0.1)
+    auto.approximate_kernel(T=float(chain.ttms[-1]))
+    assert auto.nodes.shape == auto.weights.shape == (3,)
+    pr3, _ = sv.LogSVPricer().model_mc_price_chain(option_chain=chain, params=auto, nb_path=10000, nb_steps=360,
+                                                   use_rough_mc=True, seed=10)
+    if np.allclose(auto.nodes, kw["nodes"], rtol=1e-6) and np.allclose(auto.weights, kw["weights"], rtol=1e-6):
+        for i in range(4):                     # the golden case used this very rule: the same prices
+            np.testing.assert_allclose(pr3[i], g[f"h010_prices_{i}"], rtol=1e-6, atol=1e-10)
+    assert all(np.all(np.isfinite(p_)) and np.all(p_ >= 0.0) for p_ in pr3)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -237,3 +237,34 @@ def test_build_keeps_basic_blocks_aligned():
     f = build.flags()
     assert "--align-all-blocks=4" in f and f[f.index("--align-all-blocks=4") - 1] == "-mllvm"
     assert "--offload-arch=gfx950" in f
+
+
+def test_rough_kernel_quadrature_rule(golden):
+    """LogSvParams.approximate_kernel for every H (reference pricers/logsv/logsv_params.py:96-118): the European
+    quadrature rule of rough_logsv/rough_kernel.py -- L-BFGS-B over the log-nodes of the L2 error with the optimal
+    weights eliminated -- against the reference's own nodes and weights (tests/golden/rough_kernel.npz)"""
+    from stochvolmodels_amd.pricers.logsv.logsv_params import LogSvParams
+    from stochvolmodels_amd.pricers.rough_logsv.rough_kernel import european_rule, l2_error_optimal_weights
+    g = golden("rough_kernel")
+    for i, (H, N, T) in enumerate(g["cases"]):
+        nodes, weights = european_rule(float(H), int(N), float(T))
+        np.testing.assert_allclose(nodes, g[f"nodes_{i}"], rtol=1e-6, err_msg=f"nodes H={H} N={N} T={T}")
+        np.testing.assert_allclose(weights, g[f"weights_{i}"], rtol=1e-6, err_msg=f"weights H={H} N={N} T={T}")
+        assert nodes.shape == weights.shape == (int(N),) and np.all(nodes > 0) and np.all(weights > 0)
+    for j in range(5):
+        H, T = g[f"params_H_T_{j}"]
+        p = LogSvParams(sigma0=0.8, theta=1.0, kappa1=3.0, kappa2=3.0, beta=0.15, volvol=1.8, H=float(H))
+        p.approximate_kernel(T=float(T))
+        np.testing.assert_allclose(p.nodes, g[f"params_nodes_{j}"], rtol=1e-6)
+        np.testing.assert_allclose(p.weights, g[f"params_weights_{j}"], rtol=1e-6)
+        assert p.nodes.size == (1 if H > 0.49 else 2 if H > 0.4 else 3)
+    # the analytic gradient of the objective against central differences
+    H, T, x = 0.2, 1.0, np.array([0.05, 1.3, 40.0])
+    err, grad, _ = l2_error_optimal_weights(H, T, x, want_grad=True)
+    for k in range(3):
+        h = 1e-5 * x[k]
+        up, dn = x.copy(), x.copy()
+        up[k] += h
+        dn[k] -= h
+        fd = (l2_error_optimal_weights(H, T, up)[0] - l2_error_optimal_weights(H, T, dn)[0]) / (2 * h)
+        assert abs(fd - grad[k]) <= 1e-4 * abs(grad[k]) + 1e-10          # finite-difference accuracy
