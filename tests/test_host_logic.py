@@ -268,3 +268,35 @@ def test_rough_kernel_quadrature_rule(golden):
         dn[k] -= h
         fd = (l2_error_optimal_weights(H, T, up)[0] - l2_error_optimal_weights(H, T, dn)[0]) / (2 * h)
         assert abs(fd - grad[k]) <= 1e-4 * abs(grad[k]) + 1e-10          # finite-difference accuracy
+
+
+def test_bench_workloads_and_roofline_arithmetic():
+    """bench.py's host-side pieces (no GPU): the C2 / C4 workloads are BASELINE's, the CPU baseline leg
+    runs on a tiny sample, and the VALU-issue roofline is the arithmetic DESIGN.md section 7 states"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import stochvolmodels_amd as sv
+    c2, c4 = bench.make_workload("c2", sv), bench.make_workload("c4", sv)
+    assert c2["grids"] == [(1024, 2.0 ** -10)] and c2["n_strikes"] == 21 and c2["nb_total"] == 1024
+    assert [g[0] for g in c4["grids"]] == [128] * 8 and c4["n_strikes"] == 168 and c4["nb_total"] == 1024
+    assert all(abs(g[1] - 0.125 / 128) < 1e-18 for g in c4["grids"])
+    np.testing.assert_allclose(c4["forwards"], 67000.0 * np.exp(0.05 * np.arange(1, 9) / 8))
+    for k, f, t in zip(c4["strikes"], c4["forwards"], c4["types"]):
+        np.testing.assert_allclose(k, f * np.linspace(0.6, 1.6, 21))
+        assert list(t) == ["P" if v < f else "C" for v in k]
+    base = bench.cpu_baseline(c4, 256, sv.LOGSV_BTC_PARAMS)
+    assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and "8 expiries" in base["sample"]
+    pmc = {"logsv_rng_kernel": {"valu_insts_per_wave_step": 71.0, "quarter_rate_insts_per_step": 2,
+                                "config": {"paths": 1 << 20, "steps": 1024}, "hbm_bytes": 59.0e6}}
+    r = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, pmc, 2400.0)
+    slots = (71.0 + 6.0) * (2 ** 20 / 64) * 1024 / 2.0e-3
+    assert r["roofline"]["bound"] == "valu_issue" and abs(r["roofline"]["achieved"] - slots) < 1e-3 * slots
+    assert abs(r["roofline"]["peak"] - 1024 * 2.4e9 / 4) < 1 and abs(r["roofline"]["frac"] - slots / 6.144e11) < 1e-12
+    assert abs(r["roofline"]["frac_at_measured_clock"] - r["roofline"]["frac"]) < 1e-12 and r["roofline"]["traffic"] == 59.0e6
+    assert r["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
+    # without a committed counter pass for the kernel the line falls back to the HBM roof instead of inventing a count
+    assert bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, {}, None)["roofline"]["bound"] == "hbm"
