@@ -298,7 +298,7 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  *   streams 0, 3:  R = sqrt(-ln u1);  w0 = R sqrt2 cos t;  w1 = R sqrt2 sin t    (= sqrt(-2 ln u1) (cos t, sin t))
  *   stream 1:  one call per draw, uniform = ((r0 | r1<<32) >> 12) 2^-52 + 2^-53
  *   stream 2 (vol paths, one Brownian per step): normal t = component t & 1 of pair (t >> 1) & 1 of call t >> 2
- *   stream 4 (Heston QE): one call per step, pair from (r0, r1), uniform (r2 + 1/2) 2^-32
+ *   Heston QE: pairs from stream 4 (as stream 0), uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2
  * ---------------------------------------------------------------------------------------------- */
 #define SVO_PHILOX_ROUNDS 7
 
@@ -363,13 +363,14 @@ void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t s
     draw_normals_stream(seed, call_id, path, step, 0u, w0, w1);
 }
 
-/* stream 4 (Heston QE): pair and uniform from one Philox call -- device twin draw_qe, csrc/svmc_rng.h */
+/* Heston QE: the pair from stream 4 (like stream 0: one call per two steps), the exponential branch's uniform from
+ * stream 5 (word step & 3 of call step >> 2) -- device twins rng_time_loop / qe_uniform, csrc/svmc_rng.h */
 void svo_draw_qe(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, double *w0, double *w1, double *u)
 {
     uint32_t r[4];
-    philox_draw(seed, call_id, path, step, 4u, r);
-    pair_from_words(r[0], r[1], w0, w1);
-    *u = ((double)r[2] + 0.5) * 0x1.0p-32;
+    draw_normals_stream(seed, call_id, path, step, 4u, w0, w1);
+    philox_draw(seed, call_id, path, step >> 2, 5u, r);
+    *u = ((double)r[step & 3u] + 0.5) * 0x1.0p-32;
 }
 
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step)

@@ -604,13 +604,15 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(doub
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
         if (SCHEME == SVMC_HESTON_QE) {
+            const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);
+            QeUniforms uc;
+            uint32_t step = step_offset;
             double vsum = 0.0;
             const double v_first = v;
-            for (int t = 0; t < nb_steps; ++t) {
-                double w0, w1, u;
-                draw_qe(lane, step_offset + static_cast<uint32_t>(t), tab, w0, w1, u);
-                heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return u; });
-            }
+            rng_time_loop(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
+                heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
+                ++step;
+            });
             heston_qe_fold(qc, q, vsum, v_first, v);
         } else {
             v = heston_euler_guard_zero(v);
@@ -653,6 +655,8 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kerne
         q = qvar[p];
     }
     const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
+    const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);      // QE's uniforms
+    QeUniforms uc;
     uint32_t step = step_offset;
     for (int i = 0; i < cs.m; ++i) {
         const int nb = cs.nb_steps[i];
@@ -664,11 +668,11 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kerne
             if (SCHEME == SVMC_HESTON_QE) {
                 double vsum = 0.0;
                 const double v_first = v;
-                for (int t = 0; t < nb; ++t) {
-                    double w0, w1, u;
-                    draw_qe(lane, step + static_cast<uint32_t>(t), tab, w0, w1, u);
-                    heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return u; });
-                }
+                uint32_t st = step;
+                rng_time_loop(lane, step, nb, tab, [&](double w0, double w1) {
+                    heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
+                    ++st;
+                });
                 heston_qe_fold(qc, q, vsum, v_first, v);
             } else {
                 v = heston_euler_guard_zero(v);

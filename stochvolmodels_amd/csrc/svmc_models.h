@@ -300,8 +300,8 @@ __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, co
 }
 
 // One QE-M step.  z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential
-// branch (the streamed kernel loads it only in waves that have a lane there; the on-device draw gets it from the same
-// Philox call).  The scheme's quotients are regrouped so that each branch takes ONE hardware reciprocal (two with a
+// branch -- called by the whole wave as soon as one lane is there (the streamed kernel loads it; the on-device draw is a
+// lazily evaluated Philox call shared by four steps, svmc_rng.h qe_uniform).  The scheme's quotients are regrouped so that each branch takes ONE hardware reciprocal (two with a
 // martingale correction in the exponential branch) where the textbook form -- the CPU twin's -- takes three to five:
 //   quadratic (psi = s2/m^2 <= 3/2), with w = 2 m^2 - s2, Q = sqrt(2 m^2 w), N = w + Q = s2 b^2, T = 2 m^2 + Q = s2 (1 + b^2):
 //     a = m s2 / T,   v1 = a (b + z1)^2 = (m / T) (N + 2 sqrt(N s2) z1 + s2 z1^2),
@@ -322,7 +322,12 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
     const double s2 = fma(v0, c.c1, c.c2);
     const double m2 = m * m;
     double v1, K0;                                        // K0 without its -K13 v0 term
-    if (s2 <= 1.5 * m2) {                                 // psi <= psi_c, decided without the divide
+    const bool quad = s2 <= 1.5 * m2;                     // psi <= psi_c, decided without the divide
+    // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
+    // on-device draw is a Philox call that serves four steps: every lane must take part in it)
+    double u = 0.5;
+    if (!__all(quad)) u = draw_u();
+    if (quad) {
         const double tm2 = m2 + m2;
         const double w = tm2 - s2;                        // >= m^2 / 2
         const double Q = sqrt_pos_1g(tm2 * w);
@@ -347,7 +352,6 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
             }
         }
     } else {
-        const double u = draw_u();
         const double D = s2 + m2, dm = s2 - m2;
         const bool zero = (u * D <= dm);                  // u <= p
         const double q1 = D * (1.0 - u);
@@ -367,7 +371,8 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
             }
         }
     }
-    const double sq = sqrt_pos0_1g(fma(c.K4, v1, c.K3 * v0));
+    // + 1e-300: v0 = v1 = 0 (two exponential-branch zeros in a row) must not reach the rsq seed; sqrt(1e-300) z0 is nothing
+    const double sq = sqrt_pos_1g(fma(c.K4, v1, fma(c.K3, v0, 1e-300)));
     x = fma(sq, z0, fma(c.K2, v1, fma(c.K1m, v0, x + K0)));
     vsum = vsum + v1;
     var = v1;

@@ -14,8 +14,8 @@
 //   u1 = (ra + 1/2) 2^-32                                   in (0,1), exact; R = sqrt(-ln u1) <= 4.78 (|z| <= 6.76)
 //   t  = 2 pi (rb + 1/2) 2^-32                              the angle, uniform on the full circle
 //   (w0, w1) = sqrt(-2 ln u1) (cos t, sin t) = R (sqrt2 cos t, sqrt2 sin t):  the Box-Muller pair
-//   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  stream 4 (Heston QE): one call per step, pair from
-//   (r0, r1), the exponential branch's uniform (r2 + 1/2) 2^-32.
+//   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  Heston QE: pairs from stream 4 (as stream 0), the
+//   exponential branch's uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2, drawn lazily.
 // Resolution: a pair carries 64 random bits (32 radius, 32 angle) where version 1 spent 128 -- the price of
 // halving the generator's share of the VALU-issue-bound stepping loop.  The radius is capped at sqrt(33 ln 2) = 4.78,
 // i.e. |z| <= 6.76: the truncated mass is 1.4e-11 per normal (about 30 draws in 2^41, none expected in one C2 call
@@ -252,24 +252,28 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_
     normals_from_words(odd ? r[2] : r[0], odd ? r[3] : r[1], t, 0.0, w0, w1);
 }
 
-// stream 4 (Heston QE): one call per step -- the pair from (r0, r1), the exponential branch's uniform from r2
-// (32 bits: the branch is truncated at e^-22), r3 unused.
-__device__ __forceinline__ void draw_qe(const PhiloxLane &lane, uint32_t step, const RngTables &t, double &w0,
-                                        double &w1, double &u)
-{
+// Heston QE (streams 4 and 5).  The scheme needs a pair every step (z0 for the log-price, z1 for the quadratic branch)
+// and a uniform only in the exponential branch: the pairs come from stream 4 exactly like stream 0's (one call per two
+// steps, rng_time_loop), the uniforms from stream 5 -- word step & 3 of call step >> 2, i.e. one call per FOUR steps --
+// drawn LAZILY: only when some lane of the wave is in the exponential branch at that step (a wave-uniform decision, so
+// every lane of the wave takes part in the call and keeps its four words for the rest of the group).  A parameter set
+// that never leaves the quadratic branch (Feller-satisfying sets on any sane grid) pays 12.5 Philox instructions per
+// step instead of 25; one that always does pays 18.75.
+struct QeUniforms {
     uint32_t r[4];
-    philox_draw(lane, step, r);
-    normals_from_words(r[0], r[1], t, 0.0, w0, w1);
-    u = uniform_32(r[2]);
-}
+    uint32_t group = 0xFFFFFFFFu;      // the call (step >> 2) the words belong to: wave-uniform
+};
 
-__device__ __forceinline__ void draw_qe(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
-                                        const RngTables &t, double &w0, double &w1, double &u)
+__device__ __forceinline__ double qe_uniform(const PhiloxLane &lane_u, uint32_t step, QeUniforms &cache)
 {
-    uint32_t r[4];
-    philox_draw(seed, c3 | 4u, path, step, r);
-    normals_from_words(r[0], r[1], t, 0.0, w0, w1);
-    u = uniform_32(r[2]);
+    const uint32_t g = step >> 2;
+    if (cache.group != g) {
+        philox_draw(lane_u, g, cache.r);
+        cache.group = g;
+    }
+    const uint32_t k = step & 3u;                                     // wave-uniform selects
+    const uint32_t w = (k == 0u) ? cache.r[0] : (k == 1u) ? cache.r[1] : (k == 2u) ? cache.r[2] : cache.r[3];
+    return uniform_32(w);
 }
 
 // stream 1: one uniform in (0,1) with 52 random bits
