@@ -14,7 +14,10 @@
 namespace svmc {
 
 constexpr int BLOCK = 256;             // 4 waves of 64 lanes
-constexpr int MAX_REDUCE_GRID = 1024;  // 256 CUs x 4 blocks: cap for grid-stride reductions
+#ifndef SVMC_MAX_REDUCE_GRID
+#define SVMC_MAX_REDUCE_GRID 1024
+#endif
+constexpr int MAX_REDUCE_GRID = SVMC_MAX_REDUCE_GRID;  // 256 CUs x 4 blocks: cap for grid-stride reductions
 
 // block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
 // 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
@@ -1440,13 +1443,19 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
     bool has_inv = false;
     auto flush = [&]() -> int {
         if (n_groups == 0) return SVMC_OK;
-        const dim3 grid(g, static_cast<unsigned>(n_groups));
+        // path blocks per group: about a thousand blocks per launch in all (512 are resident at the kernel's two waves
+        // per SIMD) -- more groups, fewer and longer-running blocks each, so that a block's set-up (its constants) and
+        // wind-down (the 48-value block reduction) are amortised over more paths (C3's 4 groups: 118 -> 108 us)
+        unsigned gx = (1024u + static_cast<unsigned>(n_groups) - 1u) / static_cast<unsigned>(n_groups);
+        gx = (gx < 128u) ? 128u : gx;
+        gx = (gx > g) ? g : gx;
+        const dim3 grid(gx, static_cast<unsigned>(n_groups));
         if (has_inv)
             launch_payoff_groups<true>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
         else
             launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(g), 3 * cols, sums + 3 * first_strike);
+                           static_cast<int>(gx), 3 * cols, sums + 3 * first_strike);
         first_strike += static_cast<size_t>(cols);
         n_groups = cols = kt = 0;
         has_inv = false;
