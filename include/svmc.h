@@ -98,10 +98,11 @@ SVMC_API int svmc_fill_state(double *x, double *vol, double *qvar, size_t n_path
 
 /* ---- counter-based randoms (replaces np.random.normal inside the generators,
  * pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370) ------------------------------
- * Philox4x32-10, key = seed, counter = (path_lo, path_hi, step, stream | call_id << 8); stream 0 is a
- * Box-Muller pair (w0, w1), stream 1 one uniform in (0,1).  `path` is the GLOBAL path id
- * path_offset + p, `step` the chain-global step id step_offset + t, so results do not depend on how
- * paths are sharded over GPUs.  Exact definition: DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c. */
+ * Philox4x32-7, key = seed, counter = (path_lo, path_hi, call index, stream | call_id << 8).  Stream 0: one call
+ * serves the Box-Muller pairs (w0, w1) of the two time steps 2c, 2c + 1 (a 32-bit radius uniform and a 32-bit
+ * full-circle angle per pair); stream 1: one 52-bit uniform in (0,1) per call.  `path` is the GLOBAL path id
+ * path_offset + p, `step` the chain-global step id step_offset + t, so results do not depend on how paths are
+ * sharded over GPUs or how a chain is sliced.  Exact definition: DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c. */
 SVMC_API int svmc_fill_normals(double *W0, double *W1, size_t ldw, size_t n_path, int nb_steps, uint64_t seed,
                       uint32_t call_id, uint64_t path_offset, uint32_t step_offset, svmc_stream_t stream);
 SVMC_API int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint64_t seed,

@@ -66,12 +66,14 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
 
 /* ---- counter-based RNG shared (by specification, not by code) with the HIP kernels ------------ */
 
-/* Philox4x32-10 (Salmon et al., SC'11). */
+/* Philox4x32 (Salmon et al., SC'11): the round function at any round count; _10 = the Random123 known-answer setting,
+ * the svmc streams use 7 rounds. */
 void svo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* The svmc draw: counter = (path_lo, path_hi, step, stream | call_id << 8), key = seed.
- * stream 0 -> Box-Muller pair (w0, w1); stream 1 -> one uniform in (0,1). */
+/* The svmc draw (stream definition version 2, svmc_oracle.c): counter = (path_lo, path_hi, call index, stream |
+ * call_id << 8), key = seed.  stream 0 -> the Box-Muller pair (w0, w1) of a time step (call step >> 1, half step & 1);
+ * stream 1 -> one uniform in (0,1) (call = step). */
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1);
 double svo_draw_uniform(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step);

@@ -30,7 +30,7 @@ def set_time_grid(ttm: float, nb_steps_per_year: int = 360) -> Tuple[int, float,
 
 # ---------------------------------------------------------------------------------------------------
 # seeding.  The reference seeds Numba's hidden per-thread MT19937 (set_seed) and its high-level wrappers
-# expose no seed.  Here the generators are counter-based (Philox4x32-10 keyed by a 64-bit seed and a
+# expose no seed.  Here the generators are counter-based (Philox4x32-7 keyed by a 64-bit seed and a
 # 24-bit call id, see DESIGN.md "RNG"): `set_seed(value)` fixes the key and rewinds the call counter, an
 # un-seeded process starts from OS entropy, and every generator call without an explicit `seed=` consumes
 # the next call id -- successive calls draw fresh, but replayable, randoms.
