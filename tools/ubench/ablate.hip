@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             xv += w0; q += w1;
         } else if (MODE == 4) {  // philox + table log + sqrt
             philox_draw(seed, 0, p, t, r);
-            const double e = neg_log_tab(mantissa_1_2(r[0], r[1]) - (1.0 - 0x1.0p-53), tab.log);
+            const double e = neg_log_tab<-32>(static_cast<double>(r[0]) + 0.5, tab.log);      // stream v2's radius
             xv += sqrt_pos_1g(e); q += mantissa_1_2(r[2], r[3]);
         } else if (MODE == 5) {  // philox + the table-assisted direction
             philox_draw(seed, 0, p, t, r);
-            double sn, cs; cossin_diag_tab(r[2], r[2], r[3], tab.diag, cs, sn);
+            double sn, cs; cossin_circle_tab32(r[1], tab.circle, cs, sn);                    // stream v2's direction
             xv += sn + mantissa_1_2(r[0], r[1]); q += cs;
         } else if (MODE == 6) {  // exp only
             L += 1e-3; s = exp_fast(L); xv += s;

@@ -6,7 +6,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
-#include "svmc_math.h"
+#include "svmc_rng.h"      // svmc_math.h + the tables of the draw
 using namespace svmc;
 
 __global__ void acc_kernel(const double *x, double *out, int n, int what)
@@ -21,7 +21,16 @@ __global__ void acc_kernel(const double *x, double *out, int n, int what)
     case 3: { double a = neg_log(v), b = -log(v); r = fabs(a - b) / fabs(b); } break;
     case 4: { double a = sqrt_pos(v), b = sqrt(v); r = fabs(a - b) / fabs(b); } break;
     case 5: { double a = rcp_fast(v), b = 1.0 / v; r = fabs(a - b) / fabs(b); } break;
-    case 6: { double a, b, s2, c2; cossin_diag(0, v, a, b); sincospi(0.5 * v, &s2, &c2); r = fmax(fabs(a - (c2 - s2)), fabs(b - (c2 + s2))); } break;
+    case 6: {       // stream v2's direction from a 32-bit angle word against OCML sincospi, v in [0, 1) turns
+        __shared__ CircleTabEntry tab[256];
+        for (unsigned k = threadIdx.x; k < 256u; k += blockDim.x) tab[k] = g_circle_table[k];
+        __syncthreads();
+        const uint32_t w = static_cast<uint32_t>(v * 4294967296.0);
+        double a, b, s2, c2;
+        cossin_circle_tab32(w, tab, a, b);
+        sincospi(2.0 * ((static_cast<double>(w) + 0.5) * 0x1.0p-32), &s2, &c2);
+        r = fmax(fabs(a - 1.4142135623730951 * c2), fabs(b - 1.4142135623730951 * s2));
+    } break;
     case 7: { double y = __builtin_amdgcn_sqrt(v); r = fabs(y * y / v - 1.0) * 0.5; } break;      // v_sqrt_f64 rel err
     }
     out[i] = r;
@@ -42,7 +51,16 @@ __global__ __launch_bounds__(256) void time_kernel(double *out, double seed, int
         if (WHAT == 6) acc += 1.0 / v;
         if (WHAT == 7) acc += rcp_fast(v);
         if (WHAT == 8) { double s, c; sincospi(v, &s, &c); acc += s + c; }
-        if (WHAT == 9) { double s, c; cossin_diag(i & 3, v - 0.5, c, s); acc += s + c; }
+        if (WHAT == 9) {
+            __shared__ CircleTabEntry tab[256];
+            if (i == 0) {
+                for (unsigned k = threadIdx.x; k < 256u; k += blockDim.x) tab[k] = g_circle_table[k];
+                __syncthreads();
+            }
+            double s, c;
+            cossin_circle_tab32(static_cast<uint32_t>(v * 1e6), tab, c, s);
+            acc += s + c;
+        }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -70,7 +88,7 @@ int main()
         {"v_sqrt_f64 rel err", 7, 1e-6, 80, true},
         {"exp_fast vs OCML exp rel, x in [-20,20]", 2, -20, 20, false}, {"neg_log vs OCML rel, u in (0,1)", 3, 1e-16, 1, true},
         {"sqrt_pos vs OCML rel", 4, 1e-12, 80, true}, {"rcp_fast vs IEEE div rel", 5, 0.01, 100, true},
-        {"cossin_diag vs OCML sincospi abs", 6, -0.5, 0.5, false}};
+        {"cossin_circle_tab32 vs OCML sincospi abs", 6, 0.0, 0.999999, false}};
     for (auto &t : tests) {
         for (int i = 0; i < n; ++i) {
             double u = (g() >> 11) * 0x1.0p-53;
@@ -83,7 +101,7 @@ int main()
         printf("%-45s max %.3e  (= 2^%.1f)\n", t.name, mx, std::log2(mx));
     }
     const int blocks = 256 * 8, iters = 4096;
-    const char *names[] = {"OCML exp", "exp_fast", "OCML log", "neg_log", "OCML sqrt", "sqrt_pos", "IEEE div", "rcp_fast", "OCML sincospi", "cossin_diag"};
+    const char *names[] = {"OCML exp", "exp_fast", "OCML log", "neg_log", "OCML sqrt", "sqrt_pos", "IEEE div", "rcp_fast", "OCML sincospi", "cossin_circle_tab32"};
     float ms[10] = {timeit<0>(dout, blocks, iters), timeit<1>(dout, blocks, iters), timeit<2>(dout, blocks, iters), timeit<3>(dout, blocks, iters),
                     timeit<4>(dout, blocks, iters), timeit<5>(dout, blocks, iters), timeit<6>(dout, blocks, iters), timeit<7>(dout, blocks, iters),
                     timeit<8>(dout, blocks, iters), timeit<9>(dout, blocks, iters)};
