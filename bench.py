@@ -241,8 +241,9 @@ class ClockPoller:
             self._t.join()
 
     def steady_mhz(self):
-        """median of the second half of the samples (the first half covers the sensor's lag)"""
-        half = self.samples[len(self.samples) // 2:]
+        """median of the busy readings in the second half of the samples (the first half covers the sensor's lag; a
+        reading below 500 MHz is the idle state the sensor reports between refreshes); None if there is none"""
+        half = [v for v in self.samples[len(self.samples) // 2:] if v > 500.0]
         return float(np.median(half)) if half else None
 
 

@@ -19,14 +19,19 @@ from stochvolmodels_amd.engine import get_engine  # noqa: E402
 
 
 def timed(fn, reps=5, warm=2):
+    """median wall time of `reps` synchronised calls (the median, not the mean: a process's first few hundred calls
+    contain one ~60 ms stall of the ROCm runtime, profiles/r02_runtime_stall.txt, which a mean over 3-10 calls would
+    spread over whatever leg it happens to land in)"""
     for _ in range(warm):
         fn()
     eng_sync()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         out = fn()
-    eng_sync()
-    return (time.perf_counter() - t0) / reps, out
+        eng_sync()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), out
 
 
 def eng_sync():
