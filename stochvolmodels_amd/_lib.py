@@ -9,7 +9,8 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsvmc.so")
+# SVMC_LIB: an alternative build of the same ABI (A/B runs of tools/ubench/build_variants.sh); default: the in-tree library
+LIB_PATH = os.environ.get("SVMC_LIB") or os.path.join(_PKG, "libsvmc.so")
 
 OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNKNOWN_PAYOFF, ERR_UNSUPPORTED_VARIABLE, ERR_WORKSPACE = range(6)
 

@@ -303,12 +303,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAI
 // NARR*U x 512 B in flight (hipcc does not unroll a loop that contains inline asm, and one load per array in
 // flight leaves the memory system latency-bound: 5.3 -> 5.7 TB/s for LogSV at U = 4; U = 8, 16 give no more).
 constexpr int STREAM_U = 4;
+#ifndef SVMC_ROUGH_STREAM_U
+#define SVMC_ROUGH_STREAM_U 4          // A/B hook: prefetch depth of the rough kernel's streamed normals
+#endif
 
-template <int NARR, class Step>
+template <int NARR, int U = STREAM_U, class Step>
 __device__ __forceinline__ void streamed_time_loop(const double *const (&w)[NARR], size_t ldw, int nb_steps,
                                                    Step &&step)
 {
-    constexpr int U = STREAM_U;
     double a[NARR][U], b[NARR][U];
     int t = 0;
     if (nb_steps >= U) {
@@ -571,7 +573,8 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
                           [&](double z0, double z1) { rough_step<N>(c, v, ls, y, z0, z1, exp_of); });
         } else {
             const double *const w[2] = {Z0 + p, Z1 + p};
-            streamed_time_loop<2>(w, ldw, nb_steps, [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1], exp_of); });
+            streamed_time_loop<2, SVMC_ROUGH_STREAM_U>(w, ldw, nb_steps,
+                                                       [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1], exp_of); });
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];
