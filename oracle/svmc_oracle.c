@@ -357,6 +357,26 @@ static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, 
     else pair_from_words(r[0], r[1], w0, w1);
 }
 
+/* the same pairs for a run of consecutive steps of ONE path: the call of steps 2c, 2c + 1 is evaluated once and kept
+ * (the full-size parity tests and bench.py's all-cores leg walk 10^9 path-steps through here) */
+typedef struct {
+    uint32_t r[4];
+    uint32_t call;
+    int valid;
+} pair_cache;
+
+static inline void draw_normals_cached(pair_cache *pc, uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
+                                       uint32_t stream, double *w0, double *w1)
+{
+    if (!pc->valid || pc->call != (step >> 1)) {
+        philox_draw(seed, call_id, path, step >> 1, stream, pc->r);
+        pc->call = step >> 1;
+        pc->valid = 1;
+    }
+    if (step & 1u) pair_from_words(pc->r[2], pc->r[3], w0, w1);
+    else pair_from_words(pc->r[0], pc->r[1], w0, w1);
+}
+
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1)
 {
@@ -420,8 +440,9 @@ void svo_logsv_terminal_rng(size_t n_path, int nb_steps, double dt,
 #endif
     for (size_t p = 0; p < n_path; ++p) {
         double xp = x[p], sp = sigma[p], qp = qvar[p], L = log(sp), w0, w1;
+        pair_cache pc = { {0u, 0u, 0u, 0u}, 0u, 0 };
         for (int t = 0; t < nb_steps; ++t) {
-            svo_draw_normals(seed, call_id, path_offset + p, step_offset + (uint32_t)t, &w0, &w1);
+            draw_normals_cached(&pc, seed, call_id, path_offset + p, step_offset + (uint32_t)t, 0u, &w0, &w1);
             logsv_step(&c, &xp, &L, &sp, &qp, c.sdt * w0, c.sdt * w1);
         }
         x[p] = xp; sigma[p] = sp; qvar[p] = qp;
@@ -441,14 +462,16 @@ void svo_heston_terminal_rng(size_t n_path, int nb_steps, double dt,
 #endif
     for (size_t p = 0; p < n_path; ++p) {
         double xp = x[p], vp = var[p], qp = qvar[p], w0, w1;
+        pair_cache pc = { {0u, 0u, 0u, 0u}, 0u, 0 };
         for (int t = 0; t < nb_steps; ++t) {
             uint32_t step = step_offset + (uint32_t)t;
             if (scheme == SVO_HESTON_QE) {
-                double u;
-                svo_draw_qe(seed, call_id, path_offset + p, step, &w0, &w1, &u);
-                heston_qe_step(&c, &xp, &vp, &qp, w0, w1, u);
+                uint32_t r[4];
+                draw_normals_cached(&pc, seed, call_id, path_offset + p, step, 4u, &w0, &w1);
+                philox_draw(seed, call_id, path_offset + p, step >> 2, 5u, r);
+                heston_qe_step(&c, &xp, &vp, &qp, w0, w1, ((double)r[step & 3u] + 0.5) * 0x1.0p-32);
             } else {
-                svo_draw_normals(seed, call_id, path_offset + p, step, &w0, &w1);
+                draw_normals_cached(&pc, seed, call_id, path_offset + p, step, 0u, &w0, &w1);
                 heston_euler_step(dt, theta, kappa, rho, rho_1, volvol, &xp, &vp, &qp, sdt * w0, sdt * w1);
             }
         }
