@@ -54,7 +54,7 @@ VALU_ISSUE_PEAK = N_SIMD * MAX_CLOCK_HZ / 4.0          # full-rate wave-instruct
 # ONE-TIME stall of the ROCm runtime -- a single call of ~60 ms observed at the ~150th chain call of a process for C2
 # and the ~41st for C4 (profiles/r02_runtime_stall.txt: 400-step runs, one slow step each, none afterwards) -- which a
 # 50-step window would otherwise swallow whole.  `ms_per_step_profile` in the output shows the timed steps one by one.
-PREWARM = 200
+PREWARM = int(os.environ.get("SVMC_BENCH_PREWARM", "200"))       # the environment override exists for the test suite
 # SURVEY.md 8(d)'s ESTIMATE of the algorithmic work per LogSV path-step in fp64 op-equivalents (34 simple flops + div 10
 # + sqrt 10 + exp/log/sincos 25 each + Philox/conversion ~ 11): a model of the reference's arithmetic, not a count
 LOGSV_FLOP_EQ_PER_PATH_STEP = 140.0

@@ -61,6 +61,28 @@ def test_normals_match_oracle_stream(sv, oracle):
     eng.close()
 
 
+def test_normal_stream_at_scale_on_device(sv):
+    """the counter-based stream at the scale it is used at: 2^28 normals of each component (2^22 paths x 64 steps:
+    global path ids and step indices both exercised, Philox-7, two steps per call) through the product's own
+    reduction -- sum exp(z) / n against the exact E[exp(Z)] = e^(1/2), four standard errors, no slack; the statistic
+    weighs the upper tail, where a generator defect or a wrong radius / angle map would show first"""
+    n, nb = 1 << 22, 64
+    eng = _engine(n, offset=3 * (1 << 40))
+    out_ptr, _ = eng.alloc_sums(2, "mgf")
+    exact, sd1 = np.exp(0.5), np.sqrt(np.exp(2.0) - np.exp(1.0))
+    for seed in (1, 20240927):
+        w0p, w1p = eng.fill_normals(nb, seed, call_id=2, step_offset=1001)       # an odd first step: half a call
+        for ptr in (w0p, w1p):
+            tot = 0.0
+            for t in range(nb):                          # each row is one time step of all paths
+                eng.spot_sums(ptr + 8 * t * n, 1.0, out_ptr)
+                sums = eng.download(out_ptr, 2)
+                assert sums[1] == n
+                tot += sums[0]
+            assert abs(tot / (n * nb) - exact) <= 4.0 * sd1 / np.sqrt(n * nb), (seed, tot / (n * nb) - exact)
+    eng.close()
+
+
 def test_uniforms_match_oracle_stream(sv, oracle):
     import ctypes as C
     from stochvolmodels_amd import _lib
@@ -1429,3 +1451,31 @@ def test_randomised_chain_sweep(sv, oracle):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(n_cases=40, seed=20240927) < 1e-8
+
+
+def test_bench_line_two_ranks(tmp_path):
+    """the driver's N > 1 invocation of bench.py, on the hardware there is: two ranks (gloo, sharing this GPU) launched
+    by torch.distributed.run.  The line must be the C4 workload (2^21 paths per GPU, 8 x 128 steps, 8 x 21 strikes) and
+    carry roofline, cpu_baseline, the N = 1 share rate and the whole-job-on-one-GPU leg, and the stream-ordered and
+    host-synchronised collectives must have produced identical bits."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVMC_DIST_BACKEND="gloo", SVMC_BENCH_PREWARM="12", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--steps", "4", "--warmup", "2", "--cpu-sample-paths", "4096"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["dtype"] == "f64"
+    assert line["config"]["workload"].startswith("C4") and line["config"]["paths_per_gpu"] == 1 << 21
+    assert line["config"]["paths_total"] == 1 << 22 and line["config"]["time_steps"] == 1024 and line["config"]["strikes"] == 168
+    assert line["value"] > 0 and line["unit"] == "path-steps/s"
+    r = line["roofline"]
+    assert r["kernel"] == "logsv_chain_rng_kernel" and r["bound"] == "valu_issue" and 0.0 < r["frac"] < 1.0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    assert line["n1_share_value"] > 0 and line["c4_full_one_gpu"]["paths"] == 1 << 22
+    assert line["stream_ordered_equals_strict_sync"] is True and line["comm"] == "TorchComm"
