@@ -181,7 +181,7 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
         if (so.q_snap != nullptr) so.q_snap[p] = q;
     }
     if (so.partials != nullptr) {
-        const double sp = so.forward * exp(xv);            // full-range exp: x = +-inf must give inf / 0   :61
+        const double sp = so.forward * exp_full(xv);       // full-range exp: x = +-inf must give inf / 0   :61
         const bool ok = active && (sp == sp);                                                   // nanmean :62
         double v[2] = {ok ? sp : 0.0, ok ? 1.0 : 0.0};
         block_sum_store<2>(v, lds, so.partials + static_cast<size_t>(so.ld) * blockIdx.x, 2);
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restri
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
     double v[2] = {0.0, 0.0};
     for (size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x; i < n; i += stride) {
-        const double sp = forward * exp(x[i]);             // full-range exp (user data may hold +-inf)     :61
+        const double sp = forward * exp_full(x[i]);        // full-range exp (user data may hold +-inf)     :61
         if (sp == sp) {                                                                         // nanmean :62
             v[0] += sp;
             v[1] += 1.0;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
 
     // one path's contribution to every strike of the group
     const auto add_path = [&](double xi, double qi) {
-        const double spot = forward * exp(xi) - corr;                                           // :61-63
+        const double spot = forward * exp_full(xi) - corr;                                      // :61-63
         const double u = need_q ? qi / inv_ttm_arg : spot;                                      // :65-68
 #pragma unroll
         for (int k = 0; k < KT; ++k) {

@@ -7,6 +7,7 @@ static const double EXP_TAB[256] = {SVMC_EXP_TABLE_INIT};
 static const svmc::CircleTabEntry CIRCLE_TAB[256] = {SVMC_CIRCLE_TABLE_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
+void probe_exp_full(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_full(x[i]); }
 void probe_exp_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_tab(x[i], EXP_TAB); }
 void probe_exp2u_tab(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp2u_tab(x[i], EXP_TAB); }
 void probe_neg_log(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::neg_log(x[i]); }

@@ -51,6 +51,26 @@ def test_exp(probe):
     assert np.isnan(_call(probe, "probe_exp", np.array([np.nan]))[0])
 
 
+def test_exp_full(probe):
+    """exp_full: the exponential of the payoff reductions -- any double in, the libm answer out: <= 2 ULP on the finite
+    range incl. the denormal results below e^-708, inf above the overflow point, +0 below the last denormal, +-inf and
+    NaN handled (terminal log-returns of overflowed paths reach it)"""
+    rng = np.random.default_rng(3)
+    for lo, hi in ((-1, 1), (-30, 30), (-708, 709.7)):
+        x = rng.uniform(lo, hi, N)
+        assert _ulp(_call(probe, "probe_exp_full", x), np.exp(x.astype(np.longdouble))) <= 2.0
+    x = rng.uniform(-745.0, -708.0, 20000)                              # gradual underflow: denormal results
+    got, ref = _call(probe, "probe_exp_full", x), np.exp(x)
+    assert np.all(np.abs(got - ref) <= 2.0 * 4.9406564584124654e-324 + 4e-16 * ref)
+    edge = np.array([709.78, 709.79, 745.9, 746.0, 746.1, 1e4, 1e300, np.inf, -745.13, -745.2, -746.0, -746.1, -1e4, -1e300, -np.inf, 0.0])
+    with np.errstate(over="ignore", under="ignore"):
+        want = np.exp(edge)
+    got = _call(probe, "probe_exp_full", edge)
+    for g_, w_, x_ in zip(got, want, edge):
+        assert (g_ == w_) or (np.isfinite(w_) and w_ > 0 and abs(g_ / w_ - 1) < 1e-15) or (w_ < 1e-320 and abs(g_ - w_) < 1e-322), (x_, g_, w_)
+    assert np.isnan(_call(probe, "probe_exp_full", np.array([np.nan]))[0])
+
+
 def test_exp_table(probe):
     """exp_tab (256-entry table, quadratic tail, one-constant reduction: the exponential of the issue-bound stepping
     kernels, whose arguments are log-volatilities).  <= 1.5 ULP on |x| <= 1, <= 3 ULP on |x| <= 5; the one-constant

@@ -19,10 +19,11 @@ import sys
 KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "logsv_w_kernel")
 NOTES = {
     "logsv_chain_rng_kernel": "traffic above the 48 + 8 M algorithmic bytes per path is register-spill scratch: at its 64-VGPR "
-                              "budget (8 waves per SIMD) the whole-chain kernel parks 132 B per lane of state that is dead inside "
-                              "the time loop (x, qvar, the path index, slice bookkeeping) in scratch at the 8 slice boundaries -- "
-                              "~0.87 GB per launch = 180 GB/s over 4.8 ms, 2 % of HBM peak and overlapped with the VALU-bound "
-                              "stepping; lifting the cap to 72 / 80 VGPRs (7 / 6 waves) keeps 96 / 68 B of it and measured the "
+                              "budget (8 waves per SIMD) the whole-chain kernel parks 68 B per lane of values that are dead "
+                              "inside the time loop (x, qvar, slice bookkeeping, polynomial start constants) in scratch at the "
+                              "8 slice boundaries -- ~0.33 GB per launch = 70 GB/s over 4.7 ms, under 1 % of HBM peak and "
+                              "overlapped with the VALU-bound stepping (132 B / 0.87 GB before the slice epilogue switched from "
+                              "the device libm's exp to exp_full); lifting the cap to 72 / 80 VGPRs (7 / 6 waves) measured the "
                               "same time (profiles/r02_ab_chain_residency.jsonl)",
 }
 
