@@ -296,7 +296,7 @@ def test_bench_workloads_and_roofline_arithmetic():
     slots = (71.0 + 6.0) * (2 ** 20 / 64) * 1024 / 2.0e-3
     assert r["roofline"]["bound"] == "valu_issue" and abs(r["roofline"]["achieved"] - slots) < 1e-3 * slots
     assert abs(r["roofline"]["peak"] - 1024 * 2.4e9 / 4) < 1 and abs(r["roofline"]["frac"] - slots / 6.144e11) < 1e-12
-    assert abs(r["roofline"]["frac_at_measured_clock"] - r["roofline"]["frac"]) < 1e-12 and r["roofline"]["traffic"] == 59.0e6
+    assert r["roofline"]["clock_mhz_sensor"] == 2400.0 and r["roofline"]["traffic"] == 59.0e6
     assert r["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
     # without a committed counter pass for the kernel the line falls back to the HBM roof instead of inventing a count
     assert bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, {}, None)["roofline"]["bound"] == "hbm"
