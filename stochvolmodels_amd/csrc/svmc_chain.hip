@@ -316,8 +316,15 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
             SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
             int rc = SVMC_OK;
             hipError_t e = hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream);
-            if (e == hipSuccess) rc = fill_state_indirect(s->x, s->vol, s->qvar, n, g.params_dev, s->stream);   // :1128-1130
-            for (int i = 0; i < c.m && e == hipSuccess && rc == SVMC_OK; ++i) {                                    // :1136-1160
+            if (e == hipSuccess && c.m <= MAX_FUSED_SLICES) {
+                // the whole chain in one launch: state initialised in the kernel (:1128-1130), slice loop inside (:1136-1160)
+                double *qsnaps = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
+                rc = logsv_chain_w_indirect(s->x, s->vol, s->qvar, n, c.m, nb_steps_host, g.params_dev + 1, g.params_dev, W0s, W1s,
+                                            ldw, c.forwards, s->snap, qsnaps, s->spot, s->ws, s->ws_bytes, s->stream);
+            } else if (e == hipSuccess) {
+                rc = fill_state_indirect(s->x, s->vol, s->qvar, n, g.params_dev, s->stream);                       // :1128-1130
+            }
+            for (int i = 0; c.m > MAX_FUSED_SLICES && i < c.m && e == hipSuccess && rc == SVMC_OK; ++i) {           // :1136-1160
                 double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m + i) * n : nullptr;
                 rc = logsv_slice_w_indirect(s->x, s->vol, s->qvar, n, nb_steps_host[i],
                                             g.params_dev + 1 + static_cast<size_t>(i) * LOGSV_CONSTS_DOUBLES, W0s[i], W1s[i],

@@ -33,6 +33,11 @@ int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                            const double *W0, const double *W1, size_t ldw, double forward, double *x_snapshot,
                            double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
                            hipStream_t stream);
+constexpr int MAX_FUSED_SLICES = 16;    // = MAX_CHAIN_SLICES of svmc_kernels.hip
+int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                           const double *consts_dev, const double *vol0_dev, const double *const *W0s, const double *const *W1s,
+                           size_t ldw, const double *forwards_host, double *x_snapshots, double *qvar_snapshots,
+                           double *spot_sums, void *workspace, size_t workspace_bytes, hipStream_t stream);
 void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
                              int is_spot_measure, double *out);
 

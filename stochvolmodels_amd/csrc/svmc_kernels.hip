@@ -8,6 +8,7 @@
 #include "svmc_internal.h"
 
 #include <cstring>
+#include <utility>
 #include "svmc_models.h"
 #include "svmc_rng.h"
 
@@ -397,6 +398,58 @@ __global__ __launch_bounds__(BLOCK) void logsv_w_indirect_kernel(double *__restr
     logsv_w_body(x, sigma, qvar, n, nb_steps, c, W0, W1, ldw, so);
 }
 
+// All expiries of a chain on resident fixed randoms in ONE launch, state initialised in the kernel: what the graph of
+// svmc_logsv_chain_price_fixed replays per calibration iterate.  An objective evaluation on a 4 x 13 chain with 10^5 paths
+// is a dozen microsecond-scale kernels; one launch per expiry (+ its reduce) and a separate fill were most of them.
+// Per slice the arithmetic is logsv_w_body's (L re-derived from sigma at the slice start), so the bits equal the
+// slice-by-slice launches.  `init` != nullptr: start every path from (0, *init, 0) instead of reading the state.
+struct ChainWSlices {
+    const double *W0[MAX_CHAIN_SLICES], *W1[MAX_CHAIN_SLICES];
+    double forward[MAX_CHAIN_SLICES];
+    int nb_steps[MAX_CHAIN_SLICES];
+    int m;
+};
+
+__global__ __launch_bounds__(BLOCK) void logsv_chain_w_indirect_kernel(double *__restrict__ x, double *__restrict__ sigma,
+                                                                       double *__restrict__ qvar, size_t n, ChainWSlices cs,
+                                                                       const LogsvConsts *__restrict__ consts,
+                                                                       const double *__restrict__ init, size_t ldw,
+                                                                       double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                       double *__restrict__ partials)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const bool active = p < n;
+    double xv = 0.0, s = 1.0, q = 0.0;
+    if (active) {
+        if (init != nullptr) {
+            s = *init;
+        } else {
+            xv = x[p];
+            s = sigma[p];
+            q = qvar[p];
+        }
+    }
+    for (int i = 0; i < cs.m; ++i) {
+        if (active) {
+            const LogsvConsts c = consts[i];                    // wave-uniform: scalar loads
+            double L = log(s);
+            const double *const w[2] = {cs.W0[i] + p, cs.W1[i] + p};
+            streamed_time_loop<2>(w, ldw, cs.nb_steps[i], [&](const double(&v)[2]) {
+                logsv_step(c, xv, L, s, q, c.sdt * v[0], c.sdt * v[1]);                           // :1028-1030
+            });
+        }
+        const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
+                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+        slice_epilogue(so, p, active, xv, q);
+        __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
+    }
+    if (active) {
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__restrict__ x, double *__restrict__ vol,
                                                                     double *__restrict__ qvar, size_t n,
                                                                     const double *__restrict__ vol0)
@@ -773,6 +826,14 @@ __global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restri
 //     strikes).  The time loop has NO per-strike condition: the unused strikes of a group carry c = -inf.
 //   inverse payoffs (IC / IP, HAS_INV): pay / spot can be NaN (0/0, inf/inf): per-strike NaN test and count kept.
 constexpr int PAYOFF_GROUPS = 6;       // groups per launch: 6 x 632 B of descriptors stay inside the 4 KB kernarg segment
+#ifndef SVMC_PAYOFF_PREFETCH
+#define SVMC_PAYOFF_PREFETCH 4
+#endif
+constexpr int PAYOFF_PREFETCH = SVMC_PAYOFF_PREFETCH;     // trips between a path's load and its use (A/B: tools/ubench)
+#ifndef SVMC_PAYOFF_BLOCKS
+#define SVMC_PAYOFF_BLOCKS 1024
+#endif
+constexpr unsigned PAYOFF_BLOCKS = SVMC_PAYOFF_BLOCKS;    // path blocks per payoff launch, all groups together
 constexpr int PAYOFF_KT = 24;          // strikes per group (the BASELINE chains have 21 per expiry)
 
 struct PayoffGroup {
@@ -798,9 +859,11 @@ __device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigne
     return static_cast<double>(full * BLOCK + part);
 }
 
-template <int KT, bool HAS_INV>
-__global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pack, size_t n, int variable_type,
-                                                             double *__restrict__ partials, int ld)
+// waves per SIMD the register allocator must leave room for: the accumulators (4 or 6 registers per strike) set it
+constexpr int payoff_min_waves(int kt, bool has_inv) { return kt <= (has_inv ? 8 : 15) ? 3 : 2; }
+
+template <int KT, bool HAS_INV, bool NEED_Q>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld)
 {
     constexpr int NACC = HAS_INV ? 3 : 2;
     __shared__ double lds[4 * NACC * KT];
@@ -816,16 +879,25 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         sg[k] = d.sg[k];                                   // stays wave-uniform: the scalar operand of the FMA
-        c[k] = d.c[k];
-        shift[k] = d.shift[k];
-        // these two live in VECTOR registers: left wave-uniform the compiler keeps all three constants in SGPRs, runs
-        // out (3 x 24 doubles) and re-reads the spills with v_readlane_b32 -- VALU instructions on top of the five
-        // per strike per path that do the work
-        asm volatile("" : "+v"(c[k]), "+v"(shift[k]));
+        // plain chains: payoff - shift = max(sg u + c, 0) - shift = max(sg u + (c - shift), -shift): the recentring rides
+        // in the FMA's addend and the max's floor, four instructions per strike per path instead of five
+        if constexpr (HAS_INV) {
+            c[k] = d.c[k];
+            shift[k] = d.shift[k];
+            // these two live in VECTOR registers: left wave-uniform the compiler keeps all three constants in SGPRs, runs
+            // out (3 x 24 doubles) and re-reads the spills with v_readlane_b32 -- VALU instructions on top of the ones
+            // that do the work
+            asm volatile("" : "+v"(c[k]), "+v"(shift[k]));
+        } else {
+            // ... and both are RESULTS of vector arithmetic: they stay in vector registers without a pin, and fmax()
+            // knows them quiet (an opaque operand costs a second v_max per strike per path to quiet it)
+            c[k] = d.c[k] - d.shift[k];
+            shift[k] = 0.0 - d.shift[k];
+        }
     }
 #pragma unroll
     for (int j = 0; j < NACC * KT; ++j) acc[j] = 0.0;
-    const bool need_q = variable_type != SVMC_LOG_RETURN;
+    constexpr bool need_q = NEED_Q;                        // options on realised variance (SVMC_Q_VAR)
 
     // one path's contribution to every strike of the group
     const auto add_path = [&](double xi, double qi) {
@@ -833,8 +905,8 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
         const double u = need_q ? qi / inv_ttm_arg : spot;                                      // :65-68
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            double pay = fmax(fma(sg[k], u, c[k]), 0.0);                                        // :75-82
-            if (HAS_INV) {
+            if constexpr (HAS_INV) {
+                double pay = fmax(fma(sg[k], u, c[k]), 0.0);                                    // :75-82
                 if (inv_mask & (1u << k)) pay = pay / spot;
                 if (pay == pay) {                                                               // nanmean/nanstd
                     const double dd = pay - shift[k];
@@ -843,22 +915,27 @@ __global__ __launch_bounds__(BLOCK) void payoff_group_kernel(PayoffGroupPack pac
                     acc[2 * KT + k] += 1.0;
                 }
             } else {
-                const double dd = pay - shift[k];
+                const double dd = fmax(fma(sg[k], u, c[k]), shift[k]);                          // :75-82, recentred
                 acc[k] += dd;
                 acc[KT + k] = fma(dd, dd, acc[KT + k]);
             }
         }
     };
-    size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    double xn = (i < n) ? x[i] : 0.0, qn = (need_q && i < n) ? qvar[i] : 0.0;
-    for (; i < n; i += stride) {
-        const double xi = xn, qi = qn;
-        if (i + stride < n) {                              // the next path's loads fly while this one is worked on
-            xn = x[i + stride];
-            if (need_q) qn = qvar[i + stride];
-        }
-        add_path(xi, qi);
+    // A trip is ~130 VALU instructions (~0.25 us) and the kernel runs two or three waves per SIMD (its accumulators fill the
+    // register file): a load issued one trip ahead is not back in time.  The trips every lane of the block makes go
+    // through the batched double buffer of the streamed generators (loads PAYOFF_PREFETCH trips ahead, no per-lane
+    // branches, so the waits are counted ones); the last, ragged trip is taken on its own.
+    const size_t i0 = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const size_t block_last = static_cast<size_t>(blockIdx.x) * BLOCK + (BLOCK - 1);
+    const int full_trips = (n > block_last) ? static_cast<int>((n - 1 - block_last) / stride + 1) : 0;     // block-uniform
+    if constexpr (need_q) {
+        const double *const w[2] = {x + i0, qvar + i0};
+        streamed_time_loop<2, PAYOFF_PREFETCH>(w, stride, full_trips, [&](const double(&v)[2]) { add_path(v[0], v[1]); });
+    } else {
+        const double *const w[1] = {x + i0};
+        streamed_time_loop<1, PAYOFF_PREFETCH>(w, stride, full_trips, [&](const double(&v)[1]) { add_path(v[0], 0.0); });
     }
+    for (size_t i = i0 + static_cast<size_t>(full_trips) * stride; i < n; i += stride) add_path(x[i], need_q ? qvar[i] : 0.0);
     // output row layout: [sum d, sum d^2, count] per strike, interleaved, at column 3 (col + k)
     double *row = partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col;
     const double cnt = block_path_count(n, blockIdx.x, gridDim.x);
@@ -1128,6 +1205,39 @@ int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                        nb_steps, reinterpret_cast<const LogsvConsts *>(consts_dev), W0, W1, ldw, so);
     if (int rc = check_launch(fn)) return rc;
     return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, reinterpret_cast<svmc_stream_t>(stream));
+}
+
+// every expiry of a chain on resident randoms in one launch + one column reduce (graph-replayed driver, svmc_chain.hip):
+// consts_dev = [m] LogsvConsts, vol0_dev = the initial volatility (state is initialised in the kernel), x_snapshots [m][n],
+// qvar_snapshots [m][n] or null, spot_sums [2m]
+int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                           const double *consts_dev, const double *vol0_dev, const double *const *W0s, const double *const *W1s,
+                           size_t ldw, const double *forwards_host, double *x_snapshots, double *qvar_snapshots,
+                           double *spot_sums, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    const char *fn = "logsv_chain_w_indirect";
+    if (n_slices < 1 || n_slices > MAX_CHAIN_SLICES || n_path == 0 || ldw < n_path)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
+    const unsigned g = grid_for(n_path);
+    if (workspace_bytes < static_cast<size_t>(g) * 2 * n_slices * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
+    ChainWSlices cs;
+    cs.m = n_slices;
+    for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+        const int j = (i < n_slices) ? i : 0;
+        if (W0s[j] == nullptr || W1s[j] == nullptr || nb_steps_host[j] <= 0)
+            return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad randoms / step counts");
+        cs.W0[i] = W0s[j];
+        cs.W1[i] = W1s[j];
+        cs.forward[i] = forwards_host[j];
+        cs.nb_steps[i] = (i < n_slices) ? nb_steps_host[j] : 0;
+    }
+    hipLaunchKernelGGL(logsv_chain_w_indirect_kernel, dim3(g), dim3(BLOCK), 0, stream, x, sigma, qvar, n_path, cs,
+                       reinterpret_cast<const LogsvConsts *>(consts_dev), vol0_dev, ldw, x_snapshots, qvar_snapshots,
+                       static_cast<double *>(workspace));
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_slices), dim3(BLOCK), 0, stream,
+                       static_cast<const double *>(workspace), static_cast<int>(g), 2 * n_slices, spot_sums);
+    return check_launch(fn);
 }
 
 void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
@@ -1406,17 +1516,24 @@ int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_
 
 // the launches of svmc_payoff_sums / svmc_payoff_sums_chain: groups of <= PAYOFF_KT strikes of one expiry, <= PAYOFF_GROUPS
 // groups per launch, every launch followed by its column reduce
+// one kernel per group width: a chain's 21 (or 13) strikes per expiry are worked on as 21, not as the next multiple of 8
+using PayoffKernel = void (*)(PayoffGroupPack, size_t, double *, int);
+template <bool HAS_INV, bool NEED_Q, int... KS>
+static PayoffKernel payoff_kernel_for(int kt, std::integer_sequence<int, KS...>)
+{
+    static const PayoffKernel table[] = {payoff_group_kernel<KS + 1, HAS_INV, NEED_Q>...};
+    return table[kt - 1];
+}
+constexpr int PAYOFF_KT_INV = 16;      // inverse chains: three accumulators per strike, 24 would leave one wave per SIMD
+
 template <bool HAS_INV>
 static void launch_payoff_groups(int kt, dim3 grid, hipStream_t st, const PayoffGroupPack &pack, size_t n, int variable_type,
                                  double *partials, int ld)
 {
-    if (kt <= 8)
-        hipLaunchKernelGGL((payoff_group_kernel<8, HAS_INV>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials, ld);
-    else if (kt <= 16)
-        hipLaunchKernelGGL((payoff_group_kernel<16, HAS_INV>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials, ld);
-    else if (!HAS_INV)      // inverse chains are grouped by 16 (payoff_sums_impl): their third accumulator would not fit
-        hipLaunchKernelGGL((payoff_group_kernel<PAYOFF_KT, false>), grid, dim3(BLOCK), 0, st, pack, n, variable_type, partials,
-                           ld);
+    constexpr auto widths = std::make_integer_sequence<int, HAS_INV ? PAYOFF_KT_INV : PAYOFF_KT>();
+    const PayoffKernel kern = (variable_type == SVMC_Q_VAR) ? payoff_kernel_for<HAS_INV, true>(kt, widths)
+                                                            : payoff_kernel_for<HAS_INV, false>(kt, widths);
+    hipLaunchKernelGGL(kern, grid, dim3(BLOCK), 0, st, pack, n, partials, ld);
 }
 
 static int payoff_sums_impl(const char *fn, const double *const *xs, const double *const *qs, size_t n_path,
@@ -1433,7 +1550,7 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
     }
     // strikes per group: 24 for plain chains (two accumulators per strike); 16 when the chain holds inverse options
     // (three accumulators per strike: 24 of them would leave one wave per SIMD)
-    const size_t KG = any_inv ? 16 : PAYOFF_KT;
+    const size_t KG = any_inv ? PAYOFF_KT_INV : PAYOFF_KT;
     const unsigned g = reduce_grid(n_path);
     if (workspace_bytes < static_cast<size_t>(g) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_payoff_workspace_bytes)");
@@ -1449,7 +1566,7 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
         // path blocks per group: about a thousand blocks per launch in all (512 are resident at the kernel's two waves
         // per SIMD) -- more groups, fewer and longer-running blocks each, so that a block's set-up (its constants) and
         // wind-down (the 48-value block reduction) are amortised over more paths (C3's 4 groups: 118 -> 108 us)
-        unsigned gx = (1024u + static_cast<unsigned>(n_groups) - 1u) / static_cast<unsigned>(n_groups);
+        unsigned gx = (PAYOFF_BLOCKS + static_cast<unsigned>(n_groups) - 1u) / static_cast<unsigned>(n_groups);
         gx = (gx < 128u) ? 128u : gx;
         gx = (gx > g) ? g : gx;
         const dim3 grid(gx, static_cast<unsigned>(n_groups));

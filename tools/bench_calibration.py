@@ -47,24 +47,23 @@ def main():
     def ivols(prices):
         return chain0.compute_model_ivols_from_chain_data(model_prices=prices)
 
+    def timed(fn, n=200):
+        """median wall time of one call: the ROCm runtime stalls the process once for tens of ms a fixed time after
+        start-up (profiles/r02_runtime_stall.txt), which a mean over a short loop smears over whatever runs then"""
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
     pr = price()
-    ivols(pr)
-    n = 50
-    t0 = time.perf_counter()
-    for _ in range(n):
-        pr = price()
-    t_price = (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for _ in range(n):
-        ivols(pr)
-    t_iv = (time.perf_counter() - t0) / n
+    t_price = timed(price)
+    t_iv = timed(lambda: ivols(pr))
     steps = sum(res.nb_steps)
     lp.FUSED_FIXED_RANDOMS_DRIVER = False
-    price()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        price()
-    t_price_py = (time.perf_counter() - t0) / n
+    t_price_py = timed(price)
     lp.FUSED_FIXED_RANDOMS_DRIVER = True
     from stochvolmodels_amd.engine import option_type_codes
     direct = lambda g: res.price_logsv_chain(ttms, chain0.forwards, chain0.discfactors, [k] * 4,       # noqa: E731
@@ -72,11 +71,7 @@ def main():
                                              p.volvol, np.ones(4), True, 1, use_graph=g)
     t_direct = {}
     for g in (False, True):
-        direct(g)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            direct(g)
-        t_direct[g] = (time.perf_counter() - t0) / n
+        t_direct[g] = timed(lambda: direct(g))
     print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
                           fused_graph_ms=1e3 * t_direct[True],
                           ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
