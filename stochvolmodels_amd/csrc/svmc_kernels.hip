@@ -668,8 +668,9 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(doub
             uint32_t step = step_offset;
             double vsum = 0.0;
             const double v_first = v;
+            const QeVec qv = make_qe_vec(qc);
             rng_time_loop(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
-                heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
+                heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
                 ++step;
             });
             heston_qe_fold(qc, q, vsum, v_first, v);
@@ -728,8 +729,9 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kerne
                 double vsum = 0.0;
                 const double v_first = v;
                 uint32_t st = step;
+                const QeVec qv = make_qe_vec(qc);
                 rng_time_loop(lane, step, nb, tab, [&](double w0, double w1) {
-                    heston_qe_step(qc, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
+                    heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
                     ++st;
                 });
                 heston_qe_fold(qc, q, vsum, v_first, v);
@@ -783,8 +785,9 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
     double xv = x[p], v = var[p], q = qvar[p], vsum = 0.0;
     const double v_first = v;
     const double *const w[3] = {Z0 + p, Z1 + p, U + p};
+    const QeVec qv = make_qe_vec(qc);
     streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) {
-        heston_qe_step(qc, tab, xv, v, vsum, z[0], z[1], [&]() { return z[2]; });
+        heston_qe_step(qc, qv, tab, xv, v, vsum, z[0], z[1], [&]() { return z[2]; });
     });
     heston_qe_fold(qc, q, vsum, v_first, v);
     x[p] = xv;

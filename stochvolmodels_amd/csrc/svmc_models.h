@@ -255,8 +255,20 @@ __device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double
 
 // ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------
 struct QeConsts {
-    double dt, theta, E, c1, c2, K1m, K2, K3, K4, A, twoA, K0_plain, K13;
+    double dt, theta, E, c1, c2, K1m, K2, K3, K4, A, twoA, K0_plain2, K13_2, m0;     // ..2: twice the constant
 };
+
+// The two constants that multiply the variance, held in VECTOR registers: an instruction takes one scalar-register operand
+// on this chip, so fma(v0, E, m0) and fma(v0, c1, c2) with all four in scalar registers each cost a v_mov on top
+struct QeVec {
+    double E, c1;
+};
+__device__ __forceinline__ QeVec make_qe_vec(const QeConsts &c)
+{
+    QeVec v = {c.E, c.c1};
+    asm volatile("" : "+v"(v.E), "+v"(v.c1));
+    return v;
+}
 
 inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho, double volvol)
 {
@@ -275,9 +287,11 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     c.K4 = g2 * dt * (1.0 - rho * rho);
     c.A = c.K2 + 0.5 * c.K4;
     c.twoA = 2.0 * c.A;
-    c.K0_plain = -rho * kappa * theta / volvol * dt;
-    c.K13 = K1 + 0.5 * c.K3;
-    c.K1m = K1 - c.K13;                                   // the martingale correction's -K13 v0 rides on the K1 v0 term
+    const double K13 = K1 + 0.5 * c.K3;
+    c.K0_plain2 = 2.0 * (-rho * kappa * theta / volvol * dt);
+    c.K13_2 = 2.0 * K13;
+    c.m0 = theta * (1.0 - E);                             // E[v1 | v0] = v0 E + theta (1 - E)
+    c.K1m = K1 - K13;                                     // the martingale correction's -K13 v0 rides on the K1 v0 term
     return c;
 }
 
@@ -314,18 +328,18 @@ __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, co
 // table.  The quadratic variance is dt (sum of the new variances + (v_first - v_last)/2): the caller keeps `vsum` and
 // folds it in (heston_qe_fold); x carries the martingale correction with its -K13 v0 term folded into K1m.
 template <class DrawU>
-__device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEntry *tab, double &x, double &var,
-                                               double &vsum, double z0, double z1, DrawU &&draw_u)
+__device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &cv, const LogTabEntry *tab, double &x,
+                                               double &var, double &vsum, double z0, double z1, DrawU &&draw_u)
 {
     const double v0 = var;
-    const double m = fma(v0 - c.theta, c.E, c.theta);
-    const double s2 = fma(v0, c.c1, c.c2);
+    const double m = fma(v0, cv.E, c.m0);
+    const double s2 = fma(v0, cv.c1, c.c2);
     const double m2 = m * m;
-    double v1, K0;                                        // K0 without its -K13 v0 term
+    double v1, Kd;                                        // Kd = 2 K0, K0 without its -K13 v0 term (the half rides in x's FMA)
     const bool quad = s2 <= 1.5 * m2;                     // psi <= psi_c, decided without the divide
     // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
     // on-device draw is a Philox call that serves four steps: every lane must take part in it)
-    double u = 0.5;
+    double u = m;                                         // any defined value: only lanes past the test below read it
     if (!__all(quad)) u = draw_u();
     if (quad) {
         const double tm2 = m2 + m2;
@@ -336,19 +350,20 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
         const double t = fma(z1, fma(s2, z1, g + g), N);  // (sqrt N + sqrt s2 z1)^2 up to rounding: clamped at 0 below
         if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
             v1 = fmax((m * rcp_1n(T)) * t, 0.0);
-            K0 = 0.0;
+            Kd = 0.0;
         } else {
-            const double ams2 = (c.twoA * m) * s2;
+            const double tam = c.twoA * m;
+            const double ams2 = tam * s2;
             const double dn = T - ams2;                   // T (1 - 2 A a)
             if (dn > 0.0) {
                 const double r = rcp_1n(T * dn);
                 const double invT = dn * r, invD = T * r;
                 v1 = fmax((m * invT) * t, 0.0);
                 const double ln_den = log_one_minus(ams2 * invT, dn * invT, tab);
-                K0 = fma(-(c.A * m) * N, invD, 0.5 * ln_den);
+                Kd = fma(-(tam * N), invD, ln_den);       // 2 K0 = ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)
             } else {
                 v1 = fmax((m * rcp_1n(T)) * t, 0.0);
-                K0 = fma(c.K13, v0, c.K0_plain);          // the plain drift: cancels the folded -K13 v0
+                Kd = fma(c.K13_2, v0, c.K0_plain2);       // the plain drift: cancels the folded -K13 v0
             }
         }
     } else {
@@ -360,20 +375,20 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const LogTabEn
         const double lg = neg_log_tab((m2 + m2) * iq1, tab);   // -ln((1 - p)/(1 - u)): <= 0 wherever u > p
         v1 = zero ? 0.0 : (-lg) * ((0.5 * D) * im);
         if (c.A == 0.0) {
-            K0 = 0.0;
+            Kd = 0.0;
         } else {
             const double e = fma(-c.A, D, m + m);         // D (beta - A)
             if (e > 0.0) {
                 const double r2 = rcp_1n(D * e);
-                K0 = neg_log_tab(fma(dm, e, 4.0 * m * m2) * r2, tab);
+                Kd = 2.0 * neg_log_tab(fma(dm, e, 4.0 * m * m2) * r2, tab);
             } else {
-                K0 = fma(c.K13, v0, c.K0_plain);
+                Kd = fma(c.K13_2, v0, c.K0_plain2);
             }
         }
     }
     // + 1e-300: v0 = v1 = 0 (two exponential-branch zeros in a row) must not reach the rsq seed; sqrt(1e-300) z0 is nothing
     const double sq = sqrt_pos_1g(fma(c.K4, v1, fma(c.K3, v0, 1e-300)));
-    x = fma(sq, z0, fma(c.K2, v1, fma(c.K1m, v0, x + K0)));
+    x = fma(sq, z0, fma(c.K2, v1, fma(c.K1m, v0, fma(0.5, Kd, x))));
     vsum = vsum + v1;
     var = v1;
 }
