@@ -678,7 +678,7 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(doub
             v = heston_euler_guard_zero(v);
             rng_time_loop(lane, step_offset, nb_steps, tab,
                           [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
-            heston_fold_acc(ef, xv, q, xacc, vacc);
+            heston_fold_acc(ef, xv, q, v, xacc, vacc);
         }
         x[p] = xv;
         var[p] = v;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kerne
                 v = heston_euler_guard_zero(v);
                 rng_time_loop(lane, step, nb, tab,
                               [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
-                heston_fold_acc(ef, xv, q, xacc, vacc);
+                heston_fold_acc(ef, xv, q, v, xacc, vacc);
             }
         }
         step += static_cast<uint32_t>(nb);

@@ -235,7 +235,9 @@ __device__ __forceinline__ void heston_euler_step_acc(const HestonEulerFast &f, 
     xacc = fma(s, z0, xacc);
     const double m = fma(f.a1, z1, f.a0 * z0);
     const double vn = fma(s, m, fma(v, f.one_m_kdt, f.ktdt));
-    var = (vn > 1e-4) ? vn : ((vn != vn) ? vn : 1e-4);                  // np.maximum(v, 1e-4)     :379
+    // np.maximum(v, 1e-4) :379 as ONE v_max_f64 (the compare / NaN test / two selects of the literal form are four of the
+    // step's 66 instructions).  v_max drops a NaN where np.maximum keeps it: heston_fold_acc puts it back.
+    var = fmax(vn, 1e-4);
 }
 
 // Only the incoming variance of a slice can be exactly zero (every later one is floored at 1e-4), and sqrt_pos_1g does
@@ -246,11 +248,17 @@ __device__ __forceinline__ double heston_euler_guard_zero(double var)
     return (var == 0.0) ? 0x1.0p-1000 : var;
 }
 
-__device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double &x, double &qvar, double xacc, double vacc)
+// `var` is the variance the steps ended with.  A NaN variance can only come from a NaN / infinite incoming variance (then
+// vacc, which summed it, is not finite either) or from NaN / infinite constants: either way the reference's variance is
+// NaN from there on (np.maximum propagates it), and so is ours after this.
+__device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double &x, double &qvar, double &var, double xacc,
+                                                double vacc)
 {
     const double q = f.dt * vacc;
     x = fma(f.sdt, xacc, fma(-0.5, q, x));
     qvar = qvar + q;
+    const double finite_or_nan = ((f.one_m_kdt * 0.0 + f.ktdt * 0.0) + (f.a0 * 0.0 + f.a1 * 0.0)) + vacc * 0.0;   // 0 or NaN
+    var = var + finite_or_nan;
 }
 
 // ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------

@@ -222,6 +222,32 @@ def test_heston_invariants_small(sv):
     assert np.all(np.isfinite(x)) and np.all(v >= 1e-4) and np.all(q >= 0)
 
 
+def test_heston_euler_nan_variance_propagates(sv, oracle):
+    """np.maximum(v, 1e-4) keeps a NaN variance (pricers/heston_pricer.py:379); the kernel floors with one v_max_f64, which
+    does not, and restores the NaN at the fold: a NaN incoming variance (and NaN constants) must come out NaN, as from
+    the CPU twin, and must not touch the other paths."""
+    n, nb = 512, 8
+    eng = _engine(n)
+    x0, q0 = np.zeros(n), np.zeros(n)
+    v0 = np.full(n, 0.04)
+    v0[[3, 200]] = np.nan
+    v0[77] = np.inf
+    eng.set_state(x0, v0, q0)
+    eng.heston_rng(nb, 0.01, 0.04, 4.0, -0.5, 0.4, 0, 5, 0, 0)
+    x, v, q = eng.get_state()
+    ox, ov, oq = oracle.heston_terminal_rng(x0, v0, q0, nb, 0.01, 0.04, 4.0, -0.5, 0.4, 5, scheme=oracle.HESTON_EULER_FLOOR)
+    bad = np.zeros(n, dtype=bool)
+    bad[[3, 77, 200]] = True
+    assert np.all(np.isnan(v[bad])) and np.all(np.isnan(ov[bad])) and np.all(np.isnan(x[bad]))
+    np.testing.assert_allclose(v[~bad], ov[~bad], rtol=1e-10)
+    np.testing.assert_allclose(x[~bad], ox[~bad], rtol=1e-9, atol=1e-12)
+    eng.fill_state(0.0, 0.04, 0.0)
+    eng.heston_rng(nb, 0.01, float("nan"), 4.0, -0.5, 0.4, 0, 5, 0, 0)         # theta = NaN
+    x, v, q = eng.get_state()
+    assert np.all(np.isnan(v))
+    eng.close()
+
+
 def test_payoff_vs_reference(sv, golden):
     g = golden("payoff")
     for name in g["names"]:
