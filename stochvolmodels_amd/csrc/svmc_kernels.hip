@@ -97,50 +97,57 @@ __device__ __forceinline__ void butterfly_halve(const double *v, double *w, int 
     }
 }
 
+// values a block sum works on: NV rounded up to a multiple of 8 from 8 on (the halving tree below wants it; zeros fill up)
+constexpr int block_sum_padded(int nv) { return nv >= 8 ? (nv + 7) / 8 * 8 : nv; }
+
 // every thread of the block calls; thread j < n_out ends up with the block total of v[j] and hands it to store(j, total)
 template <int NV, class Store>
-__device__ __forceinline__ void block_sum_apply(double (&v)[NV], double *lds /* [4 * NV] */, int n_out, Store &&store)
+__device__ __forceinline__ void block_sum_apply(double (&v)[NV], double *lds /* [4 * block_sum_padded(NV)] */, int n_out,
+                                                Store &&store)
 {
+    constexpr int NP = block_sum_padded(NV);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    if constexpr (NV % 8 == 0) {
-        // NV values over 64 lanes in NV/2 + NV/4 + NV/8 + 3*NV/8 shuffles instead of 6*NV: three halving levels
-        // (xor 32, 16, 8) leave every lane with NV/8 partial sums of the index block its bits 5..3 select, three
+    if constexpr (NP % 8 == 0) {
+        // NP values over 64 lanes in NP/2 + NP/4 + NP/8 + 3*NP/8 shuffles instead of 6*NP: three halving levels
+        // (xor 32, 16, 8) leave every lane with NP/8 partial sums of the index block its bits 5..3 select, three
         // plain levels (xor 4, 2, 1) finish them.  Fixed tree, hence deterministic.
-        double a[NV / 2], b[NV / 4], c[NV / 8];
-        butterfly_halve<NV / 2, 32>(v, a, lane);
-        butterfly_halve<NV / 4, 16>(a, b, lane);
-        butterfly_halve<NV / 8, 8>(b, c, lane);
+        double vp[NP], a[NP / 2], b[NP / 4], c[NP / 8];
 #pragma unroll
-        for (int j = 0; j < NV / 8; ++j) {
+        for (int j = 0; j < NP; ++j) vp[j] = (j < NV) ? v[j] : 0.0;
+        butterfly_halve<NP / 2, 32>(vp, a, lane);
+        butterfly_halve<NP / 4, 16>(a, b, lane);
+        butterfly_halve<NP / 8, 8>(b, c, lane);
+#pragma unroll
+        for (int j = 0; j < NP / 8; ++j) {
             c[j] += __shfl_xor(c[j], 4, 64);
             c[j] += __shfl_xor(c[j], 2, 64);
             c[j] += __shfl_xor(c[j], 1, 64);
         }
         if ((lane & 7) == 0) {
-            const int off = ((lane & 32) ? NV / 2 : 0) + ((lane & 16) ? NV / 4 : 0) + ((lane & 8) ? NV / 8 : 0);
+            const int off = ((lane & 32) ? NP / 2 : 0) + ((lane & 16) ? NP / 4 : 0) + ((lane & 8) ? NP / 8 : 0);
 #pragma unroll
-            for (int j = 0; j < NV / 8; ++j) lds[wave * NV + off + j] = c[j];
+            for (int j = 0; j < NP / 8; ++j) lds[wave * NP + off + j] = c[j];
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
         if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) lds[wave * NV + j] = v[j];
+            for (int j = 0; j < NV; ++j) lds[wave * NP + j] = v[j];
         }
     }
     __syncthreads();
     if (static_cast<int>(threadIdx.x) < n_out) {
         const int j = threadIdx.x;
         double t = lds[j];
-        for (int w = 1; w < n_waves; ++w) t += lds[w * NV + j];      // fixed order: wave 0, 1, 2, 3
+        for (int w = 1; w < n_waves; ++w) t += lds[w * NP + j];      // fixed order: wave 0, 1, 2, 3
         store(j, t);
     }
 }
 
 // thread j < n_out writes the block total of v[j] to out[j]
 template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * NV] */, double *out, int n_out)
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* [4 * block_sum_padded(NV)] */, double *out, int n_out)
 {
     block_sum_apply<NV>(v, lds, n_out, [&](int j, double t) { out[j] = t; });
 }
@@ -869,7 +876,7 @@ template <int KT, bool HAS_INV, bool NEED_Q>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld)
 {
     constexpr int NACC = HAS_INV ? 3 : 2;
-    __shared__ double lds[4 * NACC * KT];
+    __shared__ double lds[4 * block_sum_padded(NACC * KT)];
     const PayoffGroup &d = pack.g[blockIdx.y];
     const double *__restrict__ x = d.x;
     const double *__restrict__ qvar = d.qvar;
@@ -878,7 +885,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
     const int nk = d.k;
     const uint32_t inv_mask = d.inv_mask;
-    double acc[NACC * KT], sg[KT], c[KT], shift[KT];
+    constexpr int NSUM = block_sum_padded(NACC * KT);      // the block sum's halving tree takes multiples of 8: zeros fill up
+    double acc[NSUM], sg[KT], c[KT], shift[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         sg[k] = d.sg[k];                                   // stays wave-uniform: the scalar operand of the FMA
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
         }
     }
 #pragma unroll
-    for (int j = 0; j < NACC * KT; ++j) acc[j] = 0.0;
+    for (int j = 0; j < NSUM; ++j) acc[j] = 0.0;
     constexpr bool need_q = NEED_Q;                        // options on realised variance (SVMC_Q_VAR)
 
     // one path's contribution to every strike of the group
@@ -931,18 +939,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
     const size_t i0 = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const size_t block_last = static_cast<size_t>(blockIdx.x) * BLOCK + (BLOCK - 1);
     const int full_trips = (n > block_last) ? static_cast<int>((n - 1 - block_last) / stride + 1) : 0;     // block-uniform
+    constexpr int PF = (KT >= (HAS_INV ? 15 : 22)) ? 2 : PAYOFF_PREFETCH;      // the widest groups have no registers to spare
     if constexpr (need_q) {
         const double *const w[2] = {x + i0, qvar + i0};
-        streamed_time_loop<2, PAYOFF_PREFETCH>(w, stride, full_trips, [&](const double(&v)[2]) { add_path(v[0], v[1]); });
+        streamed_time_loop<2, PF>(w, stride, full_trips, [&](const double(&v)[2]) { add_path(v[0], v[1]); });
     } else {
         const double *const w[1] = {x + i0};
-        streamed_time_loop<1, PAYOFF_PREFETCH>(w, stride, full_trips, [&](const double(&v)[1]) { add_path(v[0], 0.0); });
+        streamed_time_loop<1, PF>(w, stride, full_trips, [&](const double(&v)[1]) { add_path(v[0], 0.0); });
     }
     for (size_t i = i0 + static_cast<size_t>(full_trips) * stride; i < n; i += stride) add_path(x[i], need_q ? qvar[i] : 0.0);
     // output row layout: [sum d, sum d^2, count] per strike, interleaved, at column 3 (col + k)
     double *row = partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col;
     const double cnt = block_path_count(n, blockIdx.x, gridDim.x);
-    block_sum_apply<NACC * KT>(acc, lds, NACC * KT, [&](int j, double t) {
+    block_sum_apply<NSUM>(acc, lds, NACC * KT, [&](int j, double t) {
         const int which = j / KT, k = j - which * KT;
         if (k < nk) {
             row[3 * k + which] = t;
