@@ -45,12 +45,10 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     m = len(ttms)
     if not (len(forwards) == len(discfactors) == len(strikes_ttms) == len(optiontypes_ttms) == m):
         raise ValueError("chain arrays must have one entry per maturity")
-    strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
-    codes = [option_type_codes(t) for t in optiontypes_ttms]          # ValueError on unknown codes, up front
-    shifts = [payoff_shifts(k, c, float(f), vt) for k, c, f in zip(strikes, codes, forwards)]
     need_q = vt == Q_VAR
 
-    # phase 1: stepping + snapshot + local spot sums, state resident
+    # phase 1: stepping + snapshot + local spot sums, state resident.  Queued FIRST: the host-side preparation of the
+    # payoff pass (strike arrays, option codes, recentring shifts) then runs while the GPU steps
     engine.reserve_snapshots(m * (2 if need_q else 1))
     spot_ptr, spot_handle = comm.alloc(engine, 2 * m, "spot")
     if advance_chain is not None:
@@ -58,6 +56,9 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     else:
         for i in range(m):
             advance_slice(i, float(forwards[i]), i, (m + i) if need_q else None, spot_ptr + 16 * i)
+    strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
+    codes = [option_type_codes(t) for t in optiontypes_ttms]          # ValueError on unknown codes
+    shifts = [payoff_shifts(k, c, float(f), vt) for k, c, f in zip(strikes, codes, forwards)]
 
     # phase 2: forward recentring needs the GLOBAL mean of the terminal spots
     comm.all_reduce_sum(engine, spot_handle)
