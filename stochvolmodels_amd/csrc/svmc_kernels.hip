@@ -966,8 +966,19 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
 {
     __shared__ double lds[4];
     const int j = blockIdx.x;
-    double v[1] = {0.0};
-    for (int r = threadIdx.x; r < n_rows; r += BLOCK) v[0] += partials[static_cast<size_t>(r) * ld + j];
+    // four rows per trip, their loads in flight together (a row is one 8-byte read at a stride of ld: latency, not
+    // bandwidth); fixed order of additions, hence deterministic
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    int r = threadIdx.x;
+    for (; r + 3 * BLOCK < n_rows; r += 4 * BLOCK) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += t[u];
+    }
+    for (; r < n_rows; r += BLOCK) a[0] += partials[static_cast<size_t>(r) * ld + j];
+    double v[1] = {(a[0] + a[1]) + (a[2] + a[3])};
     block_sum_store<1>(v, lds, out + j, 1);
 }
 

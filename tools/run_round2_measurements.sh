@@ -11,3 +11,8 @@ SVMC_DIST_COMM=rccl SVMC_DIST_SINGLE_RANK_GROUP=1 MASTER_ADDR=127.0.0.1 MASTER_P
 timeout 900 python tools/bench_configs.py > gpurun_out/configs_r2.jsonl 2> gpurun_out/configs_r2.err; cat gpurun_out/configs_r2.jsonl
 timeout 600 python tools/bench_calibration.py 100000 > gpurun_out/calib_r2.log 2>&1; tail -8 gpurun_out/calib_r2.log
 bash tools/collect_profiles.sh
+# single kernels of the final build on this box, the counter passes of the C3 kernels and of the payoff pass, the rough kernels
+timeout 300 python tools/ubench/ab_kernels.py stochvolmodels_amd/libsvmc.so final 2>/dev/null | tail -1 > gpurun_out/ab_final.jsonl; cat gpurun_out/ab_final.jsonl
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/c3pmc -o c3 -- python $GRAFT_REPO_ROOT/tools/ubench/c3_probe.py > $GRAFT_REPO_ROOT/gpurun_out/c3pmc.log 2>&1; echo c3pmc rc=$?)
+bash tools/ubench/payoff_pmc.sh 2>&1 | tail -3
+timeout 600 python tools/bench_rough.py > gpurun_out/rough_r2.jsonl 2> gpurun_out/rough_r2.err; tail -5 gpurun_out/rough_r2.jsonl

@@ -76,6 +76,23 @@ for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("bt
         m, lo = timed(lambda: L.svmc_heston_terminal_rng(h[0], h[1], h[2], n, 512, 1 / 512, th, ka, rho, vv, scheme, 7, 0, 0, 0, None),
                       lambda: L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, v0, 0.0, None), reps=6, warm=2)
         res[f"heston_{name}_{sname}_ms"] = round(m, 4)
+# the whole-chain Heston kernel at C3's shape (4 x 128 steps, fused epilogues), when the build has it
+if hasattr(L, "svmc_heston_chain_rng"):
+    L.svmc_heston_chain_rng.argtypes = [vp, vp, vp, sz, i32, C.POINTER(i32), pd_, pd_, f64, f64, f64, f64, i32, u64, u32, u64, u32,
+                                        vp, vp, vp, vp, sz, vp]
+    wsb_h = C.c_size_t()
+    assert L.svmc_slice_workspace_bytes(n, C.byref(wsb_h)) == 0
+    ws_h, spot_h, snap_h = vp(), vp(), vp()
+    assert L.svmc_malloc(C.byref(ws_h), wsb_h.value) == 0 and L.svmc_malloc(C.byref(spot_h), 256) == 0
+    assert L.svmc_malloc(C.byref(snap_h), 8 * 4 * n) == 0
+    nbs4 = (i32 * 4)(*([128] * 4))
+    dts4 = np.full(4, 1.0 / 512); fws4 = np.ones(4)
+    for name, (v0, th, ka, rho, vv) in (("base", (0.04, 0.04, 4.0, -0.5, 0.4)), ("btc", (0.8, 1.0, 2.0, 0.0, 2.0))):
+        for sname, scheme in (("euler", 0), ("qe", 1)):
+            m, lo = timed(lambda: L.svmc_heston_chain_rng(h[0], h[1], h[2], n, 4, nbs4, dts4.ctypes.data_as(pd_), fws4.ctypes.data_as(pd_),
+                                                          th, ka, rho, vv, scheme, 7, 0, 0, 0, snap_h, None, spot_h, ws_h, wsb_h.value, None),
+                          lambda: L.svmc_fill_state(h[0], h[1], h[2], n, 0.0, v0, 0.0, None), reps=6, warm=2)
+            res[f"heston_chain_{name}_{sname}_ms"] = round(m, 4)
 # ---- the chain-wide payoff pass at C3's shape: 4 expiries x 21 strikes over 2^22 paths each (P below 1, C at/above) ----
 pd, pi8, psz = C.POINTER(C.c_double), C.POINTER(C.c_int8), C.POINTER(C.c_size_t)
 L.svmc_slice_workspace_bytes.argtypes = [sz, psz]
