@@ -410,6 +410,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_w_indirect_kernel(double *__restr
 // is a dozen microsecond-scale kernels; one launch per expiry (+ its reduce) and a separate fill were most of them.
 // Per slice the arithmetic is logsv_w_body's (L re-derived from sigma at the slice start), so the bits equal the
 // slice-by-slice launches.  `init` != nullptr: start every path from (0, *init, 0) instead of reading the state.
+static_assert(MAX_FUSED_SLICES == MAX_CHAIN_SLICES, "svmc_internal.h and the chain kernels must agree");
 struct ChainWSlices {
     const double *W0[MAX_CHAIN_SLICES], *W1[MAX_CHAIN_SLICES];
     double forward[MAX_CHAIN_SLICES];

@@ -1015,6 +1015,33 @@ def test_payoff_randomised_against_numpy_semantics(sv, oracle):
         np.testing.assert_allclose(sd, esd, rtol=1e-8, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
 
 
+@pytest.mark.parametrize("vt", [1, 2])
+def test_payoff_every_group_width(sv, oracle, vt):
+    """one payoff kernel per group width (1..24 strikes of plain chains, 1..16 with inverse options) and payoff variable:
+    every instantiation once, and the widths that spill into a second group, against the NumPy restatement -- with NaN and
+    -inf log-returns in the sample, which take the saturated branches of the in-kernel exp"""
+    import warnings
+    rng = np.random.default_rng(77)
+    n = 4099
+    x = 0.4 * rng.standard_normal(n) - 0.05
+    q = 0.3 * np.exp(0.5 * rng.standard_normal(n))
+    x[[5, 900]] = np.nan
+    x[[17, 2048]] = -np.inf
+    q[33] = np.nan
+    fwd, ttm, df = 1.3, 0.75, 0.97
+    for kinds, widths in ((["C", "P"], range(1, 28)), (["C", "P", "IC", "IP"], range(1, 20))):
+        for k in widths:
+            strikes = (fwd if vt == 1 else 0.3) * np.linspace(0.5, 1.6, k)
+            types = np.array([kinds[j % len(kinds)] for j in range(k)])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                epr, esd = oracle.np_payoff(x, q, ttm, fwd, strikes, types, df, vt)
+            pr, sd = sv.compute_mc_vars_payoff(x0=x, sigma0=np.ones(n), qvar0=q, ttm=ttm, forward=fwd, strikes_ttm=strikes,
+                                               optiontypes_ttm=types, discfactor=df, variable_type=sv.VariableType(vt))
+            np.testing.assert_allclose(pr, epr, rtol=1e-10, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
+            np.testing.assert_allclose(sd, esd, rtol=1e-8, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
+
+
 # ---------------------------------------------------------------------------------------------------
 # rough LogSV (SURVEY row f.4)
 # ---------------------------------------------------------------------------------------------------
