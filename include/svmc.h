@@ -288,7 +288,8 @@ SVMC_API int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *
                                           int variable_type, const double *const *W0s, const double *const *W1s,
                                           const int *nb_steps_host, const double *dts_host, size_t ldw,
                                           double *prices_host, double *stderrs_host);
-/* svmc_logsv_chain_price_fixed captures its launches (state init, per-expiry stepping + spot sums, payoff sums, D2H)
+/* svmc_logsv_chain_price_fixed captures its launches (ONE stepping launch for all expiries that also initialises the
+ * state and writes the spot sums' partials, their reduce, the payoff sums, D2H; a launch per expiry beyond 16 expiries)
  * into a hipGraph the first time it sees a (chain, randoms) combination and replays it afterwards -- the model
  * constants travel in a small device block the graph's first node refreshes.  On by default; results are identical
  * either way.  svmc_session_graph_launches counts the replays (diagnostics). */
