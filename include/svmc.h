@@ -288,6 +288,19 @@ SVMC_API int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *
                                           int variable_type, const double *const *W0s, const double *const *W1s,
                                           const int *nb_steps_host, const double *dts_host, size_t ldw,
                                           double *prices_host, double *stderrs_host);
+/* the same call with the price -> implied-vol step of a calibration objective (data/option_chain.py:327-346) done where
+ * the prices are: ivols_host [sum K_i] receives the Black-76 implied vols of the 'C' / 'P' quotes of a LOG_RETURN chain
+ * on the bracket [1e-6, 10] (NaN outside it, for inverse quotes and for Q_VAR chains) -- on the graph route one more
+ * kernel node and one more copy-back in the captured graph (svmc_black.h: the solver of svmc_black_implied_vols), on
+ * the others the host routine after the prices.  ivols_host may be NULL (= svmc_logsv_chain_price_fixed). */
+SVMC_API int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                             const double *discfactors_host, const double *vol_backbone_etas_host,
+                                             int n_expiries, const double *strikes_host, const int8_t *types_host,
+                                             const size_t *strike_offsets_host, double v0, double theta, double kappa1,
+                                             double kappa2, double beta, double volvol, int is_spot_measure,
+                                             int variable_type, const double *const *W0s, const double *const *W1s,
+                                             const int *nb_steps_host, const double *dts_host, size_t ldw,
+                                             double *prices_host, double *stderrs_host, double *ivols_host);
 /* svmc_logsv_chain_price_fixed captures its launches (ONE stepping launch for all expiries that also initialises the
  * state and writes the spot sums' partials, their reduce, the payoff sums, D2H; a launch per expiry beyond 16 expiries)
  * into a hipGraph the first time it sees a (chain, randoms) combination and replays it afterwards -- the model

@@ -13,8 +13,13 @@
 #include <vector>
 
 #include "svmc_internal.h"
+#include "svmc_black.h"
+#include <limits>
+#include <cstring>
 
 namespace svmc {
+
+constexpr double IV_VOL_LO = 1e-6, IV_VOL_HI = 10.0;       // the bracket of the implied vols (data/option_chain.py's host mirror)
 
 // A captured chain on fixed randoms (svmc_logsv_chain_price_fixed): everything that shapes the launches -- chain,
 // randoms, step counts -- is frozen in `key`; the model constants live in `params_dev`, refreshed from the pinned
@@ -25,6 +30,8 @@ struct FixedGraph {
     std::vector<unsigned char> key;
     double *params_host = nullptr, *params_dev = nullptr, *sums_host = nullptr;   // pinned / device / pinned
     size_t params_doubles = 0, sums_doubles = 0;
+    // implied vols on the device (svmc_logsv_chain_price_fixed_iv): per-quote constants, results device / pinned
+    double *quotes_dev = nullptr, *ivols_dev = nullptr, *ivols_host = nullptr;
 };
 
 struct Session {
@@ -52,6 +59,9 @@ static void fixed_graph_release(FixedGraph &g)
     if (g.params_host != nullptr) (void)hipHostFree(g.params_host);
     if (g.sums_host != nullptr) (void)hipHostFree(g.sums_host);
     if (g.params_dev != nullptr) (void)hipFree(g.params_dev);
+    if (g.quotes_dev != nullptr) (void)hipFree(g.quotes_dev);
+    if (g.ivols_dev != nullptr) (void)hipFree(g.ivols_dev);
+    if (g.ivols_host != nullptr) (void)hipHostFree(g.ivols_host);
     g = FixedGraph();
 }
 
@@ -280,6 +290,33 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
                                  const int *nb_steps_host, const double *dts_host, size_t ldw, double *prices_host,
                                  double *stderrs_host)
 {
+    return svmc_logsv_chain_price_fixed_iv(session, ttms_host, forwards_host, discfactors_host, vol_backbone_etas_host,
+                                           n_expiries, strikes_host, types_host, strike_offsets_host, v0, theta, kappa1, kappa2,
+                                           beta, volvol, is_spot_measure, variable_type, W0s, W1s, nb_steps_host, dts_host, ldw,
+                                           prices_host, stderrs_host, nullptr);
+}
+
+// host side of the implied vols for the routes that do not replay a graph (multi-GPU, graphs off): the same solver
+static void implied_vols_on_host(const ChainView &c, int variable_type, const double *prices, double *ivols)
+{
+    for (int i = 0; i < c.m; ++i)
+        for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k) {
+            // quotes on the log-return only: options on the realised variance have no Black vol on the forward
+            const bool vanilla = variable_type == SVMC_LOG_RETURN && (c.types[k] == SVMC_CALL || c.types[k] == SVMC_PUT);
+            ivols[k] = vanilla ? black_implied_vol(prices[k], c.strikes[k], c.types[k] == SVMC_CALL, c.forwards[i], c.ttms[i],
+                                                   c.discfactors[i], IV_VOL_LO, IV_VOL_HI)
+                               : std::numeric_limits<double>::quiet_NaN();
+        }
+}
+
+int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                    const double *discfactors_host, const double *vol_backbone_etas_host, int n_expiries,
+                                    const double *strikes_host, const int8_t *types_host, const size_t *strike_offsets_host,
+                                    double v0, double theta, double kappa1, double kappa2, double beta, double volvol,
+                                    int is_spot_measure, int variable_type, const double *const *W0s,
+                                    const double *const *W1s, const int *nb_steps_host, const double *dts_host, size_t ldw,
+                                    double *prices_host, double *stderrs_host, double *ivols_host)
+{
     const char *fn = "svmc_logsv_chain_price_fixed";
     Session *s = reinterpret_cast<Session *>(session);
     const ChainView c = {n_expiries, ttms_host, forwards_host, discfactors_host, strikes_host, types_host, strike_offsets_host};
@@ -289,10 +326,13 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
     if (s->use_graphs && s->comm == nullptr) {
         // ---- replay path: the launch structure is captured once per (chain, randoms) and replayed per parameter set
         std::vector<unsigned char> key;
+        const int want_iv = (ivols_host != nullptr && variable_type == SVMC_LOG_RETURN) ? 1 : 0;
         key_append(key, &c.m, 1);
         key_append(key, &variable_type, 1);
+        key_append(key, &want_iv, 1);
         key_append(key, &ldw, 1);
         key_append(key, c.ttms, c.m);
+        key_append(key, c.discfactors, want_iv ? c.m : 0);
         key_append(key, c.forwards, c.m);
         key_append(key, c.offsets, c.m + 1);
         key_append(key, c.strikes, c.offsets[c.m]);
@@ -313,6 +353,25 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
             SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.params_host), n_params * sizeof(double), hipHostMallocDefault));
             SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.sums_host), (n_sums ? n_sums : 1) * sizeof(double), hipHostMallocDefault));
             SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.params_dev), n_params * sizeof(double)));
+            const size_t n_quotes = c.offsets[c.m];
+            if (want_iv && n_quotes) {
+                // the quotes' constants are part of the key: uploaded once, outside the graph
+                std::vector<double> quotes(IV_QUOTE_DOUBLES_HOST * n_quotes);
+                for (int i = 0; i < c.m; ++i)
+                    for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k) {
+                        double *qd = quotes.data() + IV_QUOTE_DOUBLES_HOST * k;
+                        qd[0] = c.strikes[k];
+                        qd[1] = static_cast<double>(c.types[k]);
+                        qd[2] = shifts[k];
+                        qd[3] = c.forwards[i];
+                        qd[4] = c.ttms[i];
+                        qd[5] = c.discfactors[i];
+                    }
+                SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.quotes_dev), quotes.size() * sizeof(double)));
+                SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.ivols_dev), n_quotes * sizeof(double)));
+                SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.ivols_host), n_quotes * sizeof(double), hipHostMallocDefault));
+                SVMC_HIP_TRY(hipMemcpy(g.quotes_dev, quotes.data(), quotes.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
             SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
             int rc = SVMC_OK;
             hipError_t e = hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream);
@@ -335,6 +394,12 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
             if (e == hipSuccess && rc == SVMC_OK) rc = enqueue_payoff_sums(s, c, variable_type, unused);
             if (e == hipSuccess && rc == SVMC_OK && n_sums)
                 e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr) {
+                rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, static_cast<double>(s->n_path), IV_VOL_LO, IV_VOL_HI,
+                                        g.ivols_dev, s->stream);
+                if (rc == SVMC_OK)
+                    e = hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+            }
             const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
             if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
             if (e != hipSuccess || e_end != hipSuccess) {
@@ -355,7 +420,12 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
         SVMC_HIP_TRY(hipGraphLaunch(g.exec, s->stream));
         SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
         ++s->graph_launches;
-        return finalize_prices(s, c, g.sums_host, shifts, prices_host, stderrs_host);
+        if (int rc = finalize_prices(s, c, g.sums_host, shifts, prices_host, stderrs_host)) return rc;
+        if (ivols_host != nullptr) {
+            if (g.ivols_host != nullptr) memcpy(ivols_host, g.ivols_host, c.offsets[c.m] * sizeof(double));
+            else implied_vols_on_host(c, variable_type, prices_host, ivols_host);      // Q_VAR chains: NaN
+        }
+        return SVMC_OK;
     }
     if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :1128-1130
     for (int i = 0; i < c.m; ++i) {                                                                       // :1136-1160
@@ -367,7 +437,9 @@ int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host
                                         s->stream))
             return rc;
     }
-    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+    if (int rc = reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host)) return rc;
+    if (ivols_host != nullptr) implied_vols_on_host(c, variable_type, prices_host, ivols_host);
+    return SVMC_OK;
 }
 
 int svmc_session_use_graphs(svmc_session_t session, int enable)

@@ -9,6 +9,7 @@
 
 #include <cstring>
 #include <utility>
+#include "svmc_black.h"
 #include "svmc_models.h"
 #include "svmc_rng.h"
 
@@ -1264,6 +1265,34 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
     return check_launch(fn);
 }
 
+// The price -> implied-vol step of a calibration objective on the device, where the payoff sums already are: one lane per
+// quote finalises its price (utils/mc_payoffs.py:85-88) and inverts Black-76 (svmc_black.h, the host routine's solver).
+// quotes[k] = {strike, payoff code, shift, forward, ttm, discfactor}: fixed for a chain, uploaded once by the caller.
+constexpr int IV_QUOTE_DOUBLES = 6;
+__global__ __launch_bounds__(64) void chain_implied_vols_kernel(const double *__restrict__ sums, const double *__restrict__ quotes,
+                                                               size_t n_quotes, double n_path_total, double vol_lo,
+                                                               double vol_hi, double *__restrict__ ivols)
+{
+    const size_t k = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (k >= n_quotes) return;
+    const double *qd = quotes + IV_QUOTE_DOUBLES * k;
+    double price, se;
+    payoff_finalize_one(sums[3 * k], sums[3 * k + 1], sums[3 * k + 2], qd[2], qd[5], n_path_total, &price, &se);
+    const int code = static_cast<int>(qd[1]);
+    const bool vanilla = code == SVMC_CALL || code == SVMC_PUT;
+    ivols[k] = vanilla ? black_implied_vol(price, qd[0], code == SVMC_CALL, qd[3], qd[4], qd[5], vol_lo, vol_hi)
+                       : bits_to_double(0u, 0x7ff80000u);                  // inverse quotes: not provided (NaN)
+}
+
+int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,
+                       double vol_hi, double *ivols_dev, hipStream_t stream)
+{
+    if (n_quotes == 0) return SVMC_OK;
+    hipLaunchKernelGGL(chain_implied_vols_kernel, dim3(static_cast<unsigned>((n_quotes + 63) / 64)), dim3(64), 0, stream, sums_dev,
+                       quotes_dev, n_quotes, n_path_total, vol_lo, vol_hi, ivols_dev);
+    return check_launch("chain_implied_vols");
+}
+
 void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
                              int is_spot_measure, double *out)
 {
@@ -1677,15 +1706,9 @@ int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, siz
                          double n_path_total, double *prices_host, double *stderrs_host)
 {
     SVMC_REQUIRE(sums_host && prices_host && stderrs_host, "svmc_payoff_finalize: null pointer");
-    for (size_t k = 0; k < n_strikes; ++k) {
-        const double s = sums_host[3 * k], s2 = sums_host[3 * k + 1], cnt = sums_host[3 * k + 2];
-        const double dmean = s / cnt;                     // nanmean of (p - shift); 0/0 -> NaN like NumPy
-        const double mean = (shifts_host ? shifts_host[k] : 0.0) + dmean;
-        double var = s2 / cnt - dmean * dmean;            // nanstd^2, ddof = 0 (shift-invariant)
-        if (var < 0.0) var = 0.0;
-        prices_host[k] = discfactor * mean;                                                     // :85
-        stderrs_host[k] = discfactor * sqrt(var) / sqrt(n_path_total);                          // :86-88
-    }
+    for (size_t k = 0; k < n_strikes; ++k)
+        payoff_finalize_one(sums_host[3 * k], sums_host[3 * k + 1], sums_host[3 * k + 2], shifts_host ? shifts_host[k] : 0.0,
+                            discfactor, n_path_total, prices_host + k, stderrs_host + k);
     return SVMC_OK;
 }
 

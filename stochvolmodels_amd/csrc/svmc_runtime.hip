@@ -1,5 +1,6 @@
 // svmc_runtime.hip -- device / memory / stream / event plumbing of the C ABI (include/svmc.h).
 #include "svmc_internal.h"
+#include "svmc_black.h"
 
 #include <cmath>
 #include <limits>
@@ -180,23 +181,10 @@ int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms)
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------
-// Black-76 implied volatilities of one slice -- HOST code: a chain has tens of quotes, which a kernel launch plus
-// copy would only slow down.  It sits in the library so that the calibration objective (price chain on the GPU ->
-// implied vols -> weighted squares) costs microseconds on the host side, from Python and C alike.
+// Black-76 implied volatilities of one slice on the HOST (svmc_black.h: the same solver ends the fixed-randoms graph on
+// the device, where the prices already are -- svmc_logsv_chain_price_fixed_iv; a stand-alone launch plus copy for a few
+// dozen quotes would only be slower than this).
 // ---------------------------------------------------------------------------------------------------
-namespace {
-inline double norm_cdf(double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); }
-
-// undiscounted Black price of a call (is_call) or put and its vega
-inline double black_undisc(double F, double K, double sqrt_t, double vol, bool is_call, double *vega)
-{
-    const double sv = vol * sqrt_t;
-    const double d1 = std::log(F / K) / sv + 0.5 * sv, d2 = d1 - sv;
-    if (vega) *vega = F * std::exp(-0.5 * d1 * d1) * 0.39894228040143267794 * sqrt_t;
-    const double call = F * norm_cdf(d1) - K * norm_cdf(d2);
-    return is_call ? call : call - (F - K);
-}
-}  // namespace
 
 int svmc_black_implied_vols(const double *prices, const double *strikes, const int8_t *optiontypes, size_t n_strikes,
                             double forward, double ttm, double discfactor, double vol_lo, double vol_hi, double *ivols)
@@ -208,45 +196,8 @@ int svmc_black_implied_vols(const double *prices, const double *strikes, const i
         if (optiontypes[k] != SVMC_CALL && optiontypes[k] != SVMC_PUT)
             return svmc::fail(SVMC_ERR_UNSUPPORTED_VARIABLE,
                               "svmc_black_implied_vols: implied vols are provided for 'C' and 'P' quotes");
-    const double sqrt_t = std::sqrt(ttm);
-    for (size_t k = 0; k < n_strikes; ++k) {
-        const double K = strikes[k], target = prices[k] / discfactor;
-        const bool is_call = optiontypes[k] == SVMC_CALL;
-        ivols[k] = std::numeric_limits<double>::quiet_NaN();
-        if (!(K > 0.0) || !(target > black_undisc(forward, K, sqrt_t, vol_lo, is_call, nullptr)) ||
-            !(target < black_undisc(forward, K, sqrt_t, vol_hi, is_call, nullptr)))
-            continue;                                   // outside the band attainable on [vol_lo, vol_hi] (or NaN)
-        // Solve on the out-of-the-money side (put-call parity), where the price is all time value, and on the LOG
-        // of the price, which stays well-scaled down to the far tails (price ~ exp(-d^2/2)).  Safeguarded Newton
-        // from the inflection point of price(vol) (Manaster-Koehler); a step that leaves the bracket is replaced
-        // by bisection, and the bracket always contains the root.
-        const bool otm_call = K >= forward;
-        const double otm_target = (is_call == otm_call) ? target : (is_call ? target - (forward - K) : target + (forward - K));
-        double a = vol_lo, b = vol_hi;
-        double v = std::sqrt(2.0 * std::fabs(std::log(forward / K)) / ttm);
-        if (!(v > a && v < b)) v = 0.5 * (a + b);
-        if (otm_target > 0.0) {
-            const double log_target = std::log(otm_target);
-            for (int it = 0; it < 200; ++it) {
-                double vega;
-                const double p = black_undisc(forward, K, sqrt_t, v, otm_call, &vega);
-                const double f = (p > 0.0) ? std::log(p) - log_target : -std::numeric_limits<double>::infinity();
-                if (f > 0.0) b = v; else a = v;
-                double next = (p > 0.0 && vega > 0.0) ? v - f * p / vega : 0.5 * (a + b);
-                if (!(next > a && next < b)) next = 0.5 * (a + b);
-                const double step = std::fabs(next - v);
-                v = next;
-                if (step <= 4e-16 * v || b - a <= 4e-16 * v) break;
-            }
-        } else {
-            // time value lost to rounding in the in-the-money quote: plain bisection on the quoted side
-            for (int it = 0; it < 200 && b - a > 4e-16 * a; ++it) {
-                v = 0.5 * (a + b);
-                if (black_undisc(forward, K, sqrt_t, v, is_call, nullptr) < target) a = v; else b = v;
-            }
-            v = 0.5 * (a + b);
-        }
-        ivols[k] = v;
-    }
+    for (size_t k = 0; k < n_strikes; ++k)
+        ivols[k] = svmc::black_implied_vol(prices[k], strikes[k], optiontypes[k] == SVMC_CALL, forward, ttm, discfactor, vol_lo,
+                                           vol_hi);
     return SVMC_OK;
 }

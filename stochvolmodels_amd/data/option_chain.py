@@ -195,8 +195,8 @@ class OptionChain:
 
         The reference delegates to the third-party `vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices`,
         which is not available here: this is a textbook Black-76 inversion for 'C' and 'P' done by libsvmc's host
-        routine svmc_black_implied_vols (safeguarded Newton; a few dozen numbers per chain, so deliberately not a
-        kernel).  Parity with the third-party routine is UNPINNED; prices outside the band
+        routine svmc_black_implied_vols (safeguarded Newton; the MC calibration loop gets the same inversion from the
+        last kernel of its replayed graph instead, logsv_mc_chain_pricer_fixed_randoms(return_ivols=True)).  Parity with the third-party routine is UNPINNED; prices outside the band
         attainable for vols in [1e-6, 10] give NaN."""
         forwards = self.forwards if forwards is None else forwards
         return [black_ivols_native(np.asarray(p, dtype=float), float(t), float(f), np.asarray(k, dtype=float), ty, float(d))

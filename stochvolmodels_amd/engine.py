@@ -456,11 +456,12 @@ class DeviceRandoms:
 
     def price_logsv_chain(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
                           v0, theta, kappa1, kappa2, beta, volvol, etas, is_spot_measure: bool, variable_type: int,
-                          use_graph: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+                          use_graph: bool = True, want_ivols: bool = False):
         """one call of the fused single-GPU driver svmc_logsv_chain_price_fixed on these randoms: the chain's launches
         captured once into a hipGraph and replayed per parameter set (use_graph=False: queued back to back instead),
         one synchronisation, prices and stderrs back -- the inner loop of an MC calibration.  Same kernels in the
-        same order as mc_chain.price_chain_on_engine, hence the same bits."""
+        same order as mc_chain.price_chain_on_engine, hence the same bits.  want_ivols: a third list, the Black-76
+        implied vols of the prices, computed by the graph's last kernel (svmc_logsv_chain_price_fixed_iv)."""
         lib = _lib.load()
         m = len(self)
         offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
@@ -482,14 +483,16 @@ class DeviceRandoms:
         nbs = (C.c_int * m)(*self.nb_steps)
         dts = f64(self.dts)
         prices, stderrs = np.empty(max(total, 1)), np.empty(max(total, 1))
-        _lib.check(lib.svmc_logsv_chain_price_fixed(
+        ivols = np.empty(max(total, 1)) if want_ivols else None
+        _lib.check(lib.svmc_logsv_chain_price_fixed_iv(
             self._session, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp),
             etas.ctypes.data_as(dp), m, k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)),
             offs.ctypes.data_as(C.POINTER(C.c_size_t)), float(v0), float(theta), float(kappa1), float(kappa2),
             float(beta), float(volvol), int(bool(is_spot_measure)), int(variable_type), w0, w1, nbs,
-            dts.ctypes.data_as(dp), self.n_local, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp)))
-        return ([prices[offs[i]:offs[i + 1]].copy() for i in range(m)],
-                [stderrs[offs[i]:offs[i + 1]].copy() for i in range(m)])
+            dts.ctypes.data_as(dp), self.n_local, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp),
+            ivols.ctypes.data_as(dp) if want_ivols else None))
+        split = lambda a: [a[offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
+        return (split(prices), split(stderrs), split(ivols)) if want_ivols else (split(prices), split(stderrs))
 
 
 def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float

@@ -245,12 +245,14 @@ class LogSVPricer(ModelPricer):
                 ttms=option_chain.ttms, nb_path=nb_path, nb_steps_per_year=nb_steps, seed=seed), comm=comm)
 
             def model_vols(pars):
+                # prices AND their implied vols in one call: on one GPU the inversion is the last kernel of the replayed
+                # graph (svmc_logsv_chain_price_fixed_iv), so an objective evaluation is one launch and one wait
                 p = parse(pars)
-                prices, _ = logsv_mc_chain_pricer_fixed_randoms(
+                _, _, ivols = logsv_mc_chain_pricer_fixed_randoms(
                     W0s=resident, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2,
                     beta=p.beta, volvol=p.volvol, vol_backbone_etas=p.get_vol_backbone_etas(ttms=option_chain.ttms),
-                    comm=comm, **chain_args)
-                return option_chain.compute_model_ivols_from_chain_data(model_prices=prices)
+                    comm=comm, return_ivols=True, **chain_args)
+                return ivols
         elif calibration_engine == CalibrationEngine.ROUGH_MC:
             Z0, Z1, grids = get_randoms_for_rough_vol_chain_valuation(ttms=option_chain.ttms, nb_path=nb_path,
                                                                       nb_steps_per_year=nb_steps, seed=seed)
@@ -475,8 +477,8 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                         W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], dts: Sequence[float],
                                         v0: float, theta: float, kappa1: float, kappa2: float, beta: float,
                                         volvol: float, vol_backbone_etas: np.ndarray, is_spot_measure: bool = True,
-                                        variable_type: VariableType = VariableType.LOG_RETURN, comm=None
-                                        ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+                                        variable_type: VariableType = VariableType.LOG_RETURN, comm=None,
+                                        return_ivols: bool = False) -> Tuple[List[np.ndarray], ...]:
     """chain MC on supplied randoms (reference :1100-1162): nb_path = W0s[0].shape[1]; each rank uploads only
     its own column range of the host arrays.  W0s may instead be a DeviceRandoms (upload_fixed_randoms): the
     randoms then stay in HBM across calls and W1s / dts are taken from it."""
@@ -491,12 +493,13 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
         # single GPU, randoms resident: the whole chain in one call of the fused C++ driver
         strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
         codes = [option_type_codes(t) for t in optiontypes_ttms]
-        prices, stderrs = resident.price_logsv_chain(ttms, forwards, discfactors, [k.ravel() for k in strikes],
-                                                     [c.ravel() for c in codes], v0, theta, kappa1, kappa2, beta,
-                                                     volvol, vol_backbone_etas, is_spot_measure,
-                                                     variable_type_code(variable_type))
-        return ([p.reshape(np.shape(k)) for p, k in zip(prices, strikes_ttms)],
-                [e.reshape(np.shape(k)) for e, k in zip(stderrs, strikes_ttms)])
+        if return_ivols and any(np.any(c > 1) for c in codes):           # as the host inversion (data/option_chain.py)
+            raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
+        out = resident.price_logsv_chain(ttms, forwards, discfactors, [k.ravel() for k in strikes],
+                                         [c.ravel() for c in codes], v0, theta, kappa1, kappa2, beta, volvol,
+                                         vol_backbone_etas, is_spot_measure, variable_type_code(variable_type),
+                                         want_ivols=return_ivols)
+        return tuple([a.reshape(np.shape(k)) for a, k in zip(part, strikes_ttms)] for part in out)
     eng = get_engine(n_local, path_offset=offset)
     eng.fill_state(0.0, v0, 0.0)
 
@@ -513,8 +516,15 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
         eng.logsv_slice_w(W0.shape[0], float(dts[i]), theta, kappa1, kappa2, beta, volvol,
                           float(vol_backbone_etas[i]), is_spot_measure, w0, w1, forward, snap_row, qvar_row, spot_ptr)
 
-    return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
-                                 variable_type, advance)
+    prices, stderrs = price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms,
+                                            optiontypes_ttms, variable_type, advance)
+    if not return_ivols:
+        return prices, stderrs
+    from ..data.option_chain import black_ivols_native           # the host twin of the graph's implied-vol kernel
+    ivols = [black_ivols_native(np.asarray(p, dtype=float).ravel(), float(t), float(f), np.asarray(k, dtype=float).ravel(),
+                                np.asarray(ty).ravel(), float(d)).reshape(np.shape(k))
+             for p, t, f, k, ty, d in zip(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)]
+    return prices, stderrs, ivols
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -817,6 +817,47 @@ def test_resident_fixed_randoms(sv, golden):
     res.free()
 
 
+def test_implied_vols_from_the_graph(sv, oracle):
+    """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
+    (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
+    libm against the host's), identical with the graph off (host route), the same NaN pattern for unattainable prices,
+    prices untouched by asking for them; inverse quotes raise as on the host"""
+    from stochvolmodels_amd.data.option_chain import black_ivols_native
+    ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
+    k = np.linspace(0.55, 1.6, 13)
+    ty = np.where(k >= 1.0, "C", "P")
+    common = dict(ttms=ttms, forwards=np.array([1.0, 1.01, 1.02, 1.04]), discfactors=np.array([0.999, 0.99, 0.98, 0.96]),
+                  strikes_ttms=(k,) * 4, optiontypes_ttms=(ty,) * 4, vol_backbone_etas=np.ones(4))
+    p = dict(v0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
+    W = sv.get_randoms_for_chain_valuation(ttms, nb_path=20000, nb_steps_per_year=360, seed=3)
+    res = sv.upload_fixed_randoms(*W)
+    for pp in (p, dict(p, volvol=1.2, beta=-0.2), dict(p, v0=0.05, theta=0.05, volvol=0.3)):   # the last: far strikes unattainable
+        pr0, sd0 = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **pp)
+        pr, sd, iv = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True, **common, **pp)
+        for a, b in zip(pr0 + sd0, pr + sd):
+            np.testing.assert_array_equal(a, b)
+        for i in range(4):
+            host = black_ivols_native(pr[i], float(ttms[i]), float(common["forwards"][i]), k, ty, float(common["discfactors"][i]))
+            assert np.array_equal(np.isnan(iv[i]), np.isnan(host))
+            ok = ~np.isnan(host)
+            np.testing.assert_allclose(iv[i][ok], host[ok], rtol=1e-10)
+        assert np.isfinite(np.concatenate(iv)).sum() >= (30 if pp["volvol"] > 1.0 else 8)
+    assert np.isnan(np.concatenate(iv)).any()                       # the low-vol set loses its far strikes
+    # graph off / per-call upload: the host route gives the same vols
+    from stochvolmodels_amd.engine import option_type_codes
+    args = (ttms, common["forwards"], common["discfactors"], [k] * 4, [option_type_codes(ty)] * 4, p["v0"], p["theta"],
+            p["kappa1"], p["kappa2"], p["beta"], p["volvol"], np.ones(4), True, 1)
+    on = res.price_logsv_chain(*args, use_graph=True, want_ivols=True)
+    off = res.price_logsv_chain(*args, use_graph=False, want_ivols=True)
+    np.testing.assert_allclose(np.concatenate(on[2]), np.concatenate(off[2]), rtol=1e-10)
+    _, _, iv_host = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W[0], W1s=W[1], dts=W[2], return_ivols=True, **common, **p)
+    np.testing.assert_allclose(np.concatenate(iv_host), np.concatenate(on[2]), rtol=1e-10)
+    with pytest.raises(NotImplementedError):
+        sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True,
+                                               **dict(common, optiontypes_ttms=(np.where(k >= 1.0, "IC", "P"),) * 4), **p)
+    res.free()
+
+
 def test_mc_chain_implied_vols(sv):
     """ModelPricer.compute_mc_chain_implied_vols (reference model_pricer.py:216-241): MC price +/- 1.96 stderr -> Black
     vols; shape / ordering contract of the reference's tests/test_model_calibration_contracts.py:97-118"""

@@ -58,8 +58,12 @@ def main():
             ts.append(time.perf_counter() - t0)
         return float(np.median(ts))
 
+    def price_ivols():
+        return lp.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True, **kw)[2]
+
     pr = price()
     t_price = timed(price)
+    t_price_iv = timed(price_ivols)
     t_iv = timed(lambda: ivols(pr))
     steps = sum(res.nb_steps)
     lp.FUSED_FIXED_RANDOMS_DRIVER = False
@@ -72,7 +76,7 @@ def main():
     t_direct = {}
     for g in (False, True):
         t_direct[g] = timed(lambda: direct(g))
-    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
+    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_with_ivols_from_the_graph_ms=1e3 * t_price_iv, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
                           fused_graph_ms=1e3 * t_direct[True],
                           ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
     prof = cProfile.Profile()
