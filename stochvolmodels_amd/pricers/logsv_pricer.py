@@ -122,7 +122,8 @@ LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa
 def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,
                              discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
                              optiontypes_ttms: Sequence[np.ndarray], is_spot_measure: bool = True,
-                             expansion_order: ExpansionOrder = ExpansionOrder.SECOND) -> List[List[np.ndarray]]:
+                             expansion_order: ExpansionOrder = ExpansionOrder.SECOND, vol_scaler: float = None
+                             ) -> List[List[np.ndarray]]:
     """logsv_chain_pricer (LOG_RETURN, numerical ODE route) for SEVERAL parameter sets on one chain, all sets advanced
     by one launch per expiry and inverted by one launch per expiry: [set][expiry] -> prices.  Each set keeps its own
     transform grid (set_vol_scaler follows its sigma0, reference :664-666); results are bit-identical to one
@@ -131,7 +132,8 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
     from ..analytic import AnalyticGridBatch
     order = _order_code(expansion_order)
     grids = [mgfp.get_transform_var_grid(variable_type=VariableType.LOG_RETURN, is_spot_measure=is_spot_measure,
-                                         vol_scaler=set_vol_scaler(sigma0=p.sigma0, ttm=np.min(ttms))) for p in params_list]
+                                         vol_scaler=(set_vol_scaler(sigma0=p.sigma0, ttm=np.min(ttms))
+                                                     if vol_scaler is None else vol_scaler)) for p in params_list]
     batch = AnalyticGridBatch([g[0] for g in grids], [g[1] for g in grids], 5 if order == 2 else 3)
     try:
         out, ttm0 = [[] for _ in params_list], 0.0
@@ -236,10 +238,20 @@ class LogSVPricer(ModelPricer):
         chain_args = dict(ttms=option_chain.ttms, forwards=option_chain.forwards, discfactors=option_chain.discfactors,
                           strikes_ttms=option_chain.strikes_ttms, optiontypes_ttms=option_chain.optiontypes_ttms)
         resident = None
+        model_vols_batch = None
         if calibration_engine == CalibrationEngine.ANALYTIC:
             def model_vols(pars):
                 return self.compute_model_ivols_for_chain(option_chain=option_chain, params=parse(pars),
                                                           vol_scaler=vol_scaler)
+
+            def model_vols_batch(pars_list):
+                # the n bumped vectors of SLSQP's forward-difference gradient through ONE batch of launches per expiry
+                # (logsv_chain_pricer_batch: the sets advance together; bit-identical to one call per set)
+                prices = self.price_chain_batch(option_chain=option_chain, params_list=[parse(p) for p in pars_list],
+                                                vol_scaler=vol_scaler)
+                return [option_chain.compute_model_ivols_from_chain_data(model_prices=pr) for pr in prices]
+            if not kwargs.get("batched_gradient", True):
+                model_vols_batch = None
         elif calibration_engine == CalibrationEngine.MC:
             resident = upload_fixed_randoms(*get_randoms_for_chain_valuation(
                 ttms=option_chain.ttms, nb_path=nb_path, nb_steps_per_year=nb_steps, seed=seed), comm=comm)
@@ -267,11 +279,13 @@ class LogSVPricer(ModelPricer):
                 return option_chain.compute_model_ivols_from_chain_data(model_prices=prices)
         else:
             raise NotImplementedError(f"{calibration_engine}")
-        objective = ImpliedVolObjective(model_vols, market_vols, weights)
+        objective = ImpliedVolObjective(model_vols, market_vols, weights, model_vols_batch=model_vols_batch, bounds=bounds)
         try:
             fit = minimize_slsqp(objective, p0, bounds, _calibration_constraints(parse, constraints_type),
-                                 disp=bool(kwargs.get("disp", True)))
-            self.last_calibration = dict(n_eval=objective.n_eval, objective=objective(fit))
+                                 disp=bool(kwargs.get("disp", True)),
+                                 jac=objective.gradient if model_vols_batch is not None else None)
+            self.last_calibration = dict(n_eval=objective.n_eval, n_gradient_batches=objective.n_batches,
+                                         objective=objective(fit))
         finally:
             if resident is not None:
                 resident.free()

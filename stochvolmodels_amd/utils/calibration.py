@@ -65,26 +65,85 @@ def chain_calibration_weights(option_chain, market_vols: np.ndarray, is_vega_wei
 class ImpliedVolObjective:
     """pars -> sum_n w_n (sigma_model_n - sigma_market_n)^2 with NaN terms dropped (np.nansum).  `model_vols(pars)`
     returns the per-slice model implied vols.  Counts evaluations (`n_eval`) so callers can report kernel time per
-    optimizer step."""
+    optimizer step.
+
+    `model_vols_batch(list of pars)` (optional) returns the vols of SEVERAL parameter vectors from one batch of launches;
+    `gradient` then hands SLSQP the forward-difference gradient it would otherwise build itself from n + 1 separate
+    objective calls -- the same evaluation points (scipy.optimize approx_derivative, '2-point', abs_step = sqrt(eps),
+    a step that would leave the box flipped), the same numbers, one launch batch per optimizer iterate."""
+
+    FD_STEP = float(np.sqrt(np.finfo(float).eps))          # scipy's SLSQP default `eps`
 
     def __init__(self, model_vols: Callable[[np.ndarray], List[np.ndarray]], market_vols: np.ndarray,
-                 weights: np.ndarray):
+                 weights: np.ndarray, model_vols_batch: Callable[[List[np.ndarray]], List[List[np.ndarray]]] = None,
+                 bounds: Sequence[Tuple[float, float]] = None):
         self.model_vols = model_vols
+        self.model_vols_batch = model_vols_batch
         self.market_vols = np.asarray(market_vols, dtype=float)
         self.weights = np.asarray(weights, dtype=float)
         self.n_eval = 0
+        self.n_batches = 0
+        self._last = (None, None)                          # (parameter bytes, objective value) of the latest call
+        if bounds is not None:
+            self.lower = np.array([-np.inf if lo is None else lo for lo, _ in bounds], dtype=float)
+            self.upper = np.array([np.inf if hi is None else hi for _, hi in bounds], dtype=float)
+        else:
+            self.lower = self.upper = None
+
+    def _value(self, vols) -> float:
+        return float(np.nansum(self.weights * np.square(to_flat_np_array(vols) - self.market_vols)))
 
     def __call__(self, pars: np.ndarray, args=None) -> float:
         self.n_eval += 1
-        vols = to_flat_np_array(self.model_vols(pars))
-        return float(np.nansum(self.weights * np.square(vols - self.market_vols)))
+        value = self._value(self.model_vols(pars))
+        self._last = (np.asarray(pars, dtype=float).tobytes(), value)
+        return value
+
+    def fd_steps(self, x0: np.ndarray) -> np.ndarray:
+        """the signed absolute steps of the forward difference at x0 (approx_derivative's rule for a bounded box)"""
+        h = np.full(x0.shape, self.FD_STEP)
+        if self.lower is None or np.all(np.isinf(self.lower) & np.isinf(self.upper)):
+            return h
+        lower_dist, upper_dist = x0 - self.lower, self.upper - x0
+        x = x0 + h
+        violated = (x < self.lower) | (x > self.upper)
+        fitting = np.abs(h) <= np.maximum(lower_dist, upper_dist)
+        h[violated & fitting] *= -1.0
+        forward = (upper_dist >= lower_dist) & ~fitting
+        h[forward] = upper_dist[forward]
+        backward = (upper_dist < lower_dist) & ~fitting
+        h[backward] = -lower_dist[backward]
+        return h
+
+    def gradient(self, pars: np.ndarray, args=None) -> np.ndarray:
+        x0 = np.asarray(pars, dtype=float)
+        h = self.fd_steps(x0)
+        points = []
+        for i in range(x0.size):
+            xi = x0.copy()
+            xi[i] += h[i]
+            points.append(xi)
+        key, f0 = self._last
+        need_f0 = key != x0.tobytes()
+        if need_f0:
+            points.append(x0.copy())
+        vols = self.model_vols_batch(points)
+        self.n_eval += len(points)
+        self.n_batches += 1
+        values = [self._value(v) for v in vols]
+        if need_f0:
+            f0 = values.pop()
+        return np.array([(values[i] - f0) / (points[i][i] - x0[i]) for i in range(x0.size)])
 
 
 def minimize_slsqp(objective: Callable, p0: np.ndarray, bounds: Sequence[Tuple[float, float]], constraints=None,
-                   disp: bool = True, ftol: float = 1e-8) -> np.ndarray:
-    """scipy SLSQP with the reference's options (ftol 1e-8, args=None), then the result check"""
+                   disp: bool = True, ftol: float = 1e-8, jac: Callable = None) -> np.ndarray:
+    """scipy SLSQP with the reference's options (ftol 1e-8, args=None), then the result check.  `jac`: the objective's
+    gradient when the caller can produce it in one batch (ImpliedVolObjective.gradient); SLSQP differences otherwise."""
     from scipy.optimize import minimize
     kwargs = dict(args=None, method="SLSQP", bounds=bounds, options={"disp": disp, "ftol": ftol})
+    if jac is not None:
+        kwargs["jac"] = jac
     if constraints is not None:
         kwargs["constraints"] = constraints
     return validate_optimization_result(minimize(objective, p0, **kwargs), bounds)

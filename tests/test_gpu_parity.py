@@ -1220,6 +1220,18 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
     tol = dict(rtol=2e-3, atol=2e-3) if tag != "an4" else dict(rtol=2e-2, atol=1e-2)   # an4: RK45 rtol 1e-3 in the reference
     np.testing.assert_allclose(_vec(fit), ref, **tol)
     assert pricer.last_calibration["n_eval"] > 5
+    if tag == "an4":
+        # the analytic engine hands SLSQP its forward-difference gradient from ONE batch of launches per iterate (the bumped
+        # parameter vectors advance together, logsv_chain_pricer_batch): same evaluation points as SLSQP's own differences,
+        # bit-identical prices, hence the same optimizer path
+        assert pricer.last_calibration["n_gradient_batches"] > 2
+        n_eval_batched = pricer.last_calibration["n_eval"]
+        plain = sv.LogSVPricer()
+        fit0 = plain.calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start), disp=False,
+                                                     batched_gradient=False, **kw)
+        assert plain.last_calibration["n_gradient_batches"] == 0
+        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-9, atol=1e-12)
+        assert abs(n_eval_batched - plain.last_calibration["n_eval"]) <= 2
     if tag == "mc4c":       # the constraints hold at the optimum
         assert fit.kappa2 - 2.0 * fit.beta >= -1e-8
         assert fit.kappa1 + fit.kappa2 * fit.theta - 1.5 * (fit.beta ** 2 + fit.volvol ** 2) >= -1e-8
