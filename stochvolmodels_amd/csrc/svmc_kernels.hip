@@ -837,7 +837,7 @@ __global__ __launch_bounds__(BLOCK) void spot_sums_kernel(const double *__restri
 //     accumulates) and 4 doubles of vector state per strike (two accumulators, two constants: 192 VGPRs at 24
 //     strikes).  The time loop has NO per-strike condition: the unused strikes of a group carry c = -inf.
 //   inverse payoffs (IC / IP, HAS_INV): pay / spot can be NaN (0/0, inf/inf): per-strike NaN test and count kept.
-constexpr int PAYOFF_GROUPS = 6;       // groups per launch: 6 x 632 B of descriptors stay inside the 4 KB kernarg segment
+constexpr int PAYOFF_GROUPS = 8;       // groups per launch: 8 x 440 B of descriptors stay inside the 4 KB kernarg segment
 #ifndef SVMC_PAYOFF_PREFETCH
 #define SVMC_PAYOFF_PREFETCH 4
 #endif
@@ -851,16 +851,17 @@ constexpr int PAYOFF_KT = 24;          // strikes per group (the BASELINE chains
 struct PayoffGroup {
     const double *x, *qvar, *spot_sums;
     double forward, ttm;
-    double sg[PAYOFF_KT];      // +1 call, -1 put: pay = max(fma(sg, u, c), 0)
     double c[PAYOFF_KT];       // -sg K; -inf for the unused strikes of a group (their payoff is 0 and their sums are dropped)
     double shift[PAYOFF_KT];   // sums are taken of (payoff - shift): removes the E[p^2] - E[p]^2 cancellation
     uint32_t inv_mask;         // bit k set: divide by the recentred spot (IC / IP)
+    uint32_t put_mask;         // bit k set: put, sg = -1; clear: call, sg = +1: pay = max(fma(sg, u, c), 0)
     int k;                     // live strikes in this group
     int col;                   // first output column of the group within this launch (in strikes)
 };
 struct PayoffGroupPack {
     PayoffGroup g[PAYOFF_GROUPS];
 };
+static_assert(sizeof(PayoffGroupPack) + 64 <= 4096, "the payoff descriptors travel in the kernel arguments");
 
 // number of indices i < n visited by block b of a grid-stride loop (stride = grid * BLOCK, BLOCK consecutive per block)
 __device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigned grid)
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
     double acc[NSUM], sg[KT], c[KT], shift[KT];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        sg[k] = d.sg[k];                                   // stays wave-uniform: the scalar operand of the FMA
+        sg[k] = ((d.put_mask >> k) & 1u) ? -1.0 : 1.0;     // stays wave-uniform: the scalar operand of the FMA
         // plain chains: payoff - shift = max(sg u + c, 0) - shift = max(sg u + (c - shift), -shift): the recentring rides
         // in the FMA's addend and the max's floor, four instructions per strike per path instead of five
         if constexpr (HAS_INV) {
@@ -1647,11 +1648,12 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
             d.k = static_cast<int>(left < KG ? left : KG);
             d.col = cols;
             d.inv_mask = 0u;
+            d.put_mask = 0u;
             for (int k = 0; k < PAYOFF_KT; ++k) {
                 const bool on = k < d.k;
                 const int ty = on ? types[k0 + k] : SVMC_CALL;
                 const double sgn = (ty == SVMC_CALL || ty == SVMC_INV_CALL) ? 1.0 : -1.0;
-                d.sg[k] = sgn;
+                if (sgn < 0.0) d.put_mask |= 1u << k;
                 d.c[k] = on ? -sgn * strikes[k0 + k] : -__builtin_huge_val();      // unused: pay = max(u - inf, 0) = 0
                 d.shift[k] = (on && shifts != nullptr) ? shifts[k0 + k] : 0.0;
                 if (on && (ty == SVMC_INV_CALL || ty == SVMC_INV_PUT)) d.inv_mask |= 1u << k;
