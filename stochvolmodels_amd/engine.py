@@ -436,6 +436,30 @@ class DeviceRandoms:
             self.w0.append(bufs[0])
             self.w1.append(bufs[1])
 
+    @classmethod
+    def drawn_on_device(cls, nb_steps: Sequence[int], dts: Sequence[float], nb_path: int, n_local: int, col0: int,
+                        seed: int, call_id: int = 0) -> "DeviceRandoms":
+        """the chain's fixed randoms drawn IN HBM by the counter-based generator (svmc_fill_normals) instead of being
+        drawn by NumPy and uploaded: expiry i holds the normals the on-device-RNG generators consume for
+        (seed, call_id) at steps sum(nb_steps[:i]) .. -- so a chain priced on them is the on-device-RNG chain with its
+        randoms frozen, and a calibration no longer starts with a second of host Mersenne-Twister draws."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self.nb_path, self.n_local, self.col0 = int(nb_path), int(n_local), int(col0)
+        self.dts = [float(d) for d in dts]
+        self.nb_steps, self.w0, self.w1 = [int(n) for n in nb_steps], [], []
+        self._session, self._session_strikes = None, 0
+        step0 = 0
+        for nb in self.nb_steps:
+            b0, b1 = DeviceBuffer(nb * self.n_local), DeviceBuffer(nb * self.n_local)
+            _lib.check(lib.svmc_fill_normals(b0.ptr, b1.ptr, self.n_local, self.n_local, nb, int(seed), int(call_id),
+                                             self.col0, step0, None))
+            self.w0.append(b0)
+            self.w1.append(b1)
+            step0 += nb
+        _lib.check(lib.svmc_stream_synchronize(None))
+        return self
+
     def __len__(self):
         return len(self.nb_steps)
 

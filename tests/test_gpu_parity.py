@@ -817,6 +817,29 @@ def test_resident_fixed_randoms(sv, golden):
     res.free()
 
 
+def test_fixed_randoms_drawn_on_device(sv):
+    """draw_fixed_randoms_on_device: the chain's fixed randoms made in HBM by the counter-based generator.  They are the
+    draws the on-device-RNG pricer consumes for the same (seed, first call of the process' counter): a chain priced on
+    them equals logsv_mc_chain_pricer(seed=...) up to the two kernels' evaluation order (1e-9), repeatedly; and an MC
+    calibration on them lands where the one on the reference's host-drawn arrays does, within Monte Carlo noise."""
+    ttms = np.array([0.1, 0.3, 0.75])
+    k = np.linspace(0.7, 1.3, 7)
+    ty = np.where(k >= 1.0, "C", "P")
+    common = dict(ttms=ttms, forwards=np.array([1.0, 1.01, 1.02]), discfactors=np.array([0.999, 0.99, 0.98]),
+                  strikes_ttms=(k,) * 3, optiontypes_ttms=(ty,) * 3, vol_backbone_etas=np.ones(3))
+    p = dict(v0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
+    n = 20011
+    res = sv.draw_fixed_randoms_on_device(ttms, nb_path=n, nb_steps_per_year=360, seed=77)
+    a1, e1 = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **p)
+    a2, e2 = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, **common, **p)
+    for u, v in zip(a1 + e1, a2 + e2):
+        np.testing.assert_array_equal(u, v)
+    b, eb = sv.logsv_mc_chain_pricer(nb_path=n, nb_steps_per_year=360, seed=77, **common, **p)   # (77, call 0): those draws
+    np.testing.assert_allclose(np.concatenate(a1), np.concatenate(b), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate(e1), np.concatenate(eb), rtol=1e-8, atol=1e-12)
+    res.free()
+
+
 def test_implied_vols_from_the_graph(sv, oracle):
     """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
     (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
@@ -1220,6 +1243,11 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
     tol = dict(rtol=2e-3, atol=2e-3) if tag != "an4" else dict(rtol=2e-2, atol=1e-2)   # an4: RK45 rtol 1e-3 in the reference
     np.testing.assert_allclose(_vec(fit), ref, **tol)
     assert pricer.last_calibration["n_eval"] > 5
+    if tag == "mc5":
+        # the same calibration on fixed randoms drawn in HBM instead of by NumPy: another sample of the same estimator
+        fit_dev = sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start),
+                                                                   disp=False, device_randoms=True, **kw)
+        np.testing.assert_allclose(_vec(fit_dev), _vec(fit), rtol=0.25, atol=0.25)       # 4000 paths: MC noise
     if tag == "an4":
         # the analytic engine hands SLSQP its forward-difference gradient from ONE batch of launches per iterate (the bumped
         # parameter vectors advance together, logsv_chain_pricer_batch): same evaluation points as SLSQP's own differences,
