@@ -272,9 +272,17 @@ class LogSVPricer(ModelPricer):
                     comm=comm, return_ivols=True, **chain_args)
                 return ivols
         elif calibration_engine == CalibrationEngine.ROUGH_MC:
-            Z0, Z1, grids = get_randoms_for_rough_vol_chain_valuation(ttms=option_chain.ttms, nb_path=nb_path,
-                                                                      nb_steps_per_year=nb_steps, seed=seed)
-            resident = upload_rough_randoms(Z0, Z1, comm=comm)
+            if kwargs.get("device_randoms", False):
+                # as for the MC engine: Z0 / Z1 drawn in HBM instead of by NumPy (same grids, another sample)
+                grids = [set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps)[2] for ttm in option_chain.ttms]
+                comm_ = comm or svdist.get_default_comm()
+                offset, n_local = svdist.shard_range(nb_path, comm_.rank, comm_.world)
+                get_engine(n_local, path_offset=offset)
+                resident = DeviceRandoms.drawn_on_device([grids[-1].size - 1], [0.0], nb_path, n_local, offset, seed)
+            else:
+                Z0, Z1, grids = get_randoms_for_rough_vol_chain_valuation(ttms=option_chain.ttms, nb_path=nb_path,
+                                                                          nb_steps_per_year=nb_steps, seed=seed)
+                resident = upload_rough_randoms(Z0, Z1, comm=comm)
 
             def model_vols(pars):
                 p = parse(pars)
