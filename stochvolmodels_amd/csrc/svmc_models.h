@@ -303,11 +303,21 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     return c;
 }
 
-// ln(1 - e) for the martingale correction ln(1 - 2 A a): |e| is O(volvol^2 dt) on any sane grid, where eight series
-// terms (next: e^9 / 9 <= 6e-18 at the 2^-6 switch) replace the table logarithm; larger |e| take the table.
+// ln(1 - e) for the martingale correction ln(1 - 2 A a): |e| is O(volvol^2 dt) on any sane grid.  Where the whole wave
+// has |e| < 2^-10 (the C3 base set sits at 2^-11.3) five series terms do (next: e^6 / 6 <= 1.4e-19); below 2^-6 eight
+// (next: e^9 / 9 <= 6e-18 at the switch); larger |e| take the table logarithm.
 __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, const LogTabEntry *tab)
 {
-    if (fabs(e) < 0x1.0p-6) {
+    const double ae = fabs(e);
+    if (__all(ae < 0x1.0p-10)) {
+        double p = 0x1.999999999999ap-3;                  // 1/5
+        p = fma_k(p, e, 0x1.0000000000000p-2);            // 1/4
+        p = fma_k(p, e, 0x1.5555555555555p-2);            // 1/3
+        p = fma_k(p, e, 0x1.0000000000000p-1);            // 1/2
+        p = fma_k(p, e, 1.0);
+        return -e * p;
+    }
+    if (ae < 0x1.0p-6) {
         double p = 0x1.0000000000000p-3;                  // 1/8
         p = fma_k(p, e, 0x1.2492492492492p-3);            // 1/7
         p = fma_k(p, e, 0x1.5555555555555p-3);            // 1/6
