@@ -481,29 +481,49 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
                                                                 uint64_t seed, uint32_t c3, uint64_t path_offset)
 {
     __shared__ RngTablesLds s_tab;
-    const RngTables tab = stage_rng_tables(s_tab);
+    __shared__ double s_exp[256];
+    const RngTables tab = stage_tables(s_tab, s_exp);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
     double s = v0, L = log(v0);
     sigma_t[p] = s;                                                                             // :937
     const double sdt = sqrt(dt);
-    const uint64_t gp = path_offset + p;
-    double z0 = 0.0, z1 = 0.0;
-    uint32_t r[4] = {0u, 0u, 0u, 0u};
-    for (int t = 0; t < nb_steps; ++t) {
-        double w;
-        if (RNG) {
-            // one Brownian per step: normal t is component t & 1 of pair (t >> 1) & 1 of call t >> 2 (stream 2)
-            if ((t & 3) == 0) philox_draw(seed, c3 | 2u, gp, static_cast<uint32_t>(t >> 2), r);
-            if ((t & 1) == 0) normals_from_words((t & 2) ? r[2] : r[0], (t & 2) ? r[3] : r[1], tab, 0.0, z0, z1);
-            w = sdt * ((t & 1) ? z1 : z0);                                                      // :925
-        } else {
-            w = brownians[static_cast<size_t>(t) * ldb + p];
-        }
+    double *out = sigma_t + ld + p;                        // row t + 1 of this path
+    const auto step = [&](double w) {                      // w: the scaled increment sqrt(dt) N(0,1)               :925
         const double drift = ((((k1theta * rcp_fast(s)) - kappa1) + kappa2 * (theta - s)) + adj * s) - half_vartheta2;
         L = (L + drift * dt) + vartheta * w;                                                    // :942
-        s = exp_fast(L);                                                                        // :943
-        sigma_t[static_cast<size_t>(t + 1) * ld + p] = s;                                       // :944
+        s = exp_tab(L, s_exp);                                                                  // :943
+        *out = s;                                                                               // :944
+        out += ld;
+    };
+    if (RNG) {
+        // one Brownian per step: normal t is component t & 1 of pair (t >> 1) & 1 of call t >> 2 (stream 2) -- a Philox
+        // call and two Box-Muller pairs serve four steps, so the loop runs call by call with no per-step selects
+        const PhiloxLane lane = philox_prepare(seed, c3 | 2u, path_offset + p);
+        uint32_t r[4];
+        double a0, a1, b0, b1;
+        int t = 0;
+        for (; t + 4 <= nb_steps; t += 4) {
+            philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
+            normals_from_words(r[0], r[1], tab, 0.0, a0, a1);
+            normals_from_words(r[2], r[3], tab, 0.0, b0, b1);
+            step(sdt * a0);
+            step(sdt * a1);
+            step(sdt * b0);
+            step(sdt * b1);
+        }
+        if (t < nb_steps) {                                // the last, partial call (wave-uniform)
+            philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
+            normals_from_words(r[0], r[1], tab, 0.0, a0, a1);
+            step(sdt * a0);
+            if (t + 1 < nb_steps) step(sdt * a1);
+            if (t + 2 < nb_steps) {
+                normals_from_words(r[2], r[3], tab, 0.0, b0, b1);
+                step(sdt * b0);
+            }
+        }
+    } else {
+        for (int t = 0; t < nb_steps; ++t) step(brownians[static_cast<size_t>(t) * ldb + p]);
     }
 }
 
