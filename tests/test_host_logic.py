@@ -300,3 +300,48 @@ def test_bench_workloads_and_roofline_arithmetic():
     assert r["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
     # without a committed counter pass for the kernel the line falls back to the HBM roof instead of inventing a count
     assert bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, {}, None)["roofline"]["bound"] == "hbm"
+
+
+def test_batched_gradient_uses_scipys_difference_points():
+    """ImpliedVolObjective.gradient (the analytic calibration's batched forward differences) must evaluate the objective
+    exactly where SLSQP's own differencing would (scipy.optimize approx_derivative, '2-point', abs_step = sqrt(eps),
+    steps flipped or shortened at the box): same points -> same gradient -> same optimizer path.  Checked against scipy
+    itself on random points, incl. points on and next to the bounds."""
+    from scipy.optimize._numdiff import approx_derivative
+    from stochvolmodels_amd.utils.calibration import ImpliedVolObjective
+    rng = np.random.default_rng(5)
+    n = 5
+    for trial in range(200):
+        lb = rng.uniform(-2.0, 0.0, n)
+        ub = lb + rng.uniform(1e-9 if trial % 7 == 0 else 0.1, 3.0, n)
+        x0 = rng.uniform(lb, ub)
+        if trial % 3 == 0:
+            x0[rng.integers(n)] = ub[rng.integers(n)] if trial % 2 else lb[rng.integers(n)]
+            x0 = np.clip(x0, lb, ub)
+        if trial % 5 == 0:
+            j = rng.integers(n)
+            x0[j] = ub[j] - rng.uniform(0, 2e-8)                                   # closer to the bound than one step
+            x0 = np.clip(x0, lb, ub)
+        seen = []
+
+        def fun(x):
+            seen.append(np.array(x, dtype=float))
+            return float(np.sum(np.sin(x) * np.arange(1, n + 1)))
+
+        f0 = fun(x0)
+        seen.clear()
+        g_scipy = approx_derivative(fun, x0, method="2-point", abs_step=float(np.sqrt(np.finfo(float).eps)), f0=f0,
+                                    bounds=(lb, ub))
+        pts_scipy = [p.copy() for p in seen]
+        obj = ImpliedVolObjective(None, np.zeros(1), np.ones(1), model_vols_batch=lambda pts: [np.array([0.0])] * len(pts),
+                                  bounds=list(zip(lb, ub)))
+        h = obj.fd_steps(x0)
+        for i in range(n):
+            xi = x0.copy()
+            xi[i] += h[i]
+            np.testing.assert_array_equal(xi, pts_scipy[i], err_msg=f"trial {trial} component {i}")
+        # and the gradient assembled the same way from the same values
+        obj._value = lambda vols: vols                                              # the batch hands the values straight through
+        obj.model_vols_batch = lambda pts: [fun(p) for p in pts]
+        obj._last = (x0.tobytes(), f0)
+        np.testing.assert_array_equal(obj.gradient(x0), g_scipy)
