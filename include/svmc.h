@@ -301,6 +301,20 @@ SVMC_API int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const doubl
                                              int variable_type, const double *const *W0s, const double *const *W1s,
                                              const int *nb_steps_host, const double *dts_host, size_t ldw,
                                              double *prices_host, double *stderrs_host, double *ivols_host);
+/* the same chain for SEVERAL PARAMETER SETS on the same resident randoms -- the base point of an optimizer iterate and its
+ * finite-difference neighbours -- with the randoms read once: params_host [n_sets][6 + n_expiries] = {v0, theta, kappa1,
+ * kappa2, beta, volvol, vol_backbone_eta of each expiry}, outputs [n_sets][sum K_i] (ivols_host may be NULL).  With 2..8
+ * sets and a session created for n_sets chains (svmc_session_create(.., max_expiries >= n_sets * n_expiries,
+ * max_strikes_total >= n_sets * sum K_i)) the replayed graph steps all sets in ONE launch, every lane carrying the n_sets
+ * states of its path (the single-set launch is bound by reading the randoms); otherwise the sets are priced one after the
+ * other.  Either way each set gets the bits svmc_logsv_chain_price_fixed_iv gives it. */
+SVMC_API int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                               const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                               const int8_t *types_host, const size_t *strike_offsets_host, int n_sets,
+                                               const double *params_host, int is_spot_measure, int variable_type,
+                                               const double *const *W0s, const double *const *W1s,
+                                               const int *nb_steps_host, const double *dts_host, size_t ldw,
+                                               double *prices_host, double *stderrs_host, double *ivols_host);
 /* svmc_logsv_chain_price_fixed captures its launches (ONE stepping launch for all expiries that also initialises the
  * state and writes the spot sums' partials, their reduce, the payoff sums, D2H; a launch per expiry beyond 16 expiries)
  * into a hipGraph the first time it sees a (chain, randoms) combination and replays it afterwards -- the model

@@ -33,6 +33,7 @@ _EXPORTS = {
     "get_randoms_for_chain_valuation": "pricers.logsv_pricer",
     "upload_fixed_randoms": "pricers.logsv_pricer",
     "draw_fixed_randoms_on_device": "pricers.logsv_pricer",
+    "logsv_mc_chain_pricer_fixed_randoms_batch": "pricers.logsv_pricer",
     "get_randoms_for_rough_vol_chain_valuation": "pricers.logsv_pricer",
     "rough_logsv_mc_chain_pricer_fixed_randoms": "pricers.logsv_pricer",
     "rough_logsv_mc_chain_pricer": "pricers.logsv_pricer",

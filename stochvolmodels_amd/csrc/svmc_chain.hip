@@ -43,6 +43,7 @@ struct Session {
     bool use_graphs = true;
     size_t graph_launches = 0;
     FixedGraph fixed;
+    FixedGraph fixed_sets;                  // svmc_logsv_chain_price_fixed_sets: several parameter sets per replay
     size_t n_path = 0;
     int max_expiries = 0;
     size_t max_strikes = 0;
@@ -69,6 +70,7 @@ static void session_release(Session *s)
 {
     if (s == nullptr) return;
     fixed_graph_release(s->fixed);
+    fixed_graph_release(s->fixed_sets);
     for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar),
                     static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
         if (p != nullptr) (void)hipFree(p);
@@ -135,6 +137,22 @@ static int enqueue_payoff_sums(Session *s, const ChainView &c, int variable_type
     return svmc_payoff_sums_chain(xs.data(), variable_type == SVMC_Q_VAR ? qs.data() : nullptr, n, c.forwards, c.ttms,
                                   s->spot, c.m, c.strikes, c.types, shifts.data(), c.offsets, variable_type, s->sums,
                                   s->ws, s->ws_bytes, s->stream);
+}
+
+// the same for parameter set `set` of P (svmc_logsv_chain_price_fixed_sets): its snapshot rows, spot sums and output
+// block -- one launch pair per set with the single-set launch shape, hence the single-set bits
+static int enqueue_payoff_sums_of_set(Session *s, const ChainView &c, int variable_type, const std::vector<double> &shifts,
+                                      int set, int n_sets)
+{
+    const size_t n = s->n_path, K = c.offsets[c.m];
+    std::vector<const double *> xs(c.m), qs(c.m);
+    for (int i = 0; i < c.m; ++i) {
+        xs[i] = s->snap + static_cast<size_t>(set * c.m + i) * n;
+        qs[i] = s->snap + static_cast<size_t>((n_sets + set) * c.m + i) * n;
+    }
+    return svmc_payoff_sums_chain(xs.data(), variable_type == SVMC_Q_VAR ? qs.data() : nullptr, n, c.forwards, c.ttms,
+                                  s->spot + 2 * static_cast<size_t>(set) * c.m, c.m, c.strikes, c.types, shifts.data(), c.offsets,
+                                  variable_type, s->sums + 3 * K * static_cast<size_t>(set), s->ws, s->ws_bytes, s->stream);
 }
 
 // phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88); the standard error divides by the
@@ -439,6 +457,146 @@ int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_h
     }
     if (int rc = reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host)) return rc;
     if (ivols_host != nullptr) implied_vols_on_host(c, variable_type, prices_host, ivols_host);
+    return SVMC_OK;
+}
+
+int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                      const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                      const int8_t *types_host, const size_t *strike_offsets_host, int n_sets,
+                                      const double *params_host, int is_spot_measure, int variable_type,
+                                      const double *const *W0s, const double *const *W1s, const int *nb_steps_host,
+                                      const double *dts_host, size_t ldw, double *prices_host, double *stderrs_host,
+                                      double *ivols_host)
+{
+    const char *fn = "svmc_logsv_chain_price_fixed_sets";
+    Session *s = reinterpret_cast<Session *>(session);
+    const ChainView c = {n_expiries, ttms_host, forwards_host, discfactors_host, strikes_host, types_host, strike_offsets_host};
+    if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
+    SVMC_REQUIRE(W0s && W1s && nb_steps_host && dts_host && params_host, "svmc_logsv_chain_price_fixed_sets: null randoms / grids / parameters");
+    SVMC_REQUIRE(n_sets >= 1, "svmc_logsv_chain_price_fixed_sets: n_sets must be positive");
+    const size_t K = c.offsets[c.m], row = 6 + static_cast<size_t>(c.m);          // doubles per parameter set
+    // the routes without a multi-set graph (one set, more sets than a launch takes, graphs off, a communicator attached, a
+    // session not sized for n_sets chains): the sets one after the other through the single-set entry -- the same numbers
+    const bool batched = s->use_graphs && s->comm == nullptr && n_sets >= 2 && n_sets <= MAX_FUSED_SETS && c.m <= MAX_FUSED_SLICES &&
+                         c.m * n_sets <= s->max_expiries && K * static_cast<size_t>(n_sets) <= s->max_strikes &&
+                         ((s->n_path + 255) / 256) * 2 * static_cast<size_t>(c.m) * n_sets * sizeof(double) <= s->ws_bytes;
+    if (!batched) {
+        for (int q = 0; q < n_sets; ++q) {
+            const double *pr = params_host + row * q;
+            if (int rc = svmc_logsv_chain_price_fixed_iv(session, ttms_host, forwards_host, discfactors_host, pr + 6, n_expiries,
+                                                         strikes_host, types_host, strike_offsets_host, pr[0], pr[1], pr[2], pr[3],
+                                                         pr[4], pr[5], is_spot_measure, variable_type, W0s, W1s, nb_steps_host,
+                                                         dts_host, ldw, prices_host + K * q, stderrs_host + K * q,
+                                                         ivols_host ? ivols_host + K * q : nullptr))
+                return rc;
+        }
+        return SVMC_OK;
+    }
+    const size_t n = s->n_path;
+    const int P = n_sets;
+    for (int i = 0; i < c.m; ++i)
+        SVMC_REQUIRE(dts_host[i] > 0.0 && nb_steps_host[i] > 0, "svmc_logsv_chain_price_fixed_sets: dt and nb_steps must be positive");
+    std::vector<unsigned char> key;
+    const int want_iv = (ivols_host != nullptr && variable_type == SVMC_LOG_RETURN) ? 1 : 0;
+    key_append(key, &c.m, 1);
+    key_append(key, &P, 1);
+    key_append(key, &variable_type, 1);
+    key_append(key, &want_iv, 1);
+    key_append(key, &ldw, 1);
+    key_append(key, c.ttms, c.m);
+    key_append(key, c.discfactors, want_iv ? c.m : 0);
+    key_append(key, c.forwards, c.m);
+    key_append(key, c.offsets, c.m + 1);
+    key_append(key, c.strikes, K);
+    key_append(key, c.types, K);
+    key_append(key, W0s, c.m);
+    key_append(key, W1s, c.m);
+    key_append(key, nb_steps_host, c.m);
+    FixedGraph &g = s->fixed_sets;
+    // parameter block: [P] initial volatilities, then [m][P] LogsvConsts
+    const size_t n_params = static_cast<size_t>(P) + static_cast<size_t>(c.m) * P * LOGSV_CONSTS_DOUBLES, n_sums = 3 * K * P;
+    std::vector<double> shifts(K);
+    for (int i = 0; i < c.m; ++i)
+        for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k)
+            shifts[k] = payoff_shift(c.strikes[k], c.types[k], c.forwards[i], variable_type);
+    if (g.exec == nullptr || g.key != key) {
+        fixed_graph_release(g);
+        g.params_doubles = n_params;
+        g.sums_doubles = n_sums;
+        SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.params_host), n_params * sizeof(double), hipHostMallocDefault));
+        SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.sums_host), (n_sums ? n_sums : 1) * sizeof(double), hipHostMallocDefault));
+        SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.params_dev), n_params * sizeof(double)));
+        const size_t n_quotes = K * P;
+        if (want_iv && n_quotes) {
+            std::vector<double> quotes(IV_QUOTE_DOUBLES_HOST * n_quotes);
+            for (int q = 0; q < P; ++q)
+                for (int i = 0; i < c.m; ++i)
+                    for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k) {
+                        double *qd = quotes.data() + IV_QUOTE_DOUBLES_HOST * (K * q + k);
+                        qd[0] = c.strikes[k];
+                        qd[1] = static_cast<double>(c.types[k]);
+                        qd[2] = shifts[k];
+                        qd[3] = c.forwards[i];
+                        qd[4] = c.ttms[i];
+                        qd[5] = c.discfactors[i];
+                    }
+            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.quotes_dev), quotes.size() * sizeof(double)));
+            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.ivols_dev), n_quotes * sizeof(double)));
+            SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.ivols_host), n_quotes * sizeof(double), hipHostMallocDefault));
+            SVMC_HIP_TRY(hipMemcpy(g.quotes_dev, quotes.data(), quotes.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+        int rc = SVMC_OK;
+        hipError_t e = hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) {
+            double *qsnaps = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * P * n : nullptr;
+            rc = logsv_chain_w_sets(n, P, c.m, nb_steps_host, g.params_dev + P, g.params_dev, W0s, W1s, ldw, c.forwards, s->snap,
+                                    qsnaps, s->spot, s->ws, s->ws_bytes, s->stream);
+        }
+        for (int q = 0; q < P && e == hipSuccess && rc == SVMC_OK; ++q)
+            rc = enqueue_payoff_sums_of_set(s, c, variable_type, shifts, q, P);
+        if (e == hipSuccess && rc == SVMC_OK && n_sums)
+            e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr) {
+            rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, static_cast<double>(s->n_path), IV_VOL_LO, IV_VOL_HI,
+                                    g.ivols_dev, s->stream);
+            if (rc == SVMC_OK)
+                e = hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+        }
+        const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
+        if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
+        if (e != hipSuccess || e_end != hipSuccess) {
+            fixed_graph_release(g);
+            return fail(SVMC_ERR_HIP, std::string(fn) + ": graph capture: " + hipGetErrorString(e != hipSuccess ? e : e_end));
+        }
+        SVMC_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        g.key = key;
+    }
+    for (int q = 0; q < P; ++q) {
+        const double *pr = params_host + row * q;
+        g.params_host[q] = pr[0];
+        for (int i = 0; i < c.m; ++i)
+            logsv_consts_to_doubles(dts_host[i], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6 + i], is_spot_measure,
+                                    g.params_host + P + (static_cast<size_t>(i) * P + q) * LOGSV_CONSTS_DOUBLES);
+    }
+    SVMC_HIP_TRY(hipGraphLaunch(g.exec, s->stream));
+    SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+    ++s->graph_launches;
+    const double n_all = static_cast<double>(s->n_path);
+    for (int q = 0; q < P; ++q)
+        for (int i = 0; i < c.m; ++i) {
+            const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
+            if (int rc = svmc_payoff_finalize(g.sums_host + 3 * (K * q + k0), shifts.data() + k0, k, c.discfactors[i], n_all,
+                                              prices_host + K * q + k0, stderrs_host + K * q + k0))
+                return rc;
+        }
+    if (ivols_host != nullptr) {
+        if (g.ivols_host != nullptr) {
+            memcpy(ivols_host, g.ivols_host, K * P * sizeof(double));
+        } else {
+            for (int q = 0; q < P; ++q) implied_vols_on_host(c, variable_type, prices_host + K * q, ivols_host + K * q);
+        }
+    }
     return SVMC_OK;
 }
 

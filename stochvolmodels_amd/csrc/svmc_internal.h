@@ -38,6 +38,11 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                            const double *consts_dev, const double *vol0_dev, const double *const *W0s, const double *const *W1s,
                            size_t ldw, const double *forwards_host, double *x_snapshots, double *qvar_snapshots,
                            double *spot_sums, void *workspace, size_t workspace_bytes, hipStream_t stream);
+constexpr int MAX_FUSED_SETS = 8;       // = MAX_CHAIN_SETS of svmc_kernels.hip
+int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
+                       const double *vol0_dev, const double *const *W0s, const double *const *W1s, size_t ldw,
+                       const double *forwards_host, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                       void *workspace, size_t workspace_bytes, hipStream_t stream);
 constexpr int IV_QUOTE_DOUBLES_HOST = 6;   // = IV_QUOTE_DOUBLES of svmc_kernels.hip: {strike, code, shift, forward, ttm, df}
 int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,
                        double vol_hi, double *ivols_dev, hipStream_t stream);

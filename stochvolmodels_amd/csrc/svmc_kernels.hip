@@ -459,6 +459,73 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_indirect_kernel(double *_
     }
 }
 
+// The same chain for P PARAMETER SETS in one launch, the resident randoms read ONCE: every lane carries the P states of
+// its path and steps them all on each pair of normals it loads.  The single-set launch moves 16 B per path-step for some
+// 45 instructions of arithmetic and is HBM-bound on a calibration-sized path set (5.2 TB/s); the base point of an SLSQP
+// iterate and its finite-difference neighbours share their randoms, so P sets cost one pass over them.  Per set the
+// arithmetic is logsv_chain_w_indirect_kernel's, statement for statement (L re-derived from sigma at every slice start;
+// the same step, the same epilogue), hence the same bits as P single-set launches.  The model constants of the
+// (slice, set) pairs sit in LDS: P x 13 doubles would not fit the scalar registers, and in vector registers they would
+// cost the residency the loads need -- a broadcast ds_read per use runs beside the VALU stream.
+// consts: [m][P] LogsvConsts, init: [P] initial volatilities, x_snap / q_snap rows and partial column pairs: set-major,
+// (set s, slice i) at s m + i.
+constexpr int MAX_CHAIN_SETS = 8;
+static_assert(MAX_FUSED_SETS == MAX_CHAIN_SETS, "svmc_internal.h and the chain kernels must agree");
+template <int P>
+__global__ __launch_bounds__(BLOCK) void logsv_chain_w_sets_kernel(size_t n, ChainWSlices cs,
+                                                                   const LogsvConsts *__restrict__ consts,
+                                                                   const double *__restrict__ init, size_t ldw,
+                                                                   double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                   double *__restrict__ partials)
+{
+    __shared__ LogsvConsts s_c[P];
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const bool active = p < n;
+    double xv[P], sg[P], q[P], L[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        xv[s] = 0.0;
+        sg[s] = init[s];
+        q[s] = 0.0;
+    }
+    const int rows = cs.m * P;
+    for (int i = 0; i < cs.m; ++i) {
+        __syncthreads();                                   // everybody is done with the previous slice's constants
+        {
+            constexpr int ND = P * static_cast<int>(sizeof(LogsvConsts) / sizeof(double));
+            const double *src = reinterpret_cast<const double *>(consts + static_cast<size_t>(i) * P);
+            double *dst = reinterpret_cast<double *>(s_c);
+            for (int j = threadIdx.x; j < ND; j += BLOCK) dst[j] = src[j];
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) L[s] = log(sg[s]);
+            const double *const w[2] = {cs.W0[i] + p, cs.W1[i] + p};
+            streamed_time_loop<2>(w, ldw, cs.nb_steps[i], [&](const double(&v)[2]) {
+                // the constants are RE-READ from LDS at every step, not hoisted into 26 P registers: an opaque zero in the
+                // index (not an opaque pointer -- that would turn the reads into flat loads, which wait on the global
+                // loads in flight as well and undo the prefetch)
+                unsigned zero = 0;
+                asm volatile("" : "+v"(zero));
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    const LogsvConsts c = s_c[s + zero];
+                    logsv_step(c, xv[s], L[s], sg[s], q[s], c.sdt * v[0], c.sdt * v[1]);          // :1028-1030
+                }
+            });
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int row = s * cs.m + i;
+            const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
+                                 partials + 2 * row, cs.forward[i], 2 * rows};
+            slice_epilogue(so, p, active, xv[s], q[s]);
+            __syncthreads();                               // the epilogue's LDS scratch is reused by the next one
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__restrict__ x, double *__restrict__ vol,
                                                                     double *__restrict__ qvar, size_t n,
                                                                     const double *__restrict__ vol0)
@@ -1283,6 +1350,54 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                        static_cast<double *>(workspace));
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_slices), dim3(BLOCK), 0, stream,
                        static_cast<const double *>(workspace), static_cast<int>(g), 2 * n_slices, spot_sums);
+    return check_launch(fn);
+}
+
+// P parameter sets of a chain on resident randoms in one launch + one column reduce (svmc_logsv_chain_price_fixed_sets):
+// consts_dev = [m][P] LogsvConsts, vol0_dev = [P]; snapshots [P m][n] set-major, spot_sums [P m][2]
+template <int P>
+static void launch_chain_w_sets(unsigned g, hipStream_t stream, size_t n_path, const ChainWSlices &cs, const double *consts_dev,
+                                const double *vol0_dev, size_t ldw, double *x_snapshots, double *qvar_snapshots, void *workspace)
+{
+    hipLaunchKernelGGL(logsv_chain_w_sets_kernel<P>, dim3(g), dim3(BLOCK), 0, stream, n_path, cs,
+                       reinterpret_cast<const LogsvConsts *>(consts_dev), vol0_dev, ldw, x_snapshots, qvar_snapshots,
+                       static_cast<double *>(workspace));
+}
+
+int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
+                       const double *vol0_dev, const double *const *W0s, const double *const *W1s, size_t ldw,
+                       const double *forwards_host, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                       void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    const char *fn = "logsv_chain_w_sets";
+    if (n_slices < 1 || n_slices > MAX_CHAIN_SLICES || n_sets < 2 || n_sets > MAX_CHAIN_SETS || n_path == 0 || ldw < n_path)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
+    const unsigned g = grid_for(n_path);
+    const int cols = 2 * n_slices * n_sets;
+    if (workspace_bytes < static_cast<size_t>(g) * cols * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
+    ChainWSlices cs;
+    cs.m = n_slices;
+    for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+        const int j = (i < n_slices) ? i : 0;
+        if (W0s[j] == nullptr || W1s[j] == nullptr || nb_steps_host[j] <= 0)
+            return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad randoms / step counts");
+        cs.W0[i] = W0s[j];
+        cs.W1[i] = W1s[j];
+        cs.forward[i] = forwards_host[j];
+        cs.nb_steps[i] = (i < n_slices) ? nb_steps_host[j] : 0;
+    }
+    switch (n_sets) {
+    case 2: launch_chain_w_sets<2>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    case 3: launch_chain_w_sets<3>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    case 4: launch_chain_w_sets<4>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    case 5: launch_chain_w_sets<5>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    case 6: launch_chain_w_sets<6>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    case 7: launch_chain_w_sets<7>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    default: launch_chain_w_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
+    }
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
+                       static_cast<int>(g), cols, spot_sums);
     return check_launch(fn);
 }
 

@@ -39,19 +39,22 @@ inline LogsvConsts make_logsv_consts(double dt, double theta, double kappa1, dou
     return c;
 }
 
-// w0, w1 are the scaled increments sqrt(dt)*N(0,1)
+// w0, w1 are the scaled increments sqrt(dt)*N(0,1).  The reference's evaluation order with every multiply-add written as
+// an explicit fma(): which products the compiler would contract on its own depends on the code around the call, and the
+// kernels that inline this step (one parameter set per lane, several per lane) must give the same bits.
 __device__ __forceinline__ void logsv_step(const LogsvConsts &c, double &x, double &L, double &sigma,
                                            double &qvar, double w0, double w1)
 {
     const double s = sigma;
     const double s2dt = ((c.eta2 * s) * s) * c.dt;                                              // :1041
-    const double drift = ((((c.k1theta * rcp_fast(s)) - c.kappa1) + c.kappa2 * (c.theta - s)) + c.adj * s)
-                         - c.half_vartheta2;                    // k1theta/s: v_rcp_f64 + 2 Newton steps (<= 1 ULP)
-    x = (x + c.alpha_half * s2dt) + (c.eta * s) * w0;                                           // :1042
-    L = ((L + drift * c.dt) + c.beta * w0) + c.volvol * w1;                                     // :1043
+    double drift = fma(c.k1theta, rcp_fast(s), -c.kappa1);      // k1theta/s: v_rcp_f64 + 2 Newton steps (<= 1 ULP)
+    drift = fma(c.kappa2, c.theta - s, drift);
+    drift = fma(c.adj, s, drift) - c.half_vartheta2;
+    x = fma(c.eta * s, w0, fma(c.alpha_half, s2dt, x));                                         // :1042
+    L = fma(c.volvol, w1, fma(c.beta, w0, fma(drift, c.dt, L)));                                // :1043
     const double sn = exp_fast(L);                                                              // :1044
     sigma = sn;
-    qvar = qvar + 0.5 * (s2dt + ((c.eta2 * sn) * sn) * c.dt);                                   // :1045
+    qvar = fma(0.5, fma((c.eta2 * sn) * sn, c.dt, s2dt), qvar);                                 // :1045
 }
 
 // ---- the same LogSV step, regrouped for the issue-bound on-device-RNG kernel -------------------------

@@ -419,6 +419,7 @@ class DeviceRandoms:
         self.dts = [float(d) for d in dts]
         self.nb_steps, self.w0, self.w1 = [], [], []
         self._session, self._session_strikes = None, 0
+        self._session_sets, self._session_sets_size = None, (0, 0)
         for W0, W1 in zip(W0s, W1s):
             W0 = np.ascontiguousarray(W0, dtype=np.float64)
             W1 = np.ascontiguousarray(W1, dtype=np.float64)
@@ -449,6 +450,7 @@ class DeviceRandoms:
         self.dts = [float(d) for d in dts]
         self.nb_steps, self.w0, self.w1 = [int(n) for n in nb_steps], [], []
         self._session, self._session_strikes = None, 0
+        self._session_sets, self._session_sets_size = None, (0, 0)
         step0 = 0
         for nb in self.nb_steps:
             b0, b1 = DeviceBuffer(nb * self.n_local), DeviceBuffer(nb * self.n_local)
@@ -469,6 +471,9 @@ class DeviceRandoms:
         if self._session is not None:
             _lib.check(_lib.load().svmc_session_destroy(self._session))
             self._session = None
+        if self._session_sets is not None:
+            _lib.check(_lib.load().svmc_session_destroy(self._session_sets))
+            self._session_sets = None
 
     def graph_launches(self) -> int:
         """how many chain pricings of this object were hipGraph replays (diagnostics)"""
@@ -517,6 +522,53 @@ class DeviceRandoms:
             ivols.ctypes.data_as(dp) if want_ivols else None))
         split = lambda a: [a[offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
         return (split(prices), split(stderrs), split(ivols)) if want_ivols else (split(prices), split(stderrs))
+
+
+    def price_logsv_chain_sets(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
+                               params_rows: np.ndarray, is_spot_measure: bool, variable_type: int, want_ivols: bool = False):
+        """SEVERAL parameter sets on these randoms in one call of svmc_logsv_chain_price_fixed_sets: with 2..8 sets one
+        replayed graph whose stepping launch reads the randoms once for all of them.  params_rows [n_sets][6 + m] =
+        (v0, theta, kappa1, kappa2, beta, volvol, vol-backbone eta per expiry).  Returns per set what price_logsv_chain
+        returns -- the same bits."""
+        lib = _lib.load()
+        m = len(self)
+        params_rows = np.ascontiguousarray(params_rows, dtype=np.float64)
+        n_sets = params_rows.shape[0]
+        if params_rows.ndim != 2 or params_rows.shape[1] != 6 + m or n_sets < 1:
+            raise ValueError("params_rows must have shape [n_sets, 6 + n_expiries]")
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
+        total = int(offs[-1])
+        need = (m * n_sets, max(total * n_sets, 1))
+        if self._session_sets is None or self._session_sets_size[0] < need[0] or self._session_sets_size[1] < need[1]:
+            if self._session_sets is not None:
+                _lib.check(lib.svmc_session_destroy(self._session_sets))
+            sess = C.c_void_p()
+            _lib.check(lib.svmc_session_create(C.byref(sess), self.n_local, need[0], need[1]))
+            self._session_sets, self._session_sets_size = sess, need
+        dp = C.POINTER(C.c_double)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)      # noqa: E731
+        ttms, forwards, discfactors = f64(ttms), f64(forwards), f64(discfactors)
+        k_all = f64(np.concatenate(strikes)) if total else np.zeros(1)
+        c_all = np.ascontiguousarray(np.concatenate(codes), dtype=np.int8) if total else np.zeros(1, dtype=np.int8)
+        w0 = (C.c_void_p * m)(*[b.ptr for b in self.w0])
+        w1 = (C.c_void_p * m)(*[b.ptr for b in self.w1])
+        nbs = (C.c_int * m)(*self.nb_steps)
+        dts = f64(self.dts)
+        shape = (n_sets, max(total, 1))
+        prices, stderrs = np.empty(shape), np.empty(shape)
+        ivols = np.empty(shape) if want_ivols else None
+        _lib.check(lib.svmc_logsv_chain_price_fixed_sets(
+            self._session_sets, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp), m,
+            k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
+            n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), w0, w1, nbs,
+            dts.ctypes.data_as(dp), self.n_local, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp),
+            ivols.ctypes.data_as(dp) if want_ivols else None))
+        split = lambda a, q: [a[q, offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
+        out = []
+        for q in range(n_sets):
+            out.append((split(prices, q), split(stderrs, q), split(ivols, q)) if want_ivols
+                       else (split(prices, q), split(stderrs, q)))
+        return out
 
 
 def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float

@@ -271,6 +271,15 @@ class LogSVPricer(ModelPricer):
                     beta=p.beta, volvol=p.volvol, vol_backbone_etas=p.get_vol_backbone_etas(ttms=option_chain.ttms),
                     comm=comm, return_ivols=True, **chain_args)
                 return ivols
+
+            def model_vols_batch(pars_list):
+                # the bumped vectors of SLSQP's forward-difference gradient in one replay: every lane steps all of them on
+                # each pair of normals it reads (svmc_logsv_chain_price_fixed_sets) -- bit-identical to one call per vector
+                out = logsv_mc_chain_pricer_fixed_randoms_batch(params_list=[parse(p) for p in pars_list], W0s=resident,
+                                                                return_ivols=True, comm=comm, **chain_args)
+                return [res[2] for res in out]
+            if not kwargs.get("batched_gradient", True):
+                model_vols_batch = None
         elif calibration_engine == CalibrationEngine.ROUGH_MC:
             if kwargs.get("device_randoms", False):
                 # as for the MC engine: Z0 / Z1 drawn in HBM instead of by NumPy (same grids, another sample)
@@ -570,6 +579,43 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                 np.asarray(ty).ravel(), float(d)).reshape(np.shape(k))
              for p, t, f, k, ty, d in zip(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)]
     return prices, stderrs, ivols
+
+
+def logsv_mc_chain_pricer_fixed_randoms_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,
+                                              discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
+                                              optiontypes_ttms: Sequence[np.ndarray], W0s: DeviceRandoms,
+                                              is_spot_measure: bool = True,
+                                              variable_type: VariableType = VariableType.LOG_RETURN,
+                                              return_ivols: bool = False, comm=None) -> List[Tuple[List[np.ndarray], ...]]:
+    """logsv_mc_chain_pricer_fixed_randoms for SEVERAL parameter sets on the same resident randoms (W0s: the result of
+    upload_fixed_randoms / draw_fixed_randoms_on_device): per set the (prices, stderrs[, ivols]) of a single call, the
+    same bits.  On one GPU, 2..8 sets go through ONE replayed graph whose stepping launch reads the randoms once for all
+    sets (svmc_logsv_chain_price_fixed_sets) -- the base point of an SLSQP iterate and its finite-difference neighbours;
+    otherwise the sets are priced one after the other.  Not in the reference API."""
+    vt = variable_type_code(variable_type)
+    comm = comm or svdist.get_default_comm()
+    if not isinstance(W0s, DeviceRandoms):
+        raise TypeError("the batched pricer works on resident randoms (upload_fixed_randoms / draw_fixed_randoms_on_device)")
+    codes = [option_type_codes(t) for t in optiontypes_ttms]
+    if return_ivols and any(np.any(c > 1) for c in codes):
+        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
+    if comm.world == 1 and FUSED_FIXED_RANDOMS_DRIVER and len(W0s) == len(ttms):
+        strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
+        rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol] + list(p.get_vol_backbone_etas(ttms=ttms))
+                         for p in params_list], dtype=np.float64)
+        out = []
+        for q0 in range(0, len(params_list), 8):                      # a launch takes up to 8 sets
+            out += W0s.price_logsv_chain_sets(ttms, forwards, discfactors, [k.ravel() for k in strikes],
+                                              [c.ravel() for c in codes], rows[q0:q0 + 8], is_spot_measure, vt,
+                                              want_ivols=return_ivols)
+        return [tuple([a.reshape(np.shape(k)) for a, k in zip(part, strikes_ttms)] for part in res) for res in out]
+    return [logsv_mc_chain_pricer_fixed_randoms(ttms=ttms, forwards=forwards, discfactors=discfactors,
+                                                strikes_ttms=strikes_ttms, optiontypes_ttms=optiontypes_ttms, W0s=W0s,
+                                                W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+                                                kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                                vol_backbone_etas=p.get_vol_backbone_etas(ttms=ttms),
+                                                is_spot_measure=is_spot_measure, variable_type=variable_type, comm=comm,
+                                                return_ivols=return_ivols) for p in params_list]
 
 
 # ---------------------------------------------------------------------------------------------------

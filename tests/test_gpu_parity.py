@@ -840,6 +840,52 @@ def test_fixed_randoms_drawn_on_device(sv):
     res.free()
 
 
+def test_parameter_sets_share_one_pass_over_the_randoms(sv):
+    """logsv_mc_chain_pricer_fixed_randoms_batch / svmc_logsv_chain_price_fixed_sets: several parameter sets (the base point
+    of an optimizer iterate and its finite-difference neighbours) stepped by ONE launch that reads the resident randoms
+    once, every lane carrying all the sets' states.  Per set: the bits of a single-set call -- prices, standard errors
+    and implied vols; 1, 2, 3, 6, 8 and 9 sets (9 = a launch of 8 and a single); LOG_RETURN with vol backbones and
+    Q_VAR; a replay equals the capture."""
+    ttms = np.array([0.1, 0.3, 0.75])
+    k = np.linspace(0.7, 1.3, 7)
+    ty = np.where(k >= 1.0, "C", "P")
+    common = dict(ttms=ttms, forwards=np.array([1.0, 1.01, 1.02]), discfactors=np.array([0.999, 0.99, 0.98]),
+                  strikes_ttms=(k,) * 3, optiontypes_ttms=(ty,) * 3)
+    W = sv.get_randoms_for_chain_valuation(ttms, nb_path=6007, nb_steps_per_year=360, seed=5)
+    res = sv.upload_fixed_randoms(*W)
+    import pandas as pd
+    rng = np.random.default_rng(9)
+    sets = []
+    for j in range(9):
+        bb = None if j % 2 == 0 else pd.Series(1.0 + 0.1 * rng.standard_normal(3), index=ttms)
+        sets.append(sv.LogSvParams(sigma0=0.8 + 0.02 * j, theta=1.0 + 0.01 * j, kappa1=3.0 + 0.1 * j, kappa2=3.0 - 0.1 * j,
+                                   beta=0.15 - 0.03 * j, volvol=1.8 - 0.05 * j, vol_backbone=bb))
+
+    def single(p, **kw):
+        return sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+                                                      kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                                      vol_backbone_etas=p.get_vol_backbone_etas(ttms=ttms), **common, **kw)
+
+    for n_sets in (1, 2, 3, 6, 8, 9):
+        for rep in range(2):                                        # capture, then replay
+            out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets[:n_sets], W0s=res, return_ivols=True, **common)
+            assert len(out) == n_sets
+            for p, got in zip(sets, out):
+                want = single(p, return_ivols=True)
+                for a, b in zip(got[0] + got[1] + got[2], want[0] + want[1] + want[2]):
+                    np.testing.assert_array_equal(a, b, err_msg=f"{n_sets} sets, rep {rep}")
+    qv = dict(common, strikes_ttms=(np.array([0.2, 0.6, 1.0]),) * 3, optiontypes_ttms=(np.array(["C", "P", "C"]),) * 3)
+    out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets[:4], W0s=res, variable_type=sv.VariableType.Q_VAR, **qv)
+    for p, got in zip(sets, out):
+        want = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+                                                      kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                                      vol_backbone_etas=p.get_vol_backbone_etas(ttms=ttms),
+                                                      variable_type=sv.VariableType.Q_VAR, **qv)
+        for a, b in zip(got[0] + got[1], want[0] + want[1]):
+            np.testing.assert_array_equal(a, b)
+    res.free()
+
+
 def test_implied_vols_from_the_graph(sv, oracle):
     """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
     (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
@@ -1243,6 +1289,15 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
     tol = dict(rtol=2e-3, atol=2e-3) if tag != "an4" else dict(rtol=2e-2, atol=1e-2)   # an4: RK45 rtol 1e-3 in the reference
     np.testing.assert_allclose(_vec(fit), ref, **tol)
     assert pricer.last_calibration["n_eval"] > 5
+    if tag == "mc5":
+        # the MC engine's gradient from one replay per iterate (all bumped vectors stepped on one pass over the randoms):
+        # bit-identical objective values, hence the same fit as with SLSQP's own differencing
+        assert pricer.last_calibration["n_gradient_batches"] > 2
+        plain = sv.LogSVPricer()
+        fit0 = plain.calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start), disp=False,
+                                                     batched_gradient=False, **kw)
+        assert plain.last_calibration["n_gradient_batches"] == 0
+        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-9, atol=1e-12)
     if tag in ("mc5", "rough4"):
         # the same calibration on fixed randoms drawn in HBM instead of by NumPy: another sample of the same estimator
         fit_dev = sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start),

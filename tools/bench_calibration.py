@@ -61,8 +61,16 @@ def main():
     def price_ivols():
         return lp.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True, **kw)[2]
 
+    sets = [sv.LogSvParams(sigma0=p.sigma0 + 1e-8 * j, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta,
+                           volvol=p.volvol) for j in range(6)]
+    chain_kw = {k_: kw[k_] for k_ in ("ttms", "forwards", "discfactors", "strikes_ttms", "optiontypes_ttms")}
+
+    def price_six_sets():
+        return lp.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets, W0s=res, return_ivols=True, **chain_kw)
+
     pr = price()
     t_price = timed(price)
+    t_six = timed(price_six_sets)
     t_price_iv = timed(price_ivols)
     t_iv = timed(lambda: ivols(pr))
     steps = sum(res.nb_steps)
@@ -76,7 +84,7 @@ def main():
     t_direct = {}
     for g in (False, True):
         t_direct[g] = timed(lambda: direct(g))
-    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_with_ivols_from_the_graph_ms=1e3 * t_price_iv, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
+    print(json.dumps(dict(nb_path=nb_path, steps=steps, host_draw_s=t_draw, upload_s=t_up, price_ms=1e3 * t_price, price_with_ivols_from_the_graph_ms=1e3 * t_price_iv, six_parameter_sets_one_replay_with_ivols_ms=1e3 * t_six, price_python_driver_ms=1e3 * t_price_py, fused_no_graph_ms=1e3 * t_direct[False],
                           fused_graph_ms=1e3 * t_direct[True],
                           ivol_ms=1e3 * t_iv, kernel_floor_ms=1e3 * nb_path * steps / 3.7e11)))
     prof = cProfile.Profile()

@@ -32,17 +32,21 @@ def main():
     chain = sv.OptionChain(bid_ivs=tuple(v - 0.002 for v in vols), ask_ivs=tuple(v + 0.002 for v in vols), **base)
     start = sv.LogSvParams(sigma0=0.7, theta=0.8, kappa1=3.0, kappa2=3.0, beta=0.0, volvol=1.2)
     out = dict(nb_path=nb_path)
-    for name, dev in (("host_randoms", False), ("device_randoms", True), ("host_randoms_2", False), ("device_randoms_2", True)):
+    for name, dev, batched in (("host_randoms", False, True), ("device_randoms", True, True), ("host_randoms_2", False, True),
+                               ("device_randoms_2", True, True), ("device_randoms_slsqp_differences", True, False),
+                               ("device_randoms_slsqp_differences_2", True, False)):
         p = sv.LogSVPricer()
         t0 = time.perf_counter()
         fit = p.calibrate_model_params_to_chain(option_chain=chain, params0=start, disp=False, nb_path=nb_path, nb_steps=360,
                                                 seed=10, calibration_engine=sv.CalibrationEngine.MC,
                                                 model_calibration_type=sv.LogsvModelCalibrationType.PARAMS5,
-                                                device_randoms=dev)
+                                                device_randoms=dev, batched_gradient=batched)
         dt = time.perf_counter() - t0
         out[name] = dict(seconds=dt, n_eval=p.last_calibration["n_eval"], objective=p.last_calibration["objective"],
                          fit=[fit.sigma0, fit.theta, fit.kappa1, fit.kappa2, fit.beta, fit.volvol])
     out["speedup"] = out["host_randoms_2"]["seconds"] / out["device_randoms_2"]["seconds"]
+    out["speedup_of_the_batched_gradient"] = (out["device_randoms_slsqp_differences_2"]["seconds"] /
+                                              out["device_randoms_2"]["seconds"])
     print(json.dumps(out))
 
 
