@@ -3,8 +3,10 @@
 bench.py -- MC path-steps/s of the StochVolModels Monte Carlo hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config c2|c4]
+        N > 1 without a launcher: bench.py starts its own N ranks (python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>), one per visible GPU, RCCL backend
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form: used as launched)
 
 Workloads (BASELINE.json `configs`):
   c2  (default at --gpus 1; the configuration the headline metric is quoted on)  LogSV quadratic-drift MC,
@@ -19,19 +21,26 @@ logsv_mc_chain_pricer call: state init, stepping kernel(s), spot-sum and payoff 
 all-reduces), D2H of the prices.  Weak scaling: per-GPU work is fixed.
 
 Prints ONE JSON line (rank 0): `value` = whole-job path-steps/s; `roofline` = the dominant kernel against the roof
-that binds it (VALU issue: the kernel moves 56 B per path per expiry and no HBM byte inside the time loop), HIP events
-on the launch stream; `roofline_hbm` = the same kernel against HBM (BASELINE asks for it); `cpu_baseline` = the CPU
-oracle (a port of the reference's algorithm) timed on one host core on a bounded sample; at N > 1 also
-`n1_share_value` (this rank's shard priced WITHOUT the group: the denominator of the weak-scaling ratio) and
-`c4_full_one_gpu` (all N x 2^21 paths on ONE device: the denominator of the strong-scaling ratio).
+that binds it (VALU issue: the kernel moves 56 B per path per expiry and no HBM byte inside the time loop): the time
+loop's instruction histogram read off the compiler's assembly of the loaded library (libsvmc.isa.json, written by the
+build) priced per opcode class with the issue costs measured in profiles/r03_valu_rates.txt, over the kernel time from
+HIP events on the launch stream; `roofline_hbm` = the same kernel against HBM (BASELINE asks for it); `cpu_baseline` =
+the CPU oracle (a port of the reference's algorithm) timed on one host core on a bounded sample; at N > 1 also
+`n1_share_value` (this rank's shard priced WITHOUT the group: the denominator of the weak-scaling ratio),
+`c4_full_one_gpu` (all N x 2^21 paths on ONE device: the denominator of the strong-scaling ratio), `rccl_ranks_seen` and
+`rccl_route` (the same chain timed through libsvmc's own RCCL entry points, the route a C host takes).
 See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -42,19 +51,30 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for R
 
 import numpy as np  # noqa: E402
 
-# MI355X (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8 TB/s spec; 256 CUs x 4 SIMDs, max clock 2400 MHz, one VALU
-# instruction per SIMD per 4 cycles (wave64 on 16 lanes); vector fp64 78.6 TFLOP/s (FMA = 2)
+# MI355X (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8 TB/s spec; 256 CUs x 4 SIMDs, max clock 2400 MHz; vector fp64
+# 78.6 TFLOP/s (FMA = 2), i.e. one fp64 wave64 instruction per SIMD per 4 cycles
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TFLOPS = 78.6
 N_SIMD = 256 * 4
 MAX_CLOCK_HZ = 2.4e9
-VALU_ISSUE_PEAK = N_SIMD * MAX_CLOCK_HZ / 4.0          # full-rate wave-instructions per second, whole chip
-# Untimed steps ahead of the caller's warm-up (disclosed as device_prewarm_steps).  Two things have to be behind the
-# process before K steps of 2-6 ms can be timed: the GPU's clock ramp (the first ~10 launches run 20-25 % slow) and a
-# ONE-TIME stall of the ROCm runtime -- a single call of ~60 ms observed at the ~150th chain call of a process for C2
-# and the ~41st for C4 (profiles/r02_runtime_stall.txt: 400-step runs, one slow step each, none afterwards) -- which a
-# 50-step window would otherwise swallow whole.  `ms_per_step_profile` in the output shows the timed steps one by one.
-PREWARM = int(os.environ.get("SVMC_BENCH_PREWARM", "200"))       # the environment override exists for the test suite
+SIMD_CYCLES_PEAK = N_SIMD * MAX_CLOCK_HZ               # SIMD issue cycles per second, whole chip
+# Issue cost of a wave64 VALU instruction on one SIMD, in shader cycles, by opcode class -- MEASURED on this chip with
+# tools/ubench/valu_rates.hip (profiles/r03_valu_rates.txt, s_memtime ticks, 8 waves per SIMD; measured 4.08-4.17 / 16.2 /
+# 4.07-4.17 / 2.17-2.25 / 8.1, rounded DOWN to the architectural figure so that the roof is never understated):
+#   fp64       4   v_fma / mul / add / max / ldexp / cvt ..._f64, v_mad_u64_u32, 64-bit shifts and moves
+#   quarter   16   v_rcp_f64, v_rsq_f64, v_sqrt_f64
+#   int32_3op  4   the three-operand 32-bit integer ops (v_bfi, v_add3, v_lshl_add, v_perm, v_alignbit, v_mul_lo/hi ...)
+#   int32      2   two-operand 32-bit ops, v_bitop3_b32, v_fma_f32 -- 2 only back to back; mixed into an fp64 stream they
+#                  cost 3.5 (1:1) to 3.9 (1:3) cycles each (the MIX rows of the same file): `frac` below prices them at 2,
+#                  `frac_in_stream_int32_cost` at the 3.9 the stepping loop's own mix (about 1 in 4) measures
+#   trans32    8   v_exp / log / rcp / rsq / sqrt / sin / cos _f32
+CLASS_CYCLES = {"fp64": 4.0, "quarter": 16.0, "int32_3op": 4.0, "int32": 2.0, "trans32": 8.0}
+INT32_IN_FP64_STREAM_CYCLES = 3.9
+# Untimed steps ahead of the caller's warm-up (disclosed as device_prewarm_steps): the GPU's clock ramp -- the first ~10
+# launches of a process run 20-25 % slow.  (Round 2 ran 200 here to get past a one-time ~60 ms step; that step is CPython's
+# generation-2 garbage collection -- profiles/r03_gc_stall.json: gc callbacks put a 53-67 ms full collection exactly there
+# -- and the timed region now runs after gc.collect() + gc.freeze(), as any latency-sensitive Python service does.)
+PREWARM = int(os.environ.get("SVMC_BENCH_PREWARM", "10"))         # the environment override exists for the test suite
 # SURVEY.md 8(d)'s ESTIMATE of the algorithmic work per LogSV path-step in fp64 op-equivalents (34 simple flops + div 10
 # + sqrt 10 + exp/log/sincos 25 each + Philox/conversion ~ 11): a model of the reference's arithmetic, not a count
 LOGSV_FLOP_EQ_PER_PATH_STEP = 140.0
@@ -198,12 +218,42 @@ def cpu_baseline_all_cores(nb_steps: int, P) -> dict:
 # ---------------------------------------------------------------------------------------------------------------
 # profile-derived constants (committed under profiles/, collected by tools/collect_profiles.sh)
 # ---------------------------------------------------------------------------------------------------------------
-def load_pmc():
+def file_sha256(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def load_isa(lib_path: str) -> dict:
+    """the time loops' instruction histograms of the LOADED library: libsvmc.isa.json is written beside libsvmc.so by the
+    build that produced it (stochvolmodels_amd/build.py, from that compilation's own assembly) and names the library's
+    sha256 -- a mismatch (someone rebuilt the .so by hand) marks every roofline of the line stale"""
+    out = {"lib_sha256": file_sha256(lib_path), "kernels": {}, "stale": True, "source": None}
+    path = os.path.join(os.path.dirname(lib_path), "libsvmc.isa.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as fh:
-            return json.load(fh)
+        with open(path) as fh:
+            isa = json.load(fh)
+    except (OSError, ValueError):
+        return out
+    out["kernels"] = isa.get("kernels", {})
+    out["stale"] = isa.get("lib_sha256") != out["lib_sha256"]
+    out["source"] = os.path.relpath(path, ROOT)
+    return out
+
+
+def load_pmc(lib_sha256: str) -> dict:
+    """the committed counter passes (rocprofv3 --pmc; tools/collect_profiles.sh -> profiles/r03_pmc.json): measured
+    SQ_INSTS_VALU per wave-step (cross-check of the assembly count) and HBM traffic.  They were collected on ONE build;
+    `matches_loaded_library` says whether it is the one running now"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as fh:
+            pmc = json.load(fh)
     except (OSError, ValueError):
         return {}
+    pmc["matches_loaded_library"] = pmc.get("lib_sha256") == lib_sha256
+    return pmc
 
 
 class ClockPoller:
@@ -271,44 +321,55 @@ def streamed_roofline(eng, P, nb_steps: int, pmc) -> dict:
             "config": {"paths": n, "steps": nb_steps, "bytes_per_path_step": 16}}
 
 
-def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, pmc, clock_mhz) -> dict:
-    """the stepping kernel of one chain call against (a) the VALU issue port -- the roof that binds it -- from the
-    committed SQ_INSTS_VALU pass, (b) HBM, (c) SURVEY's flop-equivalent estimate"""
+def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, isa, pmc, clock_mhz) -> dict:
+    """the stepping kernel of one chain call against (a) the VALU issue port -- the roof that binds it: the time loop's
+    instructions by opcode class (from the loaded library's assembly) x the measured issue cost of each class, (b) HBM,
+    (c) SURVEY's flop-equivalent estimate"""
     nb, m = wl["nb_total"], len(wl["grids"])
+    hist = isa["kernels"].get(kernel, {})
     prof = pmc.get(kernel, {})
-    per_step = prof.get("valu_insts_per_wave_step")
-    quarter = prof.get("quarter_rate_insts_per_step", 2)
+    alg_bytes = (48.0 + 8.0 * m) * n_local     # 24 B state read + 24 B write per chain, 8 B terminal-x snapshot per expiry
+    traffic = prof.get("hbm_bytes") if prof.get("config") == {"paths": n_local, "steps": nb} else None
     wave_steps = (n_local / 64.0) * nb
     out = {}
-    if per_step is not None:
-        # full-rate-equivalent issue slots: v_rcp_f64 / v_rsq_f64 hold the port for 16 cycles instead of 4
-        slots = per_step + 3.0 * quarter
-        achieved = slots * wave_steps / (k_ms * 1e-3)
+    classes = hist.get("classes")
+    if classes:
+        steps_per_iteration = 2.0              # one Philox call = one trip of the time loop = two time steps
+        cyc = sum(CLASS_CYCLES[c] * n for c, n in classes.items()) / steps_per_iteration
+        cyc_in_stream = sum((INT32_IN_FP64_STREAM_CYCLES if c == "int32" else CLASS_CYCLES[c]) * n
+                            for c, n in classes.items()) / steps_per_iteration
+        per_step = hist["valu"] / steps_per_iteration
+        achieved = cyc * wave_steps / (k_ms * 1e-3)
+        measured = prof.get("valu_insts_per_wave_step") if pmc.get("matches_loaded_library") else None
         out["roofline"] = {
-            "kernel": kernel, "bound": "valu_issue", "achieved": achieved, "peak": VALU_ISSUE_PEAK,
-            "unit": "wave-instr/s (full-rate slots)", "frac": achieved / VALU_ISSUE_PEAK,
-            "insts_per_wave_step": per_step, "quarter_rate_insts": quarter, "issue_slots_per_wave_step": slots,
-            "insts_source": prof.get("source", "profiles/r02_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU)"),
-            "peak_definition": "1024 SIMDs x 2400 MHz / 4 cycles per wave64 instruction",
+            "kernel": kernel, "bound": "valu_issue", "achieved": achieved, "peak": SIMD_CYCLES_PEAK,
+            "unit": "SIMD issue cycles/s", "frac": achieved / SIMD_CYCLES_PEAK,
+            "frac_in_stream_int32_cost": cyc_in_stream * wave_steps / (k_ms * 1e-3) / SIMD_CYCLES_PEAK,
+            "issue_cycles_per_wave_step": cyc, "insts_per_wave_step": per_step,
+            "classes_per_loop_trip": classes, "class_cycles": CLASS_CYCLES, "steps_per_loop_trip": steps_per_iteration,
+            "lds_insts_per_wave_step": hist.get("lds", 0) / steps_per_iteration,
+            "insts_source": f"{isa['source']} (assembly of the loaded library, sha256 {isa['lib_sha256'][:16]})",
+            "rates_source": "profiles/r03_valu_rates.txt (tools/ubench/valu_rates.hip)",
+            "stale": bool(isa["stale"]),
+            "insts_per_wave_step_counters": measured,      # SQ_INSTS_VALU of profiles/r03_pmc.json, when it is this build's
+            "peak_definition": "1024 SIMDs x 2400 MHz; a wave64 instruction holds its SIMD for the cycles of its class",
             # informational: the SMU's engine-clock reading sampled while the same call repeats for 2 s after the timed region;
             # the sensor averages and lags (boxes of the pool have reported 2100-2395 MHz for the same kernel time), so the
             # fraction above is against the 2400 MHz maximum, never against this reading
             "clock_mhz_sensor": clock_mhz, "ms_per_launch": k_ms, "launches": launches,
-            "traffic": prof.get("hbm_bytes") if prof.get("config") == {"paths": n_local, "steps": nb} else None,
-            "algorithmic_bytes": (48.0 + 8.0 * m) * n_local,
+            "traffic": traffic, "algorithmic_bytes": alg_bytes,
         }
-        if prof.get("note"):
+        if prof.get("note") and traffic is not None:
             out["roofline"]["traffic_note"] = prof["note"]
-    alg_bytes = (48.0 + 8.0 * m) * n_local     # 24 B state read + 24 B write per chain, 8 B terminal-x snapshot per expiry
     hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
     hbm = {"kernel": kernel, "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes, "ms_per_launch": k_ms, "launches": launches,
-           "traffic": prof.get("hbm_bytes") if prof.get("config") == {"paths": n_local, "steps": nb} else None,
+           "traffic": traffic,
            "note": "on-device-RNG stepping moves 48 + 8 M bytes per path per chain and nothing inside the time loop: "
                    "not HBM-bound by construction"}
     out["roofline_hbm"] = hbm
-    if "roofline" not in out:                  # no committed counter pass for this kernel: report the HBM roof
-        out["roofline"] = hbm
+    if "roofline" not in out:                  # no histogram for this kernel (libsvmc.isa.json missing): report the HBM roof
+        out["roofline"] = dict(hbm, stale=True)
     rate = n_local * nb / (k_ms * 1e-3)
     out["roofline_valu_flop_estimate"] = {
         "kernel": kernel, "bound": "valu_fp64", "achieved": rate * LOGSV_FLOP_EQ_PER_PATH_STEP / 1e12,
@@ -320,6 +381,31 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
     return out
 
 
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the driver's
+    own command does -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- and pass their output
+    through (rank 0 prints the line)."""
+    import ctypes as C
+
+    from stochvolmodels_amd import _lib
+    count = C.c_int(0)
+    _lib.check(_lib.load().svmc_device_count(C.byref(count)))
+    sharing = os.environ.get("SVMC_DIST_BACKEND") == "gloo"        # test mode: the ranks share the GPUs there are
+    if count.value < args.gpus and not sharing:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {count.value} GPU(s) visible -- one rank per GPU is required "
+                         f"(RCCL refuses two ranks on one device; SVMC_DIST_BACKEND=gloo lets ranks share a GPU for testing)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVMC_BENCH_SELF_LAUNCHED="1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -327,8 +413,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        if os.environ.get("SVMC_BENCH_SELF_LAUNCHED") == "1":
+            raise SystemExit("bench.py: launched ranks without WORLD_SIZE (torch.distributed.run did not set the environment)")
+        sys.exit(self_launch(args))
 
     import torch  # device plumbing + torch.distributed only
     import stochvolmodels_amd as sv
@@ -360,7 +447,9 @@ def main():
     n_total = per_gpu * world
     nb = wl["nb_total"]
     kernel = "logsv_rng_kernel" if len(wl["grids"]) == 1 else "logsv_chain_rng_kernel"
-    pmc = load_pmc()
+    from stochvolmodels_amd import _lib as svlib
+    isa = load_isa(svlib.LIB_PATH)
+    pmc = load_pmc(isa["lib_sha256"])
 
     def step(i):
         return price(sv, wl, P, n_total, 20240602 + i)
@@ -371,6 +460,10 @@ def main():
         step(-1 - i)
     offset, n_local = svdist.shard_range(n_total, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)
+    # no full garbage collection inside the timed region: everything alive now (the imports' ~70 000 container objects)
+    # moves to the permanent generation, so the collector's passes over what the steps allocate stay in the microseconds
+    gc.collect()
+    gc.freeze()
     barrier()
     if os.environ.get("SVMC_BENCH_NO_KERNEL_EVENTS") != "1":     # diagnostics: the HIP events around the stepping launches
         eng.start_kernel_timing()
@@ -399,6 +492,38 @@ def main():
         p_ordered, _ = step(424242)
         extra["stream_ordered_equals_strict_sync"] = bool(all(np.array_equal(a, b) for a, b in zip(p_strict, p_ordered)))
     extra["comm"] = type(comm).__name__
+    extra["backend"] = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    extra["rccl_ranks_seen"] = None
+    if isinstance(comm, svdist.RcclComm):
+        extra["rccl_ranks_seen"] = comm.ranks_seen()
+    if torch.distributed.is_initialized() and not isinstance(comm, svdist.RcclComm) and not args.no_extra_legs:
+        # the same chain through libsvmc's OWN RCCL entry points (include/svmc.h svmc_rccl_*: the route a C / C++ host
+        # takes; dist.RcclComm drives it from Python): a second communicator built from a unique id that the torch group
+        # ships, the two all-reduces issued by libsvmc on the engine's stream.  ncclCommCount says how many ranks RCCL
+        # itself sees.  Refused where two ranks share a device (the gloo test mode): reported, not fatal.
+        try:
+            box = [svdist.RcclComm.unique_id() if rank == 0 else None]
+            torch.distributed.broadcast_object_list(box, src=0)
+            rc = svdist.RcclComm(rank, world, box[0])
+            extra["rccl_ranks_seen"] = rc.ranks_seen()
+            k = max(3, min(args.steps, 20))
+            for i in range(3):
+                price(sv, wl, P, n_total, 7 + i, comm=rc)
+            barrier()
+            t0r = time.perf_counter()
+            for i in range(k):
+                p_rccl, _ = price(sv, wl, P, n_total, 20240602 + i, comm=rc)
+            barrier()
+            t_rccl = max_over_ranks((time.perf_counter() - t0r) / k)
+            p_torch, _ = price(sv, wl, P, n_total, 20240602 + k - 1)
+            extra["rccl_route"] = {"comm": "RcclComm (svmc_rccl_* through the C ABI)", "value": n_total * nb / t_rccl,
+                                   "ms_per_step": 1e3 * t_rccl, "steps": k, "origin": rc.origin(),
+                                   "prices_equal_torch_route": bool(all(np.array_equal(a, b) for a, b in zip(p_rccl, p_torch)))}
+            rc.close()
+        except Exception as exc:                             # noqa: BLE001  (e.g. ncclCommInitRank: two ranks on one device)
+            extra["rccl_route"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            if torch.distributed.is_initialized():
+                torch.distributed.barrier()
     if not args.no_extra_legs and (world > 1 or cfg == "c4"):
         # (a) this rank's shard WITHOUT the group: same kernels, no collectives -- the N = 1 rate the weak-scaling ratio
         #     is formed from (all ranks run it concurrently, each on its own GPU; the slowest rank's figure is reported)
@@ -454,9 +579,11 @@ def main():
                     step(10_000 + i)
                     i += 1
             clock_mhz = clk.steady_mhz()
-        result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, pmc, clock_mhz))
+        result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, isa, pmc, clock_mhz))
         result.update(extra)
         result["device_prewarm_steps"] = PREWARM
+        result["gc_frozen_before_timed_region"] = True
+        result["self_launched"] = os.environ.get("SVMC_BENCH_SELF_LAUNCHED") == "1"
         result["ms_per_step_profile"] = {"first5": [round(float(v), 3) for v in per_step_ms[:5]],
                                          "last5": [round(float(v), 3) for v in per_step_ms[-5:]],
                                          "median": round(float(np.median(per_step_ms)), 3),

@@ -355,9 +355,20 @@ SVMC_API const char *svmc_rccl_origin(void);         /* where RCCL was resolved 
 SVMC_API int svmc_rccl_unique_id(void *id_out, size_t bytes);
 SVMC_API int svmc_rccl_comm_create(svmc_comm_t *comm, const void *id_bytes, size_t bytes, int world, int rank);
 SVMC_API int svmc_rccl_comm_destroy(svmc_comm_t comm);
+/* ncclCommCount / ncclCommUserRank of a communicator: the number of ranks RCCL itself sees in it (bench.py reports it as
+ * rccl_ranks_seen) and this rank's index; rank_out may be NULL */
+SVMC_API int svmc_rccl_comm_count(svmc_comm_t comm, int *world_out, int *rank_out);
 SVMC_API int svmc_rccl_all_reduce_sum(svmc_comm_t comm, double *buf, size_t n, svmc_stream_t stream);
 SVMC_API int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int rank, int world,
                                    uint64_t n_path_total, uint64_t path_offset);
+/* The same sharding with the two sum all-reduces handed to the CALLER: fn(user, device_buf, n, stream) must leave in
+ * device_buf (n doubles, written by kernels queued on `stream`) the element-wise sum over all ranks, visible to work queued
+ * on `stream` afterwards, and return SVMC_OK -- MPI, a host-staged exchange, or several sessions of ONE process on one GPU
+ * summing through host memory (tests/test_gpu_parity.py runs 2- and 3-shard jobs that way and requires the unsharded bits).
+ * fn == NULL detaches, as svmc_session_set_comm(session, NULL, ...). */
+typedef int (*svmc_all_reduce_fn)(void *user, double *device_buf, size_t n, svmc_stream_t stream);
+SVMC_API int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn fn, void *user, int rank, int world,
+                                      uint64_t n_path_total, uint64_t path_offset);
 
 /* ---- analytic side: affine-expansion MGF + Fourier inversion ------------------
  * Complex arrays are interleaved (re, im) doubles, i.e. numpy.complex128 / C99 double complex, on the device.

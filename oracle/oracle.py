@@ -31,7 +31,8 @@ _lib = None
 def build(force: bool = False) -> str:
     """compile oracle/libsvmc_oracle.so with the committed Makefile (gcc only)."""
     src_time = max(os.path.getmtime(os.path.join(_HERE, f))
-                   for f in ("svmc_oracle.c", "svmc_oracle_analytic.c", "svmc_oracle_rough.c", "svmc_oracle.h", "Makefile"))
+                   for f in ("svmc_oracle.c", "svmc_oracle_analytic.c", "svmc_oracle_rough.c", "svmc_oracle.h", "svo_icdf_table.h",
+                             "Makefile"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_time:
         subprocess.run(["make", "-C", _HERE, "-B", "libsvmc_oracle.so"], check=True, capture_output=True)
     return _SO
@@ -54,6 +55,8 @@ def lib() -> C.CDLL:
         L.svo_payoff.restype = i32
         L.svo_philox4x32_10.argtypes = [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
         L.svo_fill_normals.argtypes = [u64, u32, u64, u32, sz, i32, _dp, _dp, sz]
+        L.svo_normal_from_word.argtypes = [u32]
+        L.svo_normal_from_word.restype = f64
         L.svo_fill_normals_stream.argtypes = [u64, u32, u32, u64, u32, sz, i32, _dp, _dp, sz]
         L.svo_fill_uniforms.argtypes = [u64, u32, u64, u32, sz, i32, _dp, sz]
         L.svo_logsv_terminal_rng.argtypes = [sz, i32, f64, _dp, _dp, _dp, f64, f64, f64, f64, f64, f64, i32,
@@ -192,6 +195,11 @@ def philox4x32_10(ctr: Sequence[int], key: Sequence[int]) -> Tuple[int, int, int
     o = (C.c_uint32 * 4)()
     lib().svo_philox4x32_10(c, k, o)
     return tuple(int(v) for v in o)
+
+
+def normal_from_word(w: int) -> float:
+    """one N(0,1) variate from one 32-bit word: the stream's piecewise-cubic inverse CDF (svo_normal_from_word)"""
+    return float(lib().svo_normal_from_word(int(w) & 0xFFFFFFFF))
 
 
 def fill_normals(seed, n_path, nb_steps, call_id=0, path_offset=0, step_offset=0, stream=0):

@@ -289,16 +289,21 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  * checked at its 10-round setting against the Random123 known-answer vectors in tests/test_oracle_golden.py).
  * The svmc streams use SEVEN rounds, the smallest Crush-resistant count the paper reports for 4x32.
  *
- * svmc stream definition, version 2 (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h).
- * One call yields the Box-Muller pairs of TWO consecutive time steps:
+ * svmc stream definition, version 3 (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h).
+ * One call yields the two normals of TWO consecutive time steps, each 32-bit word turned into ONE N(0,1) variate by
+ * inversion:
  *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8)
  *   r0..r3 = philox4x32_7(ctr, key);  (ra, rb) = (r0, r1) for an even step, (r2, r3) for an odd one
- *   u1 = (ra + 1/2) 2^-32                                  in (0,1), exact in fp64
- *   t  = 2 pi (rb + 1/2) 2^-32                             the angle, uniform on the full circle
- *   streams 0, 3:  R = sqrt(-ln u1);  w0 = R sqrt2 cos t;  w1 = R sqrt2 sin t    (= sqrt(-2 ln u1) (cos t, sin t))
+ *   z(r):  t = (int32) r + 1/2 (symmetric about 0, never 0);  j = the segment of |t| -- (low 5 bits of the biased fp64
+ *          exponent) << M | (top M mantissa bits), 32 octaves x 2^M equal parts;  d = |t| - (lower edge of segment j);
+ *          z = sign(t) * fma(fma(fma(a3, d, a2), d, a1), d, a0)  with {a0..a3}[j] from svo_icdf_table.h, the
+ *          piecewise cubic of -Phi^-1(|t| 2^-32) generated by tools/gen_icdf_table.py (the same bytes as the product's
+ *          csrc/svmc_icdf_table.h; tests/test_oracle_golden.py pins the table against scipy's Phi^-1 at
+ *          SVMC_ICDF_MAX_ABS_ERROR).  This evaluation order, FMAs included, IS the definition of the stream.
+ *   streams 0, 3:  (w0, w1) = (z(ra), z(rb))
  *   stream 1:  one call per draw, uniform = ((r0 | r1<<32) >> 12) 2^-52 + 2^-53
- *   stream 2 (vol paths, one Brownian per step): normal t = component t & 1 of pair (t >> 1) & 1 of call t >> 2
- *   Heston QE: pairs from stream 4 (as stream 0), uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2
+ *   stream 2 (vol paths, one Brownian per step): normal t = z(word t & 3 of call t >> 2)
+ *   Heston QE: normals from stream 4 (as stream 0), uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2
  * ---------------------------------------------------------------------------------------------- */
 #define SVO_PHILOX_ROUNDS 7
 
@@ -336,16 +341,36 @@ static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, u
     svo_philox4x32(ctr, key, SVO_PHILOX_ROUNDS, r);
 }
 
-/* the pair of one (ra, rb) word pair */
+#include "svo_icdf_table.h"
+#if !SVMC_ICDF_EDGE || SVMC_ICDF_DEG != 3
+#error "the oracle restates the edge-form cubic table"
+#endif
+static const double svo_icdf_p0[SVMC_ICDF_SEGMENTS][2] = { SVMC_ICDF_PIECE0_INIT };    /* {a0, a1} */
+static const double svo_icdf_p1[SVMC_ICDF_SEGMENTS][2] = { SVMC_ICDF_PIECE1_INIT };    /* {a2, a3} */
+
+/* one N(0,1) variate from one word (svmc_math.h normal_icdf32) */
+double svo_normal_from_word(uint32_t w)
+{
+    const double t = (double)(int32_t)w + 0.5;
+    uint64_t bits;
+    memcpy(&bits, &t, 8);
+    const uint32_t hi = (uint32_t)(bits >> 32);
+    const uint32_t j = (hi >> (20 - SVMC_ICDF_M)) & (SVMC_ICDF_SEGMENTS - 1u);
+    const uint64_t ebits = (uint64_t)(hi & (0x7FFFFFFFu & ~((1u << (20 - SVMC_ICDF_M)) - 1u))) << 32;
+    double edge;
+    memcpy(&edge, &ebits, 8);
+    const double d = fabs(t) - edge;                         /* exact */
+    double p = fma(svo_icdf_p1[j][1], d, svo_icdf_p1[j][0]);
+    p = fma(p, d, svo_icdf_p0[j][1]);
+    p = fma(p, d, svo_icdf_p0[j][0]);
+    return copysign(p, t);
+}
+
+/* the two normals of one (ra, rb) word pair */
 static inline void pair_from_words(uint32_t ra, uint32_t rb, double *w0, double *w1)
 {
-    static const double TWO_PI = 6.28318530717958647693, SQRT2 = 1.41421356237309504880;
-    double u1 = ((double)ra + 0.5) * 0x1.0p-32;
-    double t = TWO_PI * (((double)rb + 0.5) * 0x1.0p-32);    /* (rb + 1/2) 2^-32 is exact; t in (0, 2 pi) */
-    double R = sqrt(-log(u1));                               /* the sqrt2 of sqrt(-2 ln u) lives in (a, b) */
-    double a = SQRT2 * cos(t), b = SQRT2 * sin(t);
-    *w0 = R * a;
-    *w1 = R * b;
+    *w0 = svo_normal_from_word(ra);
+    *w1 = svo_normal_from_word(rb);
 }
 
 static void draw_normals_stream(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step, uint32_t stream,
@@ -503,7 +528,7 @@ void svo_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
             if (brownians) {
                 w = brownians[(size_t)t * ldb + p];
             } else {
-                if ((t & 1) == 0) draw_normals_stream(seed, call_id, path_offset + p, (uint32_t)(t >> 1), 2u, &z0, &z1);   /* = pair (t >> 1) & 1 of call t >> 2 */
+                if ((t & 1) == 0) draw_normals_stream(seed, call_id, path_offset + p, (uint32_t)(t >> 1), 2u, &z0, &z1);   /* = words (t & 2), (t & 2) + 1 of call t >> 2 */
                 w = sdt * ((t & 1) ? z1 : z0);
             }
             L = (L + ((((k1theta / s) - kappa1) + kappa2 * (theta - s)) + adj * s - 0.5 * vartheta2) * dt) + vartheta * w;

@@ -12,7 +12,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # SVMC_LIB: an alternative build of the same ABI (A/B runs of tools/ubench/build_variants.sh); default: the in-tree library
 LIB_PATH = os.environ.get("SVMC_LIB") or os.path.join(_PKG, "libsvmc.so")
 
-OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNKNOWN_PAYOFF, ERR_UNSUPPORTED_VARIABLE, ERR_WORKSPACE = range(6)
+OK, ERR_INVALID_ARGUMENT, ERR_HIP, ERR_UNKNOWN_PAYOFF, ERR_UNSUPPORTED_VARIABLE, ERR_WORKSPACE, ERR_RCCL = range(7)
+
+# svmc_all_reduce_fn (include/svmc.h): int fn(void *user, double *device_buf, size_t n, svmc_stream_t stream)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 _lock = threading.Lock()
 _lib = None
@@ -108,8 +111,10 @@ def _declare(L: C.CDLL) -> None:
         "svmc_rccl_unique_id": ([vp, sz], i32),
         "svmc_rccl_comm_create": ([pvp, vp, sz, i32, i32], i32),
         "svmc_rccl_comm_destroy": ([vp], i32),
+        "svmc_rccl_comm_count": ([vp, pi32, pi32], i32),
         "svmc_rccl_all_reduce_sum": ([vp, vp, sz, vp], i32),
         "svmc_session_set_comm": ([vp, vp, i32, i32, u64, u64], i32),
+        "svmc_session_set_reducer": ([vp, ALL_REDUCE_FN, vp, i32, i32, u64, u64], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the .so does not match include/svmc.h
@@ -151,4 +156,6 @@ def check(rc: int) -> None:
         raise NotImplementedError(msg)
     if rc == ERR_INVALID_ARGUMENT:
         raise ValueError(msg)
+    if rc == ERR_RCCL:
+        raise SvmcError(f"RCCL: {msg}")
     raise SvmcError(f"svmc status {rc}: {msg}")

@@ -38,6 +38,10 @@ struct Session {
     // multi-GPU (svmc_session_set_comm): this session holds the paths [path_offset, path_offset + n_path) of a job of
     // n_total paths spread over `world` ranks; `comm` is the ncclComm_t the two reductions of a chain go through
     void *comm = nullptr;
+    // ... or a caller-supplied all-reduce (svmc_session_set_reducer): another transport than RCCL, or a test harness
+    svmc_all_reduce_fn reduce_fn = nullptr;
+    void *reduce_user = nullptr;
+    bool sharded() const { return comm != nullptr || reduce_fn != nullptr; }
     int rank = 0, world = 1;
     uint64_t n_total = 0, path_offset = 0;
     bool use_graphs = true;
@@ -160,7 +164,7 @@ static int enqueue_payoff_sums_of_set(Session *s, const ChainView &c, int variab
 static int finalize_prices(const Session *s, const ChainView &c, const double *sums, const std::vector<double> &shifts,
                            double *prices, double *stderrs)
 {
-    const double n_all = static_cast<double>(s->comm != nullptr ? s->n_total : s->n_path);
+    const double n_all = static_cast<double>(s->sharded() ? s->n_total : s->n_path);
     for (int i = 0; i < c.m; ++i) {
         const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
         if (int rc = svmc_payoff_finalize(sums + 3 * k0, shifts.data() + k0, k, c.discfactors[i], n_all, prices + k0,
@@ -175,7 +179,11 @@ static int finalize_prices(const Session *s, const ChainView &c, const double *s
 // expiry (utils/mc_payoffs.py:61-63), phase 3' = [sum d, sum d^2, count] per strike (:85-86).  No-ops without a comm.
 static int all_reduce(Session *s, double *buf, size_t n)
 {
-    if (s->comm == nullptr || n == 0) return SVMC_OK;
+    if (!s->sharded() || n == 0) return SVMC_OK;
+    if (s->reduce_fn != nullptr) {
+        const int rc = s->reduce_fn(s->reduce_user, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
+        return rc == SVMC_OK ? SVMC_OK : fail(rc, "the session's all-reduce callback failed");
+    }
     return svmc_rccl_all_reduce_sum(s->comm, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
 }
 
@@ -238,6 +246,8 @@ int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int rank, in
 {
     Session *s = reinterpret_cast<Session *>(session);
     SVMC_REQUIRE(s != nullptr, "svmc_session_set_comm: null session");
+    s->reduce_fn = nullptr;
+    s->reduce_user = nullptr;
     if (comm == nullptr) {                     // back to a single-GPU session
         s->comm = nullptr;
         s->rank = 0;
@@ -249,6 +259,24 @@ int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int rank, in
     SVMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "svmc_session_set_comm: need 0 <= rank < world");
     SVMC_REQUIRE(path_offset + s->n_path <= n_path_total, "svmc_session_set_comm: the session's paths exceed the job");
     s->comm = comm;
+    s->rank = rank;
+    s->world = world;
+    s->n_total = n_path_total;
+    s->path_offset = path_offset;
+    return SVMC_OK;
+}
+
+int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn fn, void *user, int rank, int world,
+                             uint64_t n_path_total, uint64_t path_offset)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr, "svmc_session_set_reducer: null session");
+    if (fn == nullptr) return svmc_session_set_comm(session, nullptr, 0, 1, 0, 0);
+    SVMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "svmc_session_set_reducer: need 0 <= rank < world");
+    SVMC_REQUIRE(path_offset + s->n_path <= n_path_total, "svmc_session_set_reducer: the session's paths exceed the job");
+    s->comm = nullptr;
+    s->reduce_fn = fn;
+    s->reduce_user = user;
     s->rank = rank;
     s->world = world;
     s->n_total = n_path_total;
@@ -341,7 +369,7 @@ int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_h
     if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
     SVMC_REQUIRE(W0s && W1s && nb_steps_host && dts_host, "svmc_logsv_chain_price_fixed: null randoms / grids");
     const size_t n = s->n_path;
-    if (s->use_graphs && s->comm == nullptr) {
+    if (s->use_graphs && !s->sharded()) {
         // ---- replay path: the launch structure is captured once per (chain, randoms) and replayed per parameter set
         std::vector<unsigned char> key;
         const int want_iv = (ivols_host != nullptr && variable_type == SVMC_LOG_RETURN) ? 1 : 0;
@@ -477,7 +505,7 @@ int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms
     const size_t K = c.offsets[c.m], row = 6 + static_cast<size_t>(c.m);          // doubles per parameter set
     // the routes without a multi-set graph (one set, more sets than a launch takes, graphs off, a communicator attached, a
     // session not sized for n_sets chains): the sets one after the other through the single-set entry -- the same numbers
-    const bool batched = s->use_graphs && s->comm == nullptr && n_sets >= 2 && n_sets <= MAX_FUSED_SETS && c.m <= MAX_FUSED_SLICES &&
+    const bool batched = s->use_graphs && !s->sharded() && n_sets >= 2 && n_sets <= MAX_FUSED_SETS && c.m <= MAX_FUSED_SLICES &&
                          c.m * n_sets <= s->max_expiries && K * static_cast<size_t>(n_sets) <= s->max_strikes &&
                          ((s->n_path + 255) / 256) * 2 * static_cast<size_t>(c.m) * n_sets * sizeof(double) <= s->ws_bytes;
     if (!batched) {

@@ -15,7 +15,18 @@
 #include <cstring>
 #include <mutex>
 
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// RCCL is resolved at run time: on a build box without its headers, the handful of public types this file uses
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+}
+#endif
 
 #include "svmc_internal.h"
 
@@ -129,6 +140,20 @@ int svmc_rccl_all_reduce_sum(svmc_comm_t comm, double *buf, size_t n, svmc_strea
     const ncclResult_t r = rccl().all_reduce(buf, buf, n, ncclDouble, ncclSum, reinterpret_cast<ncclComm_t>(comm),
                                              as_stream(stream));
     if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    return SVMC_OK;
+}
+
+int svmc_rccl_comm_count(svmc_comm_t comm, int *world_out, int *rank_out)
+{
+    SVMC_REQUIRE(comm != nullptr && world_out != nullptr, "svmc_rccl_comm_count: null communicator / output");
+    if (!rccl().ok) return fail(SVMC_ERR_RCCL, rccl().error);
+    if (rccl().comm_count == nullptr) return fail(SVMC_ERR_RCCL, "RCCL (" + rccl().origin + ") lacks ncclCommCount");
+    ncclResult_t r = rccl().comm_count(reinterpret_cast<ncclComm_t>(comm), world_out);
+    if (r != ncclSuccess) return rccl_fail("ncclCommCount", r);
+    if (rank_out != nullptr && rccl().comm_user_rank != nullptr) {
+        r = rccl().comm_user_rank(reinterpret_cast<ncclComm_t>(comm), rank_out);
+        if (r != ncclSuccess) return rccl_fail("ncclCommUserRank", r);
+    }
     return SVMC_OK;
 }
 

@@ -21,9 +21,12 @@ constexpr int BLOCK = 256;             // 4 waves of 64 lanes
 #endif
 constexpr int MAX_REDUCE_GRID = SVMC_MAX_REDUCE_GRID;  // 256 CUs x 4 blocks: cap for grid-stride reductions
 
-// block size of the on-device-RNG generators: 64 and 128 were measured and are not faster than 256 (4.08 / 4.31 /
-// 4.06 ms on C2), so the tail of the launch is not a block-granularity effect
-static constexpr int rng_block() { return BLOCK; }
+// block size of the on-device-RNG generators: a block stages the draw's tables in LDS once for all of its waves
+#ifndef SVMC_RNG_BLOCK
+#define SVMC_RNG_BLOCK 512
+#endif
+constexpr int RNG_BLOCK = SVMC_RNG_BLOCK;
+static constexpr int rng_block() { return RNG_BLOCK; }
 #ifndef SVMC_RNG_SGPRS
 #define SVMC_RNG_SGPRS 72              // SGPR budget of the LogSV stepping kernels (tools/ubench/ab_kernels.py sweeps it)
 #endif
@@ -44,14 +47,14 @@ __global__ __launch_bounds__(BLOCK) void fill_state_kernel(double *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void fill_normals_kernel(double *__restrict__ W0, double *__restrict__ W1,
+__global__ __launch_bounds__(RNG_BLOCK) void fill_normals_kernel(double *__restrict__ W0, double *__restrict__ W1,
                                                              size_t ldw, size_t n, int nb_steps, uint64_t seed,
                                                              uint32_t c3, uint64_t path_offset,
                                                              uint32_t step_offset)
 {
     __shared__ RngTablesLds s_tab;
     const RngTables tab = stage_rng_tables(s_tab);
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * RNG_BLOCK + threadIdx.x;
     if (p >= n) return;
     const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
     size_t row = p;
@@ -184,7 +187,7 @@ struct SliceOut {
 
 __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, bool active, double xv, double q)
 {
-    __shared__ double lds[8];
+    __shared__ double lds[2 * 16];                         // two values per wave, up to 16 waves per block
     if (active) {
         if (so.x_snap != nullptr) so.x_snap[p] = xv;
         if (so.q_snap != nullptr) so.q_snap[p] = q;
@@ -197,10 +200,7 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
     }
 }
 
-// DRIFT_IN_Z1: the per-step drift constant rides on the second normal (svmc_models.h logsv_fold_drift; every model with
-// volvol != 0), one VALU instruction per step less; false is the volvol = 0 instantiation.
-template <bool DRIFT_IN_Z1>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
+__global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so)
@@ -216,15 +216,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), am
         xv = x[p];
         s = sigma[p];
         q = qvar[p];
-        double L = log(s) * LOG_UNITS_PER_NAT;                                                  // :1039
+        double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
         double s2 = s * s, acc = 0.0, xacc = 0.0;
         const double s2_start = s2;
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
         const int quarter = (nb_steps + 3) >> 2;
         int stage = 0, next_stage_t = 0;
         rng_time_loop(
-            lane, step_offset, nb_steps, tab, c.z1_shift,
-            [&](double z0, double z1) { logsv_step_acc<DRIFT_IN_Z1>(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
+            lane, step_offset, nb_steps, tab,
+            [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
             [&](int t) {
                 if (t >= next_stage_t) {                   // wave-uniform
                     progress_priority(stage++);
@@ -255,55 +255,88 @@ struct ChainSlices {
 #ifndef SVMC_CHAIN_WAVES
 #define SVMC_CHAIN_WAVES 8, 8          // A/B hook: residency of the whole-chain kernel (7, 8 lifts the 64-VGPR cap)
 #endif
-template <bool DRIFT_IN_Z1>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAIN_WAVES), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_chain_rng_kernel(
+// The whole-chain kernel runs 1024-thread blocks: two blocks per CU share the CU's LDS, which leaves room -- beside the
+// draw's 32 KB table -- to PARK each path's x and qvar (16 KB per block) while the time loop runs.  They are dead inside
+// the loop (the loop advances the accumulators, logsv_fold_acc folds them in at the slice's end) but live across it, and
+// in registers they pushed the kernel over the 64 VGPRs that eight waves per SIMD allow: the round-2 kernel spilled 68
+// bytes per lane to scratch at every slice boundary (2.4 x its algorithmic HBM traffic).  Now: no scratch.
+#ifndef SVMC_CHAIN_BLOCK
+#define SVMC_CHAIN_BLOCK 1024
+#endif
+#ifndef SVMC_CHAIN_SGPRS
+#define SVMC_CHAIN_SGPRS 80            // the slice loop's scalars on top of the stepping loop's; 80 still admits 8 waves per SIMD
+#endif
+constexpr int CHAIN_BLOCK = SVMC_CHAIN_BLOCK;
+static inline unsigned chain_grid(size_t n) { return static_cast<unsigned>((n + CHAIN_BLOCK - 1) / CHAIN_BLOCK); }
+
+__global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAIN_WAVES), amdgpu_num_sgpr(SVMC_CHAIN_SGPRS))) void logsv_chain_rng_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
+    __shared__ double s_park[2 * CHAIN_BLOCK];             // [0, B): x, [B, 2B): qvar -- lane t owns elements t and B + t
     const RngTables tab = stage_tables(s_tab, s_exp);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
-    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool active = p < n;
-    double xv = 0.0, s = 1.0, q = 0.0;
-    if (active) {
-        xv = x[p];
-        s = sigma[p];
-        q = qvar[p];
+    // the path index is re-derived from threadIdx.x wherever it is needed (opaque to CSE): one VGPR across the time loop
+    // instead of the 64-bit index and the addresses formed from it
+    const auto path_index = [&]() {
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return static_cast<size_t>(blockIdx.x) * CHAIN_BLOCK + t;
+    };
+    const bool active = path_index() < n;
+    double s = 1.0;
+    {
+        double xv = 0.0, q = 0.0;
+        if (active) {
+            const size_t p = path_index();
+            xv = x[p];
+            s = sigma[p];
+            q = qvar[p];
+        }
+        s_park[threadIdx.x] = xv;
+        s_park[CHAIN_BLOCK + threadIdx.x] = q;
     }
-    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
+    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + path_index());
     const int quarter = (cs.total_steps + 3) >> 2;
     int stage = 0, next_stage_t = 0, tg = 0;
     for (int i = 0; i < cs.m; ++i) {
         const int nb = cs.nb_steps[i];
-        if (active) {
+        double xv = 0.0, q = 0.0;
+        {   // every lane steps, the lanes past the last path on a dummy state: inside `if (active)` the progress counters
+            // would be divergent values (vector registers, exec-masked branches in the time loop)
             const LogsvFast c = cs.c[i];
-            double L = log(s) * LOG_UNITS_PER_NAT;                                              // :1039
+            double L = log_state(s) * LOG_UNITS_PER_NAT;                                              // :1039
             double s2 = s * s, acc = 0.0, xacc = 0.0;
             const double s2_start = s2;
             rng_time_loop(
-                lane, step_offset + static_cast<uint32_t>(tg), nb, tab, c.z1_shift,
-                [&](double z0, double z1) { logsv_step_acc<DRIFT_IN_Z1>(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
+                lane, step_offset + static_cast<uint32_t>(tg), nb, tab,
+                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
                 [&](int t) {
                     if (tg + t >= next_stage_t) {          // wave-uniform
                         progress_priority(stage++);
                         next_stage_t += quarter;
                     }
                 });
+            xv = s_park[threadIdx.x];                      // a lane reads back what it alone wrote: no barrier needed
+            q = s_park[CHAIN_BLOCK + threadIdx.x];
             logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s * s);
+            s_park[threadIdx.x] = xv;
+            s_park[CHAIN_BLOCK + threadIdx.x] = q;
         }
         tg += nb;
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
                              partials + 2 * i, cs.forward[i], 2 * cs.m};
-        slice_epilogue(so, p, active, xv, q);
+        slice_epilogue(so, path_index(), active, xv, q);
         __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
     }
     if (active) {
-        x[p] = xv;
+        const size_t p = path_index();
+        x[p] = s_park[threadIdx.x];
         sigma[p] = s;
-        qvar[p] = q;
+        qvar[p] = s_park[CHAIN_BLOCK + threadIdx.x];
     }
 }
 
@@ -540,17 +573,17 @@ __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__re
 
 // Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
 template <bool RNG>
-__global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n,
+__global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n,
                                                                 int nb_steps, double dt, double v0, double k1theta,
                                                                 double kappa1, double kappa2, double theta, double adj,
                                                                 double half_vartheta2, double vartheta,
                                                                 const double *__restrict__ brownians, size_t ldb,
                                                                 uint64_t seed, uint32_t c3, uint64_t path_offset)
 {
-    __shared__ RngTablesLds s_tab;
+    __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
-    const RngTables tab = stage_tables(s_tab, s_exp);
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const RngTables tab = stage_tables_if(s_tab, s_exp);
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= n) return;
     double s = v0, L = log(v0);
     sigma_t[p] = s;                                                                             // :937
@@ -564,16 +597,16 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
         out += ld;
     };
     if (RNG) {
-        // one Brownian per step: normal t is component t & 1 of pair (t >> 1) & 1 of call t >> 2 (stream 2) -- a Philox
-        // call and two Box-Muller pairs serve four steps, so the loop runs call by call with no per-step selects
+        // one Brownian per step: normal t is the inversion of word t & 3 of call t >> 2 (stream 2) -- a Philox call
+        // serves four steps, so the loop runs call by call with no per-step selects
         const PhiloxLane lane = philox_prepare(seed, c3 | 2u, path_offset + p);
         uint32_t r[4];
         double a0, a1, b0, b1;
         int t = 0;
         for (; t + 4 <= nb_steps; t += 4) {
             philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
-            normals_from_words(r[0], r[1], tab, 0.0, a0, a1);
-            normals_from_words(r[2], r[3], tab, 0.0, b0, b1);
+            normals_from_words(r[0], r[1], tab, a0, a1);
+            normals_from_words(r[2], r[3], tab, b0, b1);
             step(sdt * a0);
             step(sdt * a1);
             step(sdt * b0);
@@ -581,11 +614,11 @@ __global__ __launch_bounds__(BLOCK) void logsv_vol_paths_kernel(double *__restri
         }
         if (t < nb_steps) {                                // the last, partial call (wave-uniform)
             philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
-            normals_from_words(r[0], r[1], tab, 0.0, a0, a1);
+            normals_from_words(r[0], r[1], tab, a0, a1);
             step(sdt * a0);
             if (t + 1 < nb_steps) step(sdt * a1);
             if (t + 2 < nb_steps) {
-                normals_from_words(r[2], r[3], tab, 0.0, b0, b1);
+                normals_from_words(r[2], r[3], tab, b0, b1);
                 step(sdt * b0);
             }
         }
@@ -691,18 +724,18 @@ __device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N],
 
 // RNG = false: Z0/Z1 supplied (the reference's only interface for this model); true: counter-based draw
 template <int N, bool RNG>
-__global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__ log_s, double *__restrict__ vol,
+__global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_kernel(double *__restrict__ log_s, double *__restrict__ vol,
                                                             double *__restrict__ yq, size_t n, int nb_steps,
                                                             RoughConsts c, const double *__restrict__ Z0,
                                                             const double *__restrict__ Z1, size_t ldw, uint64_t seed,
                                                             uint32_t c3, uint64_t path_offset, uint32_t step_offset,
                                                             int from_origin, SliceOut so)
 {
-    __shared__ RngTablesLds s_tab;
+    __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
-    const RngTables tab = stage_tables(s_tab, s_exp);
+    const RngTables tab = stage_tables_if(s_tab, s_exp);
     const auto exp_of = [&](double a) { return exp_tab(a, s_exp); };
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double ls = 0.0, y = 0.0;
     if (active) {
@@ -740,14 +773,17 @@ __global__ __launch_bounds__(BLOCK) void rough_logsv_kernel(double *__restrict__
 #define SVMC_HESTON_ATTR               // A/B hook (tools/ubench/build_variants.sh): e.g. __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 template <int SCHEME>
-__global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
                                                            double *__restrict__ qvar, size_t n, int nb_steps,
                                                            HestonConsts c, QeConsts qc, uint64_t seed,
                                                            uint32_t c3, uint64_t path_offset,
                                                            uint32_t step_offset, SliceOut so)
 {
     __shared__ RngTablesLds s_tab;
-    const RngTables tab = stage_rng_tables(s_tab);
+    __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
+    RngTables tab;
+    if constexpr (SCHEME == SVMC_HESTON_QE) tab = stage_rng_log_tables(s_tab, s_log);
+    else tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
@@ -793,7 +829,7 @@ struct HestonChainSlices {
 };
 
 template <int SCHEME>
-__global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
                                                                  double *__restrict__ qvar, size_t n,
                                                                  HestonChainSlices cs, uint64_t seed, uint32_t c3,
                                                                  uint64_t path_offset, uint32_t step_offset,
@@ -801,7 +837,10 @@ __global__ __launch_bounds__(BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kerne
                                                                  double *__restrict__ partials)
 {
     __shared__ RngTablesLds s_tab;
-    const RngTables tab = stage_rng_tables(s_tab);
+    __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
+    RngTables tab;
+    if constexpr (SCHEME == SVMC_HESTON_QE) tab = stage_rng_log_tables(s_tab, s_log);
+    else tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
@@ -1118,7 +1157,7 @@ int svmc_fill_normals(double *W0, double *W1, size_t ldw, size_t n_path, int nb_
     SVMC_REQUIRE(ldw >= n_path && nb_steps >= 0, "svmc_fill_normals: ldw < n_path or nb_steps < 0");
     SVMC_REQUIRE(call_id < (1u << 24), "svmc_fill_normals: call_id must fit 24 bits");
     if (n_path == 0 || nb_steps == 0) return SVMC_OK;
-    hipLaunchKernelGGL(fill_normals_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream), W0, W1, ldw,
+    hipLaunchKernelGGL(fill_normals_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), W0, W1, ldw,
                        n_path, nb_steps, seed, make_c3(call_id), path_offset, step_offset);
     return check_launch("svmc_fill_normals");
 }
@@ -1145,22 +1184,16 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (n_path == 0) return SVMC_OK;
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
-    if (logsv_fold_drift(c))
-        hipLaunchKernelGGL(logsv_rng_kernel<true>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x,
-                           sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
-    else
-        hipLaunchKernelGGL(logsv_rng_kernel<false>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x,
-                           sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
+    hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
+                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
     return check_launch(fn);
 }
 
 // the [grid][2] spot partials of a fused slice kernel -> spot_sums[2]
-static int finish_slice_sums(const char *fn, size_t n_path, double *spot_sums, void *workspace, size_t workspace_bytes,
-                             svmc_stream_t stream)
+static int finish_slice_sums(const char *fn, unsigned block_rows, double *spot_sums, void *workspace, svmc_stream_t stream)
 {
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
-                       static_cast<const double *>(workspace), static_cast<int>(rng_grid(n_path)), 2, spot_sums);
-    (void)workspace_bytes;
+                       static_cast<const double *>(workspace), static_cast<int>(block_rows), 2, spot_sums);
     return check_launch(fn);
 }
 
@@ -1169,7 +1202,7 @@ static int check_slice_args(const char *fn, size_t n_path, const double *x_snaps
 {
     if (x_snapshot == nullptr || spot_sums == nullptr || workspace == nullptr)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot / spot_sums / workspace");
-    if (workspace_bytes < static_cast<size_t>(rng_grid(n_path)) * 2 * sizeof(double))
+    if (workspace_bytes < static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double))     // the finer of the two grids
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
     return SVMC_OK;
 }
@@ -1198,7 +1231,7 @@ int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                   vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream))
         return rc;
-    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+    return finish_slice_sums(fn, rng_grid(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
@@ -1215,33 +1248,25 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     SVMC_REQUIRE(n_path > 0, "svmc_logsv_chain_rng: n_path must be positive");
     for (int i = 0; i < n_slices; ++i)
         SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, "svmc_logsv_chain_rng: nb_steps and dt must be positive");
-    const unsigned g = rng_grid(n_path);
+    const unsigned g = chain_grid(n_path);
     for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
         ChainSlices cs;
         cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
         if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
             return fail(SVMC_ERR_WORKSPACE, "svmc_logsv_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
         cs.total_steps = 0;
-        bool fold = false;                                 // volvol != 0: the same answer for every slice
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
             const int j = (i < cs.m) ? i0 + i : i0;        // unused entries repeat a valid one
             cs.c[i] = logsv_fast_in_log_units(make_logsv_fast(make_logsv_consts(
                 dts_host[j], theta, kappa1, kappa2, beta, volvol, etas_host ? etas_host[j] : 1.0, is_spot_measure)));
-            fold = logsv_fold_drift(cs.c[i]);
             cs.forward[i] = forwards_host[j];
             cs.nb_steps[i] = (i < cs.m) ? nb_steps_host[j] : 0;
             cs.total_steps += cs.nb_steps[i];
         }
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
-        if (fold)
-            hipLaunchKernelGGL(logsv_chain_rng_kernel<true>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
-                               static_cast<double *>(workspace));
-        else
-            hipLaunchKernelGGL(logsv_chain_rng_kernel<false>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
-                               static_cast<double *>(workspace));
+        hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
+                           cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace));
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
@@ -1288,7 +1313,7 @@ int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, in
     if (int rc = logsv_w_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                 vol_backbone_eta, is_spot_measure, W0, W1, ldw, so, stream))
         return rc;
-    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+    return finish_slice_sums(fn, grid_for(n_path), spot_sums, workspace, stream);
 }
 
 }  // extern "C"
@@ -1317,7 +1342,7 @@ int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
     hipLaunchKernelGGL(logsv_w_indirect_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, stream, x, sigma, qvar, n_path,
                        nb_steps, reinterpret_cast<const LogsvConsts *>(consts_dev), W0, W1, ldw, so);
     if (int rc = check_launch(fn)) return rc;
-    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, reinterpret_cast<svmc_stream_t>(stream));
+    return finish_slice_sums(fn, grid_for(n_path), spot_sums, workspace, reinterpret_cast<svmc_stream_t>(stream));
 }
 
 // every expiry of a chain on resident randoms in one launch + one column reduce (graph-replayed driver, svmc_chain.hip):
@@ -1458,7 +1483,7 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
                            sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
                            0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
     else
-        hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
+        hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream),
                            sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
                            0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
     return check_launch("svmc_logsv_vol_paths");
@@ -1509,7 +1534,7 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
     if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
                                    call_id, path_offset, step_offset, so, stream))
         return rc;
-    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+    return finish_slice_sums(fn, rng_grid(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
@@ -1592,7 +1617,8 @@ static int rough_logsv_launch(const char *name, double *log_s, double *vol, doub
     c.inv_h = 1.0 / h;
     c.ito = -0.5 * c.volvol_w * c.volvol_w * h;
     c.volvol_w_sqrt_h = c.volvol_w * c.sqrt_h;
-    const dim3 g(grid_for(n_path)), b(BLOCK);
+    const bool draw = Z0 == nullptr;                        // the drawing kernels run the generators' block size
+    const dim3 g(draw ? rng_grid(n_path) : grid_for(n_path)), b(draw ? rng_block() : BLOCK);
     const hipStream_t st = as_stream(stream);
     const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals
 #define SVMC_ROUGH_LAUNCH(NF)                                                                                          \
@@ -1640,7 +1666,7 @@ int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, size_t n_pa
                                     v0_host, theta, kappa1, kappa2, rho, volvol, Z0, Z1, ldw, seed, call_id,
                                     path_offset, step_offset, from_origin, so, stream))
         return rc;
-    return finish_slice_sums(fn, n_path, spot_sums, workspace, workspace_bytes, stream);
+    return finish_slice_sums(fn, (Z0 == nullptr) ? rng_grid(n_path) : grid_for(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -1681,7 +1707,7 @@ int svmc_payoff_workspace_bytes(size_t *bytes)
 int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
-    const size_t fused = static_cast<size_t>(rng_grid(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
+    const size_t fused = static_cast<size_t>(grid_for(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
     const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;

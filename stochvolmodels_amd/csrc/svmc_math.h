@@ -5,10 +5,11 @@
 // (tools/ubench/ablate.hip).  The versions below do the same fp64 arithmetic with ~2.5x fewer
 // instructions by using what this path knows about its arguments:
 //   neg_log(u)      u > 0 normal                 -> no denormal/negative/NaN handling, integer frexp
-//   neg_log_tab     same, 512-entry table        -> no reciprocal, cubic tail (the RNG's radius)
+//   neg_log_tab     same, 512-entry table        -> no reciprocal, cubic tail (Heston QE's martingale correction)
+//   log_state(s)    any s >= 0, inf, NaN         -> ln(sigma) at slice starts, constants in scalar registers
 //   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
-//   sqrt_pos_1g     same, Goldschmidt step only  -> 2^-47 (the RNG's radius)
-//   cossin_circle_tab32  a raw 32-bit angle   -> no range reduction, no quadrant logic, 256-entry table
+//   sqrt_pos_1g     same, Goldschmidt step only  -> 2^-47 (Heston's sqrt(v))
+//   normal_icdf32   a raw 32-bit word            -> N(0,1) by a piecewise cubic of the inverse CDF, 512-segment table
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
 //   exp_tab(x)      log-volatilities             -> 256-entry table, quadratic tail, one reduction constant
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup
@@ -232,6 +233,12 @@ SVMC_HD double exp2u_tab(double y, const double *tab)
 // f = m - 1, s = f/(2+f), ln(1+f) = f - (f^2/2 - s (f^2/2 + R)), R = s^2 G(s^2)   (Cody-Waite / fdlibm form)
 SVMC_HD double neg_log(double u)
 {
+#if defined(__clang__)
+    // no implicit contraction: which of the products below the compiler would fuse with a following add depends on the code
+    // around the (inlined) call, and the generators that take ln(sigma) at slice starts -- one launch per slice, or the whole
+    // chain in one launch -- must produce the same bits
+#pragma clang fp contract(off)
+#endif
     uint32_t hx = double_hi(u);
     hx += 0x3ff00000u - 0x3fe6a09eu;
     const int k = static_cast<int>(hx >> 20) - 0x3ff;
@@ -254,6 +261,23 @@ SVMC_HD double neg_log(double u)
     const double lg = f - t2;                        // ln(m)
     const double a = fma(dk, 0x1.a39ef35793c76p-33, lg);
     return fma(-dk, 0x1.62e42fee00000p-1, -a);      // -(k ln2 + ln m)
+}
+
+// ln(s) of a state variable: any s >= 0 including denormals, 0 (-> -inf), +inf (-> +inf) and NaN / negative (-> NaN).
+// The generators take ln(sigma) at every slice start; the device libm's log keeps its constants in vector registers, which
+// the compiler hoists out of the whole-chain kernel's slice loop and then spills across the time loop -- neg_log() takes
+// its constants as scalar operands.  <= 4 ULP (tests/test_math_accuracy.py).
+SVMC_HD double log_state(double s)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const bool tiny = s < 0x1.0p-1000;
+    double r = -neg_log(tiny ? s * 0x1.0p+512 : s);
+    r = tiny ? fma(-512.0, 0x1.62e42fefa39efp-1, r) : r;
+    r = (s == __builtin_huge_val()) ? __builtin_huge_val() : r;
+    r = (s == 0.0) ? -__builtin_huge_val() : r;
+    return (s >= 0.0) ? r : __builtin_nan("");
 }
 
 // Table-assisted -ln(u), any positive normal u: the top 9 bits of the [sqrt(1/2), sqrt(2)) mantissa pick
@@ -288,39 +312,58 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
     return fma(-dk, 0x1.62e42fefa39efp-1, nl);
 }
 
-struct alignas(32) CircleTabEntry {
-    double a, b;      // sqrt2 (cos, sin) at the interval midpoint
-    double c;         // the midpoint in units of 2^-32 turns: j 2^24 + 2^23 - 1/2
-    double pad;
+// One N(0,1) variate from ONE 32-bit word by inversion (random stream version 3, tools/gen_icdf_table.py): the word is
+// read as a signed integer k, t = k + 1/2 is symmetric about 0 and never 0, and
+//     z = sign(t) P_j(|t| - c_j)   ~   sign(t) * -Phi^-1(|t| 2^-32),      |z| <= 6.34
+// with P_j the segment's cubic.  The segment index is read off the high word of t -- five exponent bits and the top
+// SVMC_ICDF_M mantissa bits: 32 octaves x 2^M equal parts, i.e. geometric spacing towards the tail where Phi^-1 is singular
+// -- by one shift and one mask that leave the BYTE offset of the segment's 16-byte pieces; the pieces sit in arrays one
+// after the other so that one address serves all the ds_read_b128 (LDS pipe, beside the VALU stream).
+//   EDGE form (the committed table): c_j = the segment's lower edge = |t| with the mantissa below the segment bits
+//   cleared (a v_and_b32 on the high word over a zero low word), pieces {a0, a1}, {a2, a3}: 10 VALU instructions -- cvt,
+//   add, shift, and, and, subtract (the modulus is an operand modifier), three FMAs, v_bfi_b32 for the sign -- and 32 table
+//   bytes per normal, where the Box-Muller pair of stream version 2 took 19 instructions per normal.
+//   Midpoint form: c_j from the table, pieces {c, a0}, {a1, a2}, {a3, a4}: 9 instructions but 40 table bytes -- measured
+//   LDS-bound (the LDS pipe 95 % busy, 61 % of it bank conflicts of the randomly indexed reads) and no faster.
+// This evaluation order IS the stream's definition: the CPU twin (oracle/svmc_oracle.c svo_normal_from_word) evaluates the
+// same expression.
+struct alignas(16) IcdfPiece {
+    double a, b;
 };
 
-// The direction of a Box-Muller pair from ONE 32-bit word (stream version 2): the word IS the angle,
-// t = 2 pi (w + 1/2) 2^-32 on the full circle -- no sign bits, no quadrant logic.  w[31:24] picks one of 256 intervals
-// with midpoint t_j = 2 pi (j + 1/2)/256; D = w - (j 2^24 + 2^23 - 1/2) = cvt(w) - center[j] is the offset from it in
-// units of 2^-32 turns, an exact double with |D| < 2^23, and with y = (2 pi 2^-32) D, |y| <= 0.01227:
-//     a = sqrt2 cos t = A_j cos y - B_j sin y,    b = sqrt2 sin t = B_j cos y + A_j sin y,
-// {A_j, B_j, c_j} = {sqrt2 cos t_j, sqrt2 sin t_j, the midpoint} from one 256-entry table of 32-byte entries (8 KB, LDS on
-// the device: a ds_read_b128 and a ds_read_b64 off ONE address, beside the VALU stream).  sin y: three Taylor terms (next: 8e-18 absolute); cos y:
-// four (next: 1e-20); the 2 pi 2^-32 scale lives in the coefficients.  12 VALU instructions + the index.
-// Absolute accuracy 5e-16 on values up to sqrt2.
-SVMC_HD void cossin_circle_tab32(uint32_t w, const CircleTabEntry *tab, double &a, double &b)
+template <int M, int SEGMENTS, int DEG, bool EDGE = false>
+SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(w));                    // a plain register value (see cossin_diag_tab)
-#endif
-    const CircleTabEntry &e = tab[w >> 24];
-    const double D = static_cast<double>(w) - e.c;
-    const double z = D * D;
-    double ps = 0x1.466bc6775aae2p-154;            //  (2 pi 2^-32)^5 / 120
-    ps = fma_k(ps, z, -0x1.4abbce625be53p-91);     // -(2 pi 2^-32)^3 / 6
-    ps = fma_k(ps, z, 0x1.921fb54442d18p-30);      //   2 pi 2^-32
-    const double sn = D * ps;                      // sin y
-    double pc = -0x1.55d3c7e3cbffap-186;           // -(2 pi 2^-32)^6 / 720
-    pc = fma_k(pc, z, 0x1.03c1f081b5ac4p-122);     //  (2 pi 2^-32)^4 / 24
-    pc = fma_k(pc, z, -0x1.3bd3cc9be45dep-60);     // -(2 pi 2^-32)^2 / 2
-    const double cs = fma_k(pc, z, 1.0);           // cos y
-    a = fma(-e.b, sn, e.a * cs);
-    b = fma(e.a, sn, e.b * cs);
+    const double t = static_cast<double>(static_cast<int32_t>(w)) + 0.5;
+    const uint32_t hi = double_hi(t);
+    const uint32_t off = (hi >> (16 - M)) & ((static_cast<uint32_t>(SEGMENTS) - 1u) << 4);
+    const char *base = reinterpret_cast<const char *>(tab) + off;
+    const IcdfPiece e0 = *reinterpret_cast<const IcdfPiece *>(base);
+    const IcdfPiece e1 = *reinterpret_cast<const IcdfPiece *>(base + 16 * SEGMENTS);
+    double p;
+    if (EDGE) {
+        // pieces {a0, a1}, {a2, a3}: the polynomial runs in |t| - (the segment's lower edge), and the edge is |t| with the
+        // mantissa below the segment bits cleared -- one v_and_b32 on the high word instead of 8 table bytes
+        const double edge = bits_to_double(0u, hi & (0x7FFFFFFFu & ~((1u << (20 - M)) - 1u)));
+        const double d = fabs(t) - edge;
+        if (DEG == 4) {
+            const IcdfPiece e2 = *reinterpret_cast<const IcdfPiece *>(base + 32 * SEGMENTS);
+            p = fma(e2.a, d, e1.b);
+        } else {
+            p = e1.b;
+        }
+        p = fma(p, d, e1.a);
+        p = fma(p, d, e0.b);
+        p = fma(p, d, e0.a);
+    } else {
+        const IcdfPiece e2 = *reinterpret_cast<const IcdfPiece *>(base + 32 * SEGMENTS);
+        const double d = fabs(t) - e0.a;
+        p = (DEG == 4) ? fma(e2.b, d, e2.a) : e2.a;
+        p = fma(p, d, e1.b);
+        p = fma(p, d, e1.a);
+        p = fma(p, d, e0.b);
+    }
+    return copysign(p, t);
 }
 
 }  // namespace svmc

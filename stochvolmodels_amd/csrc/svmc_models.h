@@ -72,7 +72,6 @@ struct LogsvFast {
     double c3;    // (kappa2 theta - kappa1 - vartheta^2/2) dt
     double bs;    // beta sqrt(dt)
     double es;    // volvol sqrt(dt)
-    double z1_shift;  // accumulator-form kernels: c3 / es, added to the second normal by the draw itself (then c3 = 0)
 };
 
 inline LogsvFast make_logsv_fast(const LogsvConsts &c)
@@ -87,19 +86,7 @@ inline LogsvFast make_logsv_fast(const LogsvConsts &c)
     f.c3 = (c.kappa2 * c.theta - c.kappa1 - c.half_vartheta2) * c.dt;
     f.bs = c.beta * c.sdt;
     f.es = c.volvol * c.sdt;
-    f.z1_shift = 0.0;
     return f;
-}
-
-// The constant per-step drift c3 rides on the second normal: es (z1 + c3 / es) = es z1 + c3, with the shift added inside
-// the FMA that forms z1 (svmc_rng.h normals_from_words) -- one VALU instruction per step less.  volvol = 0 has no
-// second normal to carry it: c3 stays an explicit add there (logsv_step_acc<false>).
-inline bool logsv_fold_drift(LogsvFast &f)
-{
-    if (f.es == 0.0) return false;
-    f.z1_shift = f.c3 / f.es;
-    f.c3 = 0.0;
-    return true;
 }
 
 // The accumulator-form kernels carry L = ln(sigma) in units of ln2/256 (svmc_math.h exp2u_tab: exact reduction): the
@@ -113,7 +100,7 @@ inline LogsvFast logsv_fast_in_log_units(LogsvFast f)
     f.c3 *= LOG_UNITS_PER_NAT;
     f.bs *= LOG_UNITS_PER_NAT;
     f.es *= LOG_UNITS_PER_NAT;
-    return f;                                      // z1_shift = c3 / es is a ratio: unit-free
+    return f;
 }
 
 // z0, z1 are UNSCALED N(0,1); s2 = sigma^2 is carried; exp_of(L) is the exponential to use (exp_fast, or exp_tab with
@@ -147,7 +134,7 @@ __device__ __forceinline__ void logsv_step_fast(const LogsvFast &f, double &x, d
 //     qvar_T = qvar_0 + hA (2 acc + sigma_0^2 - sigma_T^2)                          [= hA sum (sigma_t^2 + sigma_{t+1}^2)]
 // and L is advanced by single FMAs (no constant has to be moved into a vector register): 9 arithmetic instructions
 // around the exp and the reciprocal instead of 12.  Identical in exact arithmetic; rounding differs at 1e-16.
-template <bool DRIFT_IN_Z1, class Exp>
+template <class Exp>
 __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc, double &L, double &sigma, double &s2,
                                                double &acc, double z0, double z1, Exp &&exp_of)
 {
@@ -156,7 +143,7 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc,
     xacc = fma(s, z0, xacc);                      // sum sigma_t z0_t; the factor B = eta sqrt(dt) is applied in the fold
     L = fma(f.c2, s, L);
     L = fma(f.c1, y, L);
-    if (!DRIFT_IN_Z1) L = L + f.c3;               // otherwise z1 arrives as z1 + c3 / es (logsv_fold_drift)
+    L = L + f.c3;
     L = fma(f.bs, z0, L);
     L = fma(f.es, z1, L);
     const double sn = exp_of(L);

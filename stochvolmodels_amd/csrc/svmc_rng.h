@@ -7,44 +7,56 @@
 // GPUs.  Replaces the reference's serial MT19937+polar draw of two [nb_steps, nb_path] arrays
 // (pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370).
 //
-// Stream definition, version 2 (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals).  One call yields
-// four 32-bit words = the Box-Muller pairs of TWO consecutive time steps:
+// Stream definition, version 3 (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals).  One call yields
+// four 32-bit words = the two normals of TWO consecutive time steps, each word turned into ONE N(0,1) variate by
+// inversion:
 //   (r0, r1, r2, r3) = philox4x32_7(ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8), key = seed)
 //   (ra, rb) = (r0, r1) for an even chain-global step index, (r2, r3) for an odd one
-//   u1 = (ra + 1/2) 2^-32                                   in (0,1), exact; R = sqrt(-ln u1) <= 4.78 (|z| <= 6.76)
-//   t  = 2 pi (rb + 1/2) 2^-32                              the angle, uniform on the full circle
-//   (w0, w1) = sqrt(-2 ln u1) (cos t, sin t) = R (sqrt2 cos t, sqrt2 sin t):  the Box-Muller pair
-//   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  Heston QE: pairs from stream 4 (as stream 0), the
+//   z(r) = sign(t) P_j(|t| - c_j),  t = (int32) r + 1/2:  the piecewise cubic of -Phi^-1(|t| 2^-32) of
+//          svmc_icdf_table.h (tools/gen_icdf_table.py; svmc_math.h normal_icdf32), |z| <= 6.34
+//   (w0, w1) = (z(ra), z(rb))
+//   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  Heston QE: normals from stream 4 (as stream 0), the
 //   exponential branch's uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2, drawn lazily.
-// Resolution: a pair carries 64 random bits (32 radius, 32 angle) where version 1 spent 128 -- the price of
-// halving the generator's share of the VALU-issue-bound stepping loop.  The radius is capped at sqrt(33 ln 2) = 4.78,
-// i.e. |z| <= 6.76: the truncated mass is 1.4e-11 per normal (about 30 draws in 2^41, none expected in one C2 call
-// of 2^31 normals); lattice spacings are 2^-32 in u1 and 2 pi 2^-32 in the angle -- far below the 1e-4 relative
-// Monte Carlo error of any chain priced here.
+// Resolution: a normal carries 32 random bits (as in version 2, whose Box-Muller pair spent 32 on the radius and 32 on
+// the angle); the lattice is 2^-32 in probability, symmetric about 0, largest |z| = -Phi^-1(2^-33) = 6.34 (truncated
+// mass 2.3e-10 per normal).  The cubic deviates from the exact inverse CDF by at most SVMC_ICDF_MAX_ABS_ERROR (1.1e-8)
+// -- a smooth deterministic distortion four orders below the Monte Carlo error of any chain priced here, pinned against
+// scipy's Phi^-1 in tests/test_oracle_golden.py.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef SVMC_ICDF_TABLE_HEADER          // A/B hook: another (M, degree) of tools/gen_icdf_table.py
+#include SVMC_ICDF_TABLE_HEADER
+#else
+#include "svmc_icdf_table.h"
+#endif
 #include "svmc_log_table.h"
 #include "svmc_math.h"
 
 namespace svmc {
 
-// The tables of the draw, constant memory -> LDS once per block: 8 KB for neg_log_tab() and 8 KB for
-// cossin_circle_tab32() (blocks are 256 threads: two + one entries per thread); the stepping kernels that call exp_tab() stage its 2 KB
-// with them behind the same barrier.
+// The tables, constant memory -> LDS once per block: the inverse-CDF pieces of the draw (SVMC_ICDF_SEGMENTS x 48 bytes,
+// three arrays of 16-byte pieces), the 2 KB exp table of the kernels that call exp2u_tab() / exp_tab(), and -- Heston QE
+// only -- the 8 KB log table of its martingale correction.
+#if SVMC_ICDF_EDGE && SVMC_ICDF_DEG == 3
+#define SVMC_ICDF_PIECES 2
+__constant__ IcdfPiece g_icdf_table[2 * SVMC_ICDF_SEGMENTS] = {SVMC_ICDF_PIECE0_INIT, SVMC_ICDF_PIECE1_INIT};
+#else
+#define SVMC_ICDF_PIECES 3
+__constant__ IcdfPiece g_icdf_table[3 * SVMC_ICDF_SEGMENTS] = {SVMC_ICDF_PIECE0_INIT, SVMC_ICDF_PIECE1_INIT, SVMC_ICDF_PIECE2_INIT};
+#endif
 __constant__ LogTabEntry g_log_table[512] = {SVMC_LOG_TABLE_INIT};
-__constant__ CircleTabEntry g_circle_table[256] = {SVMC_CIRCLE_TABLE_INIT};   // sqrt2 (cos, sin) and the midpoint of 256 intervals
 __constant__ double g_exp_table[256] = {SVMC_EXP_TABLE_INIT};
 
 struct RngTables {
-    const LogTabEntry *log;
-    const CircleTabEntry *circle;
+    const IcdfPiece *icdf;
+    const LogTabEntry *log;        // null unless the kernel staged it (stage_rng_log_tables)
 };
 
+constexpr unsigned ICDF_PIECES = SVMC_ICDF_PIECES;
 struct RngTablesLds {
-    LogTabEntry log[512];
-    CircleTabEntry circle[256];
+    IcdfPiece icdf[ICDF_PIECES * SVMC_ICDF_SEGMENTS];
 };
 
 // the log table alone (the streamed Heston QE kernel: its martingale correction takes logs, it draws nothing)
@@ -55,27 +67,53 @@ __device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)
     return lds;
 }
 
+__device__ __forceinline__ void copy_icdf_table(RngTablesLds &lds)
+{
+    for (unsigned i = threadIdx.x; i < ICDF_PIECES * SVMC_ICDF_SEGMENTS; i += blockDim.x) lds.icdf[i] = g_icdf_table[i];
+}
+
 __device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
 {
-    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
-        lds.log[i] = g_log_table[i];
-        lds.log[i + 256u] = g_log_table[i + 256u];
-        lds.circle[i] = g_circle_table[i];
-    }
+    copy_icdf_table(lds);
     __syncthreads();
-    return RngTables{lds.log, lds.circle};
+    return RngTables{lds.icdf, nullptr};
+}
+
+// Heston QE: the draw's table and the log table behind one barrier
+__device__ __forceinline__ RngTables stage_rng_log_tables(RngTablesLds &lds, LogTabEntry (&lds_log)[512])
+{
+    copy_icdf_table(lds);
+    for (unsigned i = threadIdx.x; i < 512u; i += blockDim.x) lds_log[i] = g_log_table[i];
+    __syncthreads();
+    return RngTables{lds.icdf, lds_log};
+}
+
+// a kernel template that draws in one instantiation and reads supplied normals in the other: the table's LDS only in the first
+template <bool DRAWS>
+struct RngTablesLdsIf {
+    RngTablesLds t;
+};
+template <>
+struct RngTablesLdsIf<false> {
+    char unused;
+};
+
+template <bool DRAWS>
+__device__ __forceinline__ RngTables stage_tables_if(RngTablesLdsIf<DRAWS> &lds, double (&lds_exp)[256])
+{
+    if constexpr (DRAWS) copy_icdf_table(lds.t);
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
+    __syncthreads();
+    if constexpr (DRAWS) return RngTables{lds.t.icdf, nullptr};
+    else return RngTables{nullptr, nullptr};
 }
 
 __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&lds_exp)[256])
 {
-    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
-        lds.log[i] = g_log_table[i];
-        lds.log[i + 256u] = g_log_table[i + 256u];
-        lds.circle[i] = g_circle_table[i];
-    }
+    copy_icdf_table(lds);
     for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) lds_exp[i] = g_exp_table[i];
     __syncthreads();
-    return RngTables{lds.log, lds.circle};
+    return RngTables{lds.icdf, nullptr};
 }
 
 #ifndef SVMC_PHILOX_ROUNDS
@@ -193,18 +231,11 @@ __device__ __forceinline__ double uniform_32(uint32_t k)
     return fma(static_cast<double>(k), 0x1.0p-32, 0x1.0p-33);
 }
 
-// One Box-Muller pair from two words: radius from ra, direction from rb.  `shift1` is added to
-// the second normal inside its final FMA (a model whose update has a constant term beside a multiple of z1 folds the
-// constant in here for free: LogSV's per-step drift constant); 0.0 gives the plain pair.
-__device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double shift1,
-                                                   double &w0, double &w1)
+// The two normals of a time step from two words, each by inversion (svmc_math.h normal_icdf32)
+__device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double &w0, double &w1)
 {
-    // u1 = (ra + 1/2) 2^-32: the half is an inline constant of the add and the 2^-32 an exponent offset of the logarithm
-    const double R = sqrt_pos_1g(neg_log_tab<-32>(static_cast<double>(ra) + 0.5, t.log));  // sqrt(-ln u1): the sqrt2 lives in (a, b)
-    double a, b;
-    cossin_circle_tab32(rb, t.circle, a, b);
-    w0 = R * a;
-    w1 = fma(R, b, shift1);
+    w0 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(ra, t.icdf);
+    w1 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(rb, t.icdf);
 }
 
 // The time loop of every on-device-RNG generator: time steps [0, nb) of a lane whose first step has the chain-global
@@ -215,7 +246,7 @@ __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, con
 // the local index of the call's first step in this range (the progress priorities).
 template <class Step, class Tick>
 __device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
-                                              double shift1, Step &&step, Tick &&tick)
+                                              Step &&step, Tick &&tick)
 {
     if (nb <= 0) return;
     const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
@@ -225,11 +256,11 @@ __device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t s
         philox_draw(lane, c, r);
         double z0, z1;
         if (2u * c >= first) {
-            normals_from_words(r[0], r[1], tab, shift1, z0, z1);
+            normals_from_words(r[0], r[1], tab, z0, z1);
             step(z0, z1);
         }
         if (2u * c + 1u <= last) {
-            normals_from_words(r[2], r[3], tab, shift1, z0, z1);
+            normals_from_words(r[2], r[3], tab, z0, z1);
             step(z0, z1);
         }
     }
@@ -239,21 +270,21 @@ template <class Step>
 __device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
                                               Step &&step)
 {
-    rng_time_loop(lane, step0, nb, tab, 0.0, step, [](int) {});
+    rng_time_loop(lane, step0, nb, tab, step, [](int) {});
 }
 
-// stream 0 for a single (path, step), from scratch: Box-Muller pair of UNSCALED N(0,1)  (svmc_fill_normals)
+// stream 0 for a single (path, step), from scratch: the step's two UNSCALED N(0,1)  (svmc_fill_normals)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
                                              const RngTables &t, double &w0, double &w1)
 {
     uint32_t r[4];
     philox_draw(seed, c3, path, step >> 1, r);
     const bool odd = (step & 1u) != 0u;
-    normals_from_words(odd ? r[2] : r[0], odd ? r[3] : r[1], t, 0.0, w0, w1);
+    normals_from_words(odd ? r[2] : r[0], odd ? r[3] : r[1], t, w0, w1);
 }
 
-// Heston QE (streams 4 and 5).  The scheme needs a pair every step (z0 for the log-price, z1 for the quadratic branch)
-// and a uniform only in the exponential branch: the pairs come from stream 4 exactly like stream 0's (one call per two
+// Heston QE (streams 4 and 5).  The scheme needs two normals every step (z0 for the log-price, z1 for the quadratic branch)
+// and a uniform only in the exponential branch: the normals come from stream 4 exactly like stream 0's (one call per two
 // steps, rng_time_loop), the uniforms from stream 5 -- word step & 3 of call step >> 2, i.e. one call per FOUR steps --
 // drawn LAZILY: only when some lane of the wave is in the exponential branch at that step (a wave-uniform decision, so
 // every lane of the wave takes part in the call and keeps its four words for the rest of the group).  A parameter set

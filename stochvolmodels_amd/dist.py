@@ -146,6 +146,15 @@ class RcclComm:
     def to_host(self, engine, ptr, handle, n: int):
         return engine.download(ptr, n)
 
+    def ranks_seen(self) -> int:
+        """ncclCommCount of the communicator: the number of ranks RCCL itself sees"""
+        n = self._C.c_int(0)
+        self._lib.check(self._lib.load().svmc_rccl_comm_count(self.handle, self._C.byref(n), None))
+        return int(n.value)
+
+    def origin(self) -> str:
+        return self._lib.load().svmc_rccl_origin().decode()
+
     def close(self) -> None:
         if self.handle is not None:
             self._lib.load().svmc_rccl_comm_destroy(self.handle)
@@ -209,6 +218,17 @@ def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
     tcomm = TorchComm()
     _share_rng_seed(tcomm)
     if comm == "rccl":
+        # bind this rank's GPU through libsvmc itself (torch may be a CPU-only build, or the bootstrap group gloo): RCCL
+        # needs one device per rank
+        import ctypes as C
+
+        from . import _lib
+        count = C.c_int(0)
+        _lib.check(_lib.load().svmc_device_count(C.byref(count)))
+        if tcomm.world > count.value and os.environ.get("SVMC_DIST_BACKEND") != "gloo":
+            raise _lib.SvmcError(f"comm='rccl': {tcomm.world} ranks but {count.value} GPU(s) visible -- RCCL needs one "
+                                 f"device per rank")
+        _lib.check(_lib.load().svmc_set_device(local_rank % max(count.value, 1)))
         box = [RcclComm.unique_id() if tcomm.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         set_default_comm(RcclComm(tcomm.rank, tcomm.world, box[0]))

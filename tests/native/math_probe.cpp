@@ -4,7 +4,8 @@
 #include "svmc_math.h"
 static const svmc::LogTabEntry LOG_TAB[512] = {SVMC_LOG_TABLE_INIT};
 static const double EXP_TAB[256] = {SVMC_EXP_TABLE_INIT};
-static const svmc::CircleTabEntry CIRCLE_TAB[256] = {SVMC_CIRCLE_TABLE_INIT};
+#include "svmc_icdf_table.h"
+static const svmc::IcdfPiece ICDF_TAB[2 * SVMC_ICDF_SEGMENTS] = {SVMC_ICDF_PIECE0_INIT, SVMC_ICDF_PIECE1_INIT};
 extern "C" {
 void probe_exp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_fast(x[i]); }
 void probe_exp_full(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::exp_full(x[i]); }
@@ -15,9 +16,11 @@ void probe_neg_log_tab(const double *x, double *y, size_t n) { for (size_t i = 0
 void probe_sqrt(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos(x[i]); }
 void probe_sqrt_1g(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::sqrt_pos_1g(x[i]); }
 void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::rcp_fast(x[i]); }
-// the table-assisted direction from one raw 32-bit angle word
-void probe_circle_tab32(const uint32_t *w, double *a, double *b, size_t n)
+// one normal from one raw 32-bit word (random stream version 3)
+void probe_normal_icdf32(const uint32_t *w, double *z, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) svmc::cossin_circle_tab32(w[i], CIRCLE_TAB, a[i], b[i]);
+    for (size_t i = 0; i < n; ++i)
+        z[i] = svmc::normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(w[i], ICDF_TAB);
 }
+void probe_log_state(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::log_state(x[i]); }
 }

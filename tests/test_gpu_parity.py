@@ -591,6 +591,128 @@ def test_two_rccl_ranks_on_one_gpu(oracle, tmp_path, route):
             np.testing.assert_array_equal(runs[0][key], runs[1][key], err_msg=key)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_chain_drivers_sharded_on_one_gpu(sv, world):
+    """The sharding logic of the fused C drivers with world > 1 (csrc/svmc_chain.hip: global path offsets into the
+    counter-based randoms, the two sum all-reduces between the kernels, the finalisation by the job's path count) --
+    RCCL refuses two ranks on one device, so the all-reduce is handed to the caller (svmc_session_set_reducer): `world`
+    sessions of THIS process, one thread each, hold the shards of an odd-sized job on the one GPU there is and sum their
+    reduction buffers through host memory.  Every rank must return the job's prices, equal to the unsharded session's to
+    reduction-order rounding, for svmc_logsv_chain_price (LOG_RETURN with inverse options, and Q_VAR) and
+    svmc_heston_chain_price (Euler and QE)."""
+    import ctypes as C
+    import threading
+    from stochvolmodels_amd import _lib
+    from stochvolmodels_amd.dist import shard_range
+    from stochvolmodels_amd.engine import option_type_codes
+    L = _lib.load()
+    dp, pi8, psz = C.POINTER(C.c_double), C.POINTER(C.c_int8), C.POINTER(C.c_size_t)
+    n_total = 6007
+    ttms = np.array([0.1, 0.25, 0.4])
+    fw = 100.0 * np.exp(0.03 * ttms)
+    df = np.exp(-0.03 * ttms)
+    etas = np.array([1.0, 1.05, 0.95])
+    P = sv.LOGSV_BTC_PARAMS
+
+    def chains(kind):
+        if kind == "qvar":
+            strikes = [np.array([0.02, 0.05, 0.1]), np.array([0.05, 0.15]), np.array([0.1, 0.2, 0.3, 0.4])]
+            types = [np.array(["C", "P", "C"]), np.array(["P", "C"]), np.array(["C", "C", "P", "C"])]
+        else:
+            strikes = [f * np.array([0.8, 1.0, 1.2]) for f in fw]
+            types = [np.array(["P", "IC", "C"]), np.array(["IP", "C", "IC"]), np.array(["P", "C", "C"])]
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
+        return (np.concatenate(strikes), np.concatenate([option_type_codes(t) for t in types]).astype(np.int8), offs)
+
+    def price(sess, model, kind, seed):
+        k_all, c_all, offs = chains(kind)
+        total = int(offs[-1])
+        prices, stderrs = np.empty(total), np.empty(total)
+        vt = 2 if kind == "qvar" else 1
+        a = lambda v: np.ascontiguousarray(v, dtype=np.float64).ctypes.data_as(dp)      # noqa: E731
+        if model == "logsv":
+            rc = L.svmc_logsv_chain_price(sess, a(ttms), a(fw), a(df), a(etas), 3, a(k_all), c_all.ctypes.data_as(pi8),
+                                          offs.ctypes.data_as(psz), P.sigma0, P.theta, P.kappa1, P.kappa2, P.beta, P.volvol,
+                                          1, vt, 200, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
+        else:
+            rc = L.svmc_heston_chain_price(sess, a(ttms), a(fw), a(df), 3, a(k_all), c_all.ctypes.data_as(pi8),
+                                           offs.ctypes.data_as(psz), 0.04, 0.05, 2.0, -0.5, 0.4, 0 if model == "heston_euler" else 1,
+                                           vt, 200, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
+        _lib.check(rc)
+        return prices, stderrs
+
+    def new_session(n):
+        sess = C.c_void_p()
+        _lib.check(L.svmc_session_create(C.byref(sess), n, 3, 16))
+        return sess
+
+    one = new_session(n_total)
+    shards = [shard_range(n_total, r, world) for r in range(world)]
+    assert sum(n for _, n in shards) == n_total and shards[-1][0] > 0
+    sessions = [new_session(n) for _, n in shards]
+    barrier = threading.Barrier(world)
+    staged = [None] * world
+    calls = [0] * world
+
+    def make_reducer(r):
+        def reduce(user, buf, n, stream):
+            try:
+                host = np.empty(n)
+                if L.svmc_stream_synchronize(stream) or L.svmc_memcpy_d2h(host.ctypes.data, buf, 8 * n, stream) or \
+                        L.svmc_stream_synchronize(stream):
+                    return 2
+                staged[r] = host
+                barrier.wait(timeout=60)
+                total = staged[0].copy()
+                for other in staged[1:]:                     # fixed rank order on every rank: identical sums everywhere
+                    total += other
+                barrier.wait(timeout=60)
+                calls[r] += 1
+                if L.svmc_memcpy_h2d(buf, total.ctypes.data, 8 * n, stream) or L.svmc_stream_synchronize(stream):
+                    return 2
+                return 0
+            except Exception:                                # never raise through the C frame
+                return 2
+        return _lib.ALL_REDUCE_FN(reduce)
+
+    reducers = [make_reducer(r) for r in range(world)]       # kept alive for the duration of the calls
+    for r, (sess, (off, n)) in enumerate(zip(sessions, shards)):
+        _lib.check(L.svmc_session_set_reducer(sess, reducers[r], None, r, world, n_total, off))
+    try:
+        for model, kind in (("logsv", "inverse"), ("logsv", "qvar"), ("heston_euler", "plain"), ("heston_qe", "qvar")):
+            ref_p, ref_e = price(one, model, kind, 424242)
+            out, errs = [None] * world, []
+
+            def run(r):
+                try:
+                    out[r] = price(sessions[r], model, kind, 424242)
+                except Exception as exc:                     # noqa: BLE001
+                    errs.append(exc)
+                    barrier.abort()
+            before = list(calls)
+            threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            assert not errs, errs
+            assert [c - b for c, b in zip(calls, before)] == [2] * world          # exactly the two all-reduces per chain
+            worst = 0.0
+            for r in range(world):
+                np.testing.assert_array_equal(out[r][0], out[0][0])               # every rank holds the job's prices
+                np.testing.assert_array_equal(out[r][1], out[0][1])
+                np.testing.assert_allclose(out[r][0], ref_p, rtol=1e-12, atol=1e-14)
+                np.testing.assert_allclose(out[r][1], ref_e, rtol=1e-12, atol=1e-14)
+                worst = max(worst, float(np.max(np.abs(out[r][0] / ref_p - 1.0))))
+            print(f"C drivers, {world} shards on one GPU, {model}/{kind}: max relative deviation from the unsharded session {worst:.2e}")
+        # detaching gives a single-GPU session again
+        _lib.check(L.svmc_session_set_reducer(sessions[0], _lib.ALL_REDUCE_FN(0), None, 0, 1, 0, 0))
+    finally:
+        for sess in sessions + [one]:
+            L.svmc_session_destroy(sess)
+
+
 def test_c_host_rccl_example(sv, tmp_path):
     """examples/price_chain_rccl.c: a plain-C host drives the multi-GPU path -- its own RCCL communicator, the fused
     chain drivers issuing the two all-reduces (svmc_session_set_comm).  One rank with a real communicator must match
@@ -947,9 +1069,13 @@ def test_mc_chain_implied_vols(sv):
 
 def test_analytic_qvar(sv, golden):
     """analytic calls on quadratic variance (40 000 psi-grid lanes per expiry) vs the reference, and vs the GPU Monte
-    Carlo Q_VAR price.  The second-order affine expansion is an approximation whose error shows in the far OTM variance
-    calls (measured at 2^20 paths: <= 2 % of the price for the BTC set, <= 8e-6 absolute for the 20%-vol set, where the
-    analytic price is floored at 1e-10): 4 stderr + 2.5 % + 2e-5"""
+    Carlo Q_VAR price at the reference's own scale and criterion (40 000 paths, |analytic - MC| <= 4 stderr).  The
+    second-order affine expansion is an approximation: for the BTC set's SECOND expiry the Monte Carlo price sits below it
+    by 0.4 % at the money to 6 % at the far strike -- measured at 2^22 paths (z = -9.6 .. -33) and as a mean z of -0.9 ..
+    -3.0 over 24 seeds at 40 000 paths, identically under the round-2 Box-Muller stream and the round-3 inverse-CDF one
+    (tools/r03/qvar_zscores.py, profiles/r03_qvar_expansion_bias.json).  A bare 4-stderr band around a price that is 3
+    stderr off on average fails one seed in six whatever the generator, so for that expiry the band is widened DOWNWARDS
+    by the measured truncation error (6.5 % of the analytic price); everywhere else it is the bare criterion."""
     g = golden("analytic_qvar")
     for tag in ("test", "btc"):
         v = [float(a) for a in g[f"{tag}_params"]]
@@ -967,8 +1093,12 @@ def test_analytic_qvar(sv, golden):
         # visible only at millions of paths, is reported by tools/c5_bias.py (profiles/r02_c5_bias.json)
         mc, sd = pricer.model_mc_price_chain(chain, params, variable_type=sv.VariableType.Q_VAR, nb_path=40_000,
                                              nb_steps=720, seed=8)
-        assert np.all(np.abs(np.stack(mc) - np.stack(an)) <= 4.0 * np.stack(sd)), \
-            (tag, np.abs(np.stack(mc) - np.stack(an)) / np.stack(sd))
+        diff, band = np.stack(mc) - np.stack(an), 4.0 * np.stack(sd)
+        lower = -band
+        if tag == "btc":
+            lower[1] -= 0.065 * np.stack(an)[1]              # the expansion's measured truncation error (docstring)
+        print(f"analytic vs MC Q_VAR [{tag}]: z = {np.round(diff / np.stack(sd), 2).tolist()}")
+        assert np.all((diff <= band) & (diff >= lower)), (tag, diff / np.stack(sd))
     with pytest.raises(ValueError):
         chain_p = sv.OptionChain.slice_to_chain(0.25, 1.0, np.array([0.04]), np.array(["P"]))
         sv.LogSVPricer().price_chain(chain_p, sv.LogSvParams(), variable_type=sv.VariableType.Q_VAR)
@@ -1643,28 +1773,47 @@ def test_randomised_chain_sweep(sv, oracle):
 
 
 def test_bench_line_two_ranks(tmp_path):
-    """the driver's N > 1 invocation of bench.py, on the hardware there is: two ranks (gloo, sharing this GPU) launched
-    by torch.distributed.run.  The line must be the C4 workload (2^21 paths per GPU, 8 x 128 steps, 8 x 21 strikes) and
-    carry roofline, cpu_baseline, the N = 1 share rate and the whole-job-on-one-GPU leg, and the stream-ordered and
-    host-synchronised collectives must have produced identical bits."""
+    """the driver's N > 1 invocation of bench.py in its PLAIN form -- `python bench.py --gpus 2`, no launcher around it:
+    bench.py starts its own ranks under torch.distributed.run -- on the hardware there is: two ranks sharing this GPU
+    (gloo; RCCL refuses two ranks on one device).  The line must be the C4 workload (2^21 paths per GPU, 8 x 128 steps,
+    8 x 21 strikes) and carry roofline (from the loaded library's own instruction histogram, not stale), cpu_baseline, the
+    N = 1 share rate and the whole-job-on-one-GPU leg, the RCCL-route leg (here: its refusal, reported) and the stream-
+    ordered and host-synchronised collectives must have produced identical bits."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SVMC_DIST_BACKEND="gloo", SVMC_BENCH_PREWARM="12", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2",
-                          "--steps", "4", "--warmup", "2", "--cpu-sample-paths", "4096"],
-                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    env = dict(os.environ, SVMC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--cpu-sample-paths", "4096"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak" and line["dtype"] == "f64"
+    assert line["self_launched"] is True and line["gc_frozen_before_timed_region"] is True
     assert line["config"]["workload"].startswith("C4") and line["config"]["paths_per_gpu"] == 1 << 21
     assert line["config"]["paths_total"] == 1 << 22 and line["config"]["time_steps"] == 1024 and line["config"]["strikes"] == 168
     assert line["value"] > 0 and line["unit"] == "path-steps/s"
     r = line["roofline"]
     assert r["kernel"] == "logsv_chain_rng_kernel" and r["bound"] == "valu_issue" and 0.0 < r["frac"] < 1.0
+    assert r["stale"] is False and r["frac"] <= r["frac_in_stream_int32_cost"] < 1.05 and 40 < r["insts_per_wave_step"] < 60
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     assert line["n1_share_value"] > 0 and line["c4_full_one_gpu"]["paths"] == 1 << 22
-    assert line["stream_ordered_equals_strict_sync"] is True and line["comm"] == "TorchComm"
+    assert line["stream_ordered_equals_strict_sync"] is True and line["comm"] == "TorchComm" and line["backend"] == "gloo"
+    # two ranks on one device: RCCL's own refusal comes back in the line; with a GPU per rank the leg carries a rate
+    rr = line["rccl_route"]
+    assert ("error" in rr) or (rr["value"] > 0 and line["rccl_ranks_seen"] == 2 and rr["prices_equal_torch_route"] is True)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 8` on a box with fewer GPUs says so instead of hanging in a rendezvous"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SVMC_DIST_BACKEND")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
+                         env=env, timeout=300, cwd=root)
+    assert run.returncode != 0 and "GPU(s) visible" in (run.stdout + run.stderr)

@@ -157,32 +157,35 @@ def test_sqrt_and_rcp(probe):
     assert float(rel.max()) <= 2.0 ** -45
 
 
-def test_cossin_circle_table(probe):
-    """the table-assisted Box-Muller direction of the stepping kernels, fed with raw 32-bit angle words:
-    (a, b) = sqrt2 (cos t, sin t), t = 2 pi (w + 1/2) 2^-32; absolute accuracy 5e-16 on values up to sqrt2, on the
-    circle of radius sqrt2; every table interval probed at both ends"""
+def test_normal_icdf32(probe):
+    """normal_icdf32: one N(0,1) variate from one raw 32-bit word (random stream version 3) -- the product's own source
+    compiled for the host must be the CPU twin's function bit for bit (oracle svo_normal_from_word restates it in C), and
+    within the table's stated error of Phi^-1"""
+    from scipy.special import ndtri
+    from oracle import oracle
     rng = np.random.default_rng(13)
     U32 = C.POINTER(C.c_uint32)
-    w = rng.integers(0, 2 ** 32, N, dtype=np.uint64).astype(np.uint32)
-    edge = np.arange(256, dtype=np.uint32) << np.uint32(24)                  # both ends of every table interval
-    w = np.concatenate([w, edge, edge | np.uint32(0x00FFFFFF), edge | np.uint32(0x00800000), [0, 0xFFFFFFFF]]).astype(np.uint32)
-    n = w.size
-    a, b = np.empty(n), np.empty(n)
-    probe.probe_circle_tab32(w.ctypes.data_as(U32), a.ctypes.data_as(DP), b.ctypes.data_as(DP), C.c_size_t(n))
-    turn = (w.astype(np.longdouble) + np.longdouble(0.5)) * np.longdouble(2.0) ** -32
-    # reduce in turns before multiplying by 2 pi (80-bit): the argument of cos / sin stays below pi/4 in magnitude
-    pi = np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16)
-    q = np.floor(turn * 8 + np.longdouble(0.5))                                  # nearest eighth of a turn
-    y = 2 * pi * (turn - q / 8)
-    cq, sq = np.cos((q / 8 * 2 * pi)), np.sin((q / 8 * 2 * pi))
-    ct = cq * np.cos(y) - sq * np.sin(y)
-    st = sq * np.cos(y) + cq * np.sin(y)
-    r2 = np.sqrt(np.longdouble(2.0))
-    ea = float(np.max(np.abs(a - r2 * ct)))
-    eb = float(np.max(np.abs(b - r2 * st)))
-    assert ea <= 5e-16 and eb <= 5e-16, (ea, eb)
-    np.testing.assert_allclose(np.float64(a * a + b * b), 2.0, rtol=0, atol=1.5e-15)
-    # the direction is uniform on the circle: the eight octants are hit evenly by uniform words
-    octant = (np.arctan2(b[:N], a[:N]) // (np.pi / 4)).astype(int) % 8
-    counts = np.bincount(octant, minlength=8)
-    assert np.all(np.abs(counts - N / 8) < 5 * np.sqrt(N / 8))
+    w = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    edges = np.concatenate([np.arange(-3, 4, dtype=np.int64) + (1 << e) for e in range(31)])
+    w = np.concatenate([w, edges.astype(np.uint32), (-edges).astype(np.uint32), [0, 0xFFFFFFFF, 0x7FFFFFFF, 0x80000000]]).astype(np.uint32)
+    z = np.empty(w.size)
+    probe.probe_normal_icdf32(w.ctypes.data_as(U32), z.ctypes.data_as(DP), C.c_size_t(w.size))
+    twin = np.array([oracle.normal_from_word(int(v)) for v in w])
+    np.testing.assert_array_equal(z, twin)
+    t = w.view(np.int32).astype(np.float64) + 0.5
+    assert float(np.max(np.abs(z - np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t)))) <= 1e-9
+
+
+def test_log_state(probe):
+    """log_state: ln of a state variable with its constants in scalar registers -- <= 4 ULP on normal arguments (3.4 measured
+    where k ln2 and ln m partly cancel), and the
+    special values the generators can meet at a slice start: denormals, 0 -> -inf, +inf -> +inf, NaN and negatives -> NaN"""
+    rng = np.random.default_rng(14)
+    for lo, hi in ((-3, 3), (-60, 60), (-1000, 1000)):
+        s = 2.0 ** rng.uniform(lo, hi, N // 4)
+        assert _ulp(_call(probe, "probe_log_state", s), np.log(s.astype(np.longdouble))) <= 4.0
+    tiny = 2.0 ** rng.uniform(-1074, -1000, 2000)
+    assert _ulp(_call(probe, "probe_log_state", tiny), np.log(tiny.astype(np.longdouble))) <= 3.0
+    got = _call(probe, "probe_log_state", np.array([0.0, np.inf, np.nan, -1.0, -np.inf, 1.0, 5e-324]))
+    assert got[0] == -np.inf and got[1] == np.inf and np.isnan(got[2]) and np.isnan(got[3]) and np.isnan(got[4])
+    assert got[5] == 0.0 and abs(got[6] - np.log(5e-324)) < 1e-12

@@ -34,7 +34,7 @@ def test_normal_stream_moments(oracle):
     assert abs((a ** 4).mean() - 3) < 4 * np.sqrt(96 / n)
     assert abs(np.corrcoef(W0.ravel(), W1.ravel())[0, 1]) < 4 / np.sqrt(n / 2)
     assert abs(np.corrcoef(W0[:-1].ravel(), W0[1:].ravel())[0, 1]) < 4 / np.sqrt(n / 2)
-    # stream version 2 serves two consecutive steps from ONE Philox call (words r0 r1 | r2 r3) and adjacent lanes from
+    # the stream serves two consecutive steps from ONE Philox call (words r0 r1 | r2 r3) and adjacent lanes from
     # adjacent counters: lag-1 serial correlation across steps -- inside a call (even -> odd step) and across calls
     # (odd -> even) separately, for both components and crosswise -- and across adjacent paths
     bound = 4 / np.sqrt(W0[0::2].size)
@@ -45,15 +45,17 @@ def test_normal_stream_moments(oracle):
     # squares too (a generator that leaks magnitude leaks volatility clustering into the paths)
     assert abs(np.corrcoef((W0[0::2] ** 2).ravel(), (W0[1::2] ** 2).ravel())[0, 1]) < bound
     assert abs(np.corrcoef((W0[0::2] ** 2).ravel(), (W1[1::2] ** 2).ravel())[0, 1]) < bound
-    # the marginal law, against the exact N(0,1) cdf (Kolmogorov-Smirnov at 1e-3), radius and angle separately
+    # the marginal law, against the exact N(0,1) cdf (Kolmogorov-Smirnov at 1e-3), each component and the pair's joint law
+    # through its polar form (radius^2 / 2 ~ Exp(1), angle uniform: independence of the two normals of a step)
     from scipy import stats
     sub = a[:: max(1, n // 400000)]
     assert stats.kstest(sub, "norm").pvalue > 1e-3
-    r2 = 0.5 * (W0 ** 2 + W1 ** 2).ravel()[::8]                                          # -ln u1: Exp(1)
+    assert stats.kstest(W0.ravel()[::4], "norm").pvalue > 1e-3 and stats.kstest(W1.ravel()[::4], "norm").pvalue > 1e-3
+    r2 = 0.5 * (W0 ** 2 + W1 ** 2).ravel()[::8]
     assert stats.kstest(r2, "expon").pvalue > 1e-3
-    ang = (np.arctan2(W1, W0).ravel()[::8] + np.pi) / (2 * np.pi)                       # uniform on the circle
+    ang = (np.arctan2(W1, W0).ravel()[::8] + np.pi) / (2 * np.pi)
     assert stats.kstest(ang, "uniform").pvalue > 1e-3
-    assert np.abs(a).max() <= 6.76                                                       # |z| <= sqrt(2 * 33 ln 2)
+    assert np.abs(a).max() <= 6.338                                                      # |z| <= -Phi^-1(2^-33)
     U = oracle.fill_uniforms(99, 1 << 15, 8)
     assert 0.0 < U.min() and U.max() < 1.0
     assert abs(U.mean() - 0.5) < 4 / np.sqrt(12 * U.size)
@@ -63,6 +65,46 @@ def test_normal_stream_moments(oracle):
     np.testing.assert_array_equal(A1, W1[7:12, 1000:1100])
     B0, _ = oracle.fill_normals(99, 100, 5, call_id=1)
     assert not np.array_equal(B0, W0[:5, :100])
+
+
+def test_inverse_cdf_table_against_scipy(oracle):
+    """stream version 3 turns a 32-bit word into a normal with a piecewise cubic of the inverse normal CDF
+    (tools/gen_icdf_table.py -> oracle/svo_icdf_table.h == stochvolmodels_amd/csrc/svmc_icdf_table.h).  Pin it against an
+    independent Phi^-1 (scipy.special.ndtri) at the accuracy the header states, on the extreme words, around every octave
+    edge of both signs and on a dense random set; and check the properties the stream's definition promises: exact
+    antisymmetry under w -> ~w, monotonicity in the signed word, and the two copies of the table being the same bytes."""
+    import os
+    import re
+    from scipy.special import ndtri
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "svo_icdf_table.h")).read()
+    b = open(os.path.join(root, "stochvolmodels_amd", "csrc", "svmc_icdf_table.h")).read()
+    assert a == b
+    stated = float(re.search(r"#define SVMC_ICDF_MAX_ABS_ERROR (\S+)", a).group(1))
+    assert stated <= 1e-9
+    rng = np.random.default_rng(5)
+    words = [np.array([0, 1, 2, 3, 0x7FFFFFFF, 0x7FFFFFFE, 0x80000000, 0x80000001, 0xFFFFFFFF, 0xFFFFFFFE], dtype=np.uint32),
+             rng.integers(0, 1 << 32, size=200000, dtype=np.uint64).astype(np.uint32)]
+    for e in range(0, 31):
+        edge = np.arange(-40, 41, dtype=np.int64) + (1 << e)
+        words += [edge.astype(np.uint32), (-edge).astype(np.uint32)]
+    w = np.concatenate(words)
+    z = np.array([oracle.normal_from_word(int(v)) for v in w])
+    t = w.view(np.int32).astype(np.float64) + 0.5
+    exact = np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t)
+    err = np.abs(z - exact)
+    print(f"inverse-CDF table: max |z - Phi^-1| = {err.max():.3e} (stated {stated:.3e}) over {w.size} words")
+    assert err.max() <= 1.02 * stated
+    # w and ~w are the lattice points t and -t
+    zc = np.array([oracle.normal_from_word(int(v)) for v in (~w[:5000])])
+    np.testing.assert_array_equal(zc, -z[:5000])
+    # |t| small is the tail: on each sign the normal decreases as the signed word grows (from -0 down to -6.34 over the
+    # negative words, from +6.34 down to +0 over the positive ones), up to the table's own error at segment joins
+    k = w.view(np.int32)
+    for half in (k < 0, k >= 0):
+        order = np.argsort(k[half], kind="stable")
+        assert np.all(np.diff(z[half][order]) <= 2.0 * stated)
+    assert z.max() <= 6.338 and z.min() >= -6.338 and z[k >= 0].min() > 0.0 and z[k < 0].max() < 0.0
 
 
 def test_time_grid(oracle, golden):

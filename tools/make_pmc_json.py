@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """
-Build profiles/r02_pmc.json -- the per-kernel constants bench.py's `roofline` is computed from -- out of the rocprofv3
+Build profiles/r03_pmc.json -- the per-kernel constants bench.py's `roofline` is computed from -- out of the rocprofv3
 PMC passes collected by tools/collect_profiles.sh (rocpd sqlite databases, one counter group per pass):
 
-    python tools/make_pmc_json.py gpurun_out/prof_c2 gpurun_out/prof_c4 > profiles/r02_pmc.json
+    python tools/make_pmc_json.py gpurun_out/prof_c2 gpurun_out/prof_c4 > profiles/r03_pmc.json
 
 Each directory holds sq/ fetch/ write/ sub-runs of ONE bench configuration.  Per stepping kernel:
   valu_insts_per_wave_step = SQ_INSTS_VALU per dispatch / ((paths / 64) * steps)
@@ -17,15 +17,7 @@ import sqlite3
 import sys
 
 KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "logsv_w_kernel")
-NOTES = {
-    "logsv_chain_rng_kernel": "traffic above the 48 + 8 M algorithmic bytes per path is register-spill scratch: at its 64-VGPR "
-                              "budget (8 waves per SIMD) the whole-chain kernel parks 68 B per lane of values that are dead "
-                              "inside the time loop (x, qvar, slice bookkeeping, polynomial start constants) in scratch at the "
-                              "8 slice boundaries -- ~0.33 GB per launch = 70 GB/s over 4.7 ms, under 1 % of HBM peak and "
-                              "overlapped with the VALU-bound stepping (132 B / 0.87 GB before the slice epilogue switched from "
-                              "the device libm's exp to exp_full); lifting the cap to 72 / 80 VGPRs (7 / 6 waves) measured the "
-                              "same time (profiles/r02_ab_chain_residency.jsonl)",
-}
+NOTES = {}
 
 
 def counters(db_path):
@@ -51,6 +43,10 @@ def main():
                     "as reported; quarter-rate instructions per step (v_rcp_f64, v_rsq_f64) counted in the ISA"}
     for d in sys.argv[1:]:
         meta = json.load(open(os.path.join(d, "config.json")))
+        if meta.get("lib_sha256"):
+            if res.get("lib_sha256", meta["lib_sha256"]) != meta["lib_sha256"]:
+                raise SystemExit("the passes were collected on different builds of libsvmc.so")
+            res["lib_sha256"] = meta["lib_sha256"]
         merged = {}
         for sub in ("sq", "fetch", "write"):
             for db in glob.glob(os.path.join(d, sub, "**", "*.db"), recursive=True):
@@ -64,12 +60,12 @@ def main():
             if "SQ_INSTS_VALU" in c:
                 e["sq_insts_valu_per_dispatch"] = c["SQ_INSTS_VALU"][0]
                 e["valu_insts_per_wave_step"] = c["SQ_INSTS_VALU"][0] / ((paths / 64.0) * steps)
-                e["quarter_rate_insts_per_step"] = 2
-                e["source"] = "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02_pmc.json)"
+                e["source"] = "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc.json)"
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 e["fetch_size_kb_raw"], e["write_size_kb_raw"] = c["FETCH_SIZE"][0], c["WRITE_SIZE"][0]
                 e["hbm_bytes"] = 2.0 * c["FETCH_SIZE"][0] * 1024.0 + c["WRITE_SIZE"][0] * 1024.0
-            for extra in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS"):
+            for extra in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE",
+                          "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS"):
                 if extra in c:
                     e[extra.lower() + "_per_dispatch"] = c[extra][0]
             if k in NOTES:
