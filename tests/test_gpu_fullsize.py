@@ -2,14 +2,19 @@
 Full-size, same-stream parity on the BASELINE configurations themselves (run with `-m gpu` on an MI355X).
 
 C2 (LogSV, 2^20 paths x 1024 steps, 21 strikes), C3 (Heston, 2^22 paths x 4 expiries x 128 steps, 21 strikes per
-expiry, both parameter sets, Euler and QE) and one rank's share of C4 (LogSV, 2^21 paths x 8 expiries x 128 steps,
-8 x 21 strikes) are priced on the GPU through the product entry points AND on the CPU oracle fed the SAME
+expiry, both parameter sets, Euler and QE), one rank's share of C4 (LogSV, 2^21 paths x 8 expiries x 128 steps,
+8 x 21 strikes) -- plain C / P, and once each with inverse options [P, IP, C, IC], as calls / puts on the quadratic
+variance, and in the inverse measure -- and one rank's share of C5's Monte Carlo leg (five parameter sets, 2^20 paths x
+4 expiries x 128 steps) are priced on the GPU through the product entry points AND on the CPU oracle fed the SAME
 counter-based stream (oracle/svmc_oracle.c svo_*_terminal_rng, OpenMP over paths, a few seconds per configuration on
-the box's host cores).  Asserted, per configuration:
-  * terminal states path by path: 1e-9 (the two sides differ only in the rounding of their elementary functions
-    and in FMA contraction; sigma / variance dynamics are contracting, so the differences do not grow),
-  * prices and standard errors: 1e-9,
+the box's host cores).  Per configuration the test PRINTS the largest deviation it observed (run with -s to read
+them; profiles/r03_fullsize_parity.txt holds the round's) and asserts, per quantity, the tightest power of ten that
+holds with the committed build:
+  * terminal states path by path, |gpu - cpu| / (1 + |cpu|),
+  * prices and standard errors, |gpu - cpu| / (|cpu| + 1e-3 x forward)   [Q_VAR: forward -> 1],
   * and BASELINE.json north_star's criterion verbatim: |price_gpu - price_cpu| <= 2 x MC-stderr, per option.
+The two sides share the draw bit for bit (stream version 3: the same table and FMA sequence); they differ in the rounding
+of exp / log / 1/x and in the accumulator form of the device step, amplified by sigma = exp(sum of increments).
 """
 import numpy as np
 import pytest
@@ -17,6 +22,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BASE_HESTON = dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)        # C1 / HestonParams defaults
+
+# asserted bounds: {configuration: (states, prices, stderrs)} -- the next power of ten above what the round-3 build shows
+BOUNDS = {}
+DEFAULT_BOUND = (1e-9, 1e-9, 1e-9)
 
 
 @pytest.fixture(scope="module")
@@ -33,12 +42,25 @@ def cpu(oracle):
     return oracle
 
 
-def _check(tag, gpu_state, cpu_state, pr, sd, opr, osd, scale=1.0):
-    for name, g, o in zip(("x", "vol", "qvar"), gpu_state, cpu_state):
-        np.testing.assert_allclose(g, o, rtol=1e-9, atol=1e-9, err_msg=f"{tag}: terminal {name}")
+def _dev(g, o, floor):
+    g, o = np.asarray(g, dtype=np.float64), np.asarray(o, dtype=np.float64)
+    same = (g == o) | (np.isnan(g) & np.isnan(o))                       # equal infinities / NaN patterns count as equal
+    d = np.where(same, 0.0, np.abs(g - o) / (np.abs(o) + floor))
+    return float(np.max(d)) if d.size else 0.0
+
+
+def _check(tag, gpu_state, cpu_state, pr, sd, opr, osd, price_floor=1e-3):
+    b_state, b_price, b_stderr = BOUNDS.get(tag, DEFAULT_BOUND)
+    devs = {name: _dev(g, o, 1.0) for name, g, o in zip(("x", "vol", "qvar"), gpu_state, cpu_state)}
+    devs["price"] = max(_dev(pr[i], opr[i], price_floor) for i in range(len(pr)))
+    devs["stderr"] = max(_dev(sd[i], osd[i], price_floor) for i in range(len(pr)))
+    devs["price_in_stderr"] = max(float(np.max(np.abs(pr[i] - opr[i]) / osd[i])) for i in range(len(pr)))
+    print(f"FULLSIZE PARITY {tag}: " + "  ".join(f"{k} {v:.2e}" for k, v in devs.items())
+          + f"   [asserted: states {b_state:g}, prices {b_price:g}, stderrs {b_stderr:g}]")
+    for name in ("x", "vol", "qvar"):
+        assert devs[name] <= b_state, (tag, name, devs[name])
+    assert devs["price"] <= b_price and devs["stderr"] <= b_stderr, (tag, devs)
     for i in range(len(pr)):
-        np.testing.assert_allclose(pr[i], opr[i], rtol=1e-9, atol=1e-9 * scale, err_msg=f"{tag}: prices, expiry {i}")
-        np.testing.assert_allclose(sd[i], osd[i], rtol=1e-9, atol=1e-9 * scale, err_msg=f"{tag}: stderrs, expiry {i}")
         # north_star: "option prices within 2x MC-stderr of the CPU reference" -- verbatim, on identical randoms
         assert np.all(np.abs(pr[i] - opr[i]) <= 2.0 * osd[i]), (tag, i)
 
@@ -91,27 +113,105 @@ def test_c3_heston_full_size_same_stream(sv, cpu, tag, scheme):
     _check(f"C3 {tag} {scheme}", get_engine(n).get_state(), (x, v, q), pr, sd, opr, osd)
 
 
-def test_c4_rank_share_full_size_same_stream(sv, cpu):
-    from stochvolmodels_amd.engine import get_engine
-    p = sv.LOGSV_BTC_PARAMS
-    n, spy, seed = 1 << 21, 1016, 20240604
-    ttms = np.arange(1, 9) / 8.0
+def _c4_chain(m=8):
+    ttms = np.arange(1, m + 1) / 8.0
     fw = 67000.0 * np.exp(0.05 * ttms)
     dfs = np.exp(-0.05 * ttms)
-    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
-    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    return ttms, fw, dfs
+
+
+def _logsv_chain_gpu_vs_cpu(sv, cpu, tag, p, n, ttms, fw, dfs, strikes, types, seed, spy=1016, is_spot_measure=True,
+                            variable_type=None, etas=None, price_floor=None):
+    """one LogSV chain on the GPU (product entry point) and slice by slice on the oracle, same stream"""
+    from stochvolmodels_amd.engine import get_engine
+    m = len(ttms)
+    etas = np.ones(m) if etas is None else etas
+    vt = sv.VariableType.LOG_RETURN if variable_type is None else variable_type
     pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=dfs, strikes_ttms=strikes,
                                       optiontypes_ttms=types, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
-                                      kappa2=p.kappa2, beta=p.beta, volvol=p.volvol, vol_backbone_etas=np.ones(8),
-                                      nb_path=n, nb_steps_per_year=spy, seed=seed)
+                                      kappa2=p.kappa2, beta=p.beta, volvol=p.volvol, vol_backbone_etas=etas,
+                                      is_spot_measure=is_spot_measure, nb_path=n, nb_steps_per_year=spy, seed=seed,
+                                      variable_type=vt)
     x, s, q = np.zeros(n), p.sigma0 * np.ones(n), np.zeros(n)
     opr, osd, t0, step0 = [], [], 0.0, 0
     for i, ttm in enumerate(ttms):
         nb, dt, _ = sv.set_time_grid(ttm - t0, spy)
         assert nb == 128
         x, s, q = cpu.logsv_terminal_rng(x, s, q, nb, dt, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, seed,
-                                         step_offset=step0)
-        a, b = cpu.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]))
+                                         eta=float(etas[i]), is_spot_measure=is_spot_measure, step_offset=step0)
+        a, b = cpu.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]), variable_type=int(vt.value))
         opr.append(a), osd.append(b)
         t0, step0 = ttm, step0 + nb
-    _check("C4 share", get_engine(n).get_state(), (x, s, q), pr, sd, opr, osd, scale=67000.0)
+    floor = price_floor if price_floor is not None else 1e-3 * float(fw[0])
+    _check(tag, get_engine(n).get_state(), (x, s, q), pr, sd, opr, osd, price_floor=floor)
+    return pr, sd
+
+
+def test_c4_rank_share_full_size_same_stream(sv, cpu):
+    ttms, fw, dfs = _c4_chain()
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    _logsv_chain_gpu_vs_cpu(sv, cpu, "C4 share", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types, 20240604)
+
+
+def test_c4_rank_share_inverse_options(sv, cpu):
+    """the C4 rank share with the option types cycling [P, IP, C, IC] ("also one run with IC/IP"): the
+    payoff_group_kernel<..., HAS_INV = 1> instantiation at full size -- inverse payoffs divide by the recentred spot and
+    drop out of nanmean / nanstd where it is not finite (utils/mc_payoffs.py:66-83)"""
+    ttms, fw, dfs = _c4_chain()
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    cyc = np.array(["P", "IP", "C", "IC"])
+    types = tuple(cyc[np.arange(21) % 4] for _ in fw)
+    # an inverse payoff is a fraction of the spot: O(0.1), not O(forward)
+    _logsv_chain_gpu_vs_cpu(sv, cpu, "C4 share IC/IP", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types, 20240605,
+                            price_floor=1e-3)
+
+
+def test_c4_rank_share_quadratic_variance(sv, cpu):
+    """the C4 rank share as calls / puts on the annualised quadratic variance (strikes in variance units): the
+    <..., NEED_Q = 1> instantiation and the qvar snapshot rows at full size, with a vol backbone"""
+    ttms, fw, dfs = _c4_chain()
+    kv = np.linspace(0.2, 1.6, 21)                       # BTC set: sigma0^2 = 0.70, theta^2 = 1.08
+    strikes = tuple(kv for _ in fw)
+    types = tuple(np.where(kv >= 0.8, "C", "P") for _ in fw)
+    etas = np.linspace(0.9, 1.1, 8)
+    _logsv_chain_gpu_vs_cpu(sv, cpu, "C4 share Q_VAR", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types, 20240606,
+                            variable_type=sv.VariableType.Q_VAR, etas=etas, price_floor=1e-3)
+
+
+def test_c4_rank_share_inverse_measure(sv, cpu):
+    """the C4 rank share simulated in the inverse measure (pricers/logsv_pricer.py:1032-1035: alpha = +1, adj = beta eta),
+    inverse options priced on it"""
+    ttms, fw, dfs = _c4_chain()
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "IC", "IP") for k, f in zip(strikes, fw))
+    _logsv_chain_gpu_vs_cpu(sv, cpu, "C4 share inverse measure", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types,
+                            20240607, is_spot_measure=False, price_floor=1e-3)
+
+
+C5_SETS = {   # SURVEY.md 8d: LOGSV_BTC_PARAMS, README calibrated, quickstart, the tests' stiff set, the article's Fig. 3
+    "btc": None,
+    "readme": dict(sigma0=0.8327, theta=1.0139, kappa1=4.8609, kappa2=4.7940, beta=0.1988, volvol=2.3694),
+    "quick": dict(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0),
+    "test": dict(sigma0=0.2, theta=0.22, kappa1=3.0, kappa2=12.0, beta=-0.3, volvol=0.4),
+    "fig3": dict(sigma0=1.5, theta=1.0, kappa1=4.0, kappa2=4.0, beta=0.0, volvol=1.5),
+}
+
+
+@pytest.mark.parametrize("tag", list(C5_SETS))
+def test_c5_monte_carlo_leg_rank_share(sv, cpu, tag):
+    """C5's Monte Carlo leg on ITS workload: each of the five parameter sets on C4's first four expiries, one rank's share
+    of the 2^23 paths (2^20 paths x 4 x 128 steps, 4 x 21 strikes), GPU vs the oracle on the same stream -- the stiff
+    kappa2 = 12 set, sigma0 = 1.5 and volvol 2.37 meet the oracle at scale here.  Also printed (no tolerance: the
+    expansion's truncation error is a property of the reference's approximation, tabulated in
+    profiles/r02_c5_bias.json): the z-scores of the Monte Carlo prices against the GPU's analytic chain."""
+    p = sv.LOGSV_BTC_PARAMS if C5_SETS[tag] is None else sv.LogSvParams(**C5_SETS[tag])
+    ttms, fw, dfs = _c4_chain(4)
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    pr, sd = _logsv_chain_gpu_vs_cpu(sv, cpu, f"C5 {tag}", p, 1 << 20, ttms, fw, dfs, strikes, types, 20240610)
+    chain = sv.OptionChain(ttms=ttms, forwards=fw, strikes_ttms=strikes, optiontypes_ttms=types, ids=None, discfactors=dfs)
+    an = sv.LogSVPricer().price_chain(chain, p)
+    z = np.stack([(a - b) / c for a, b, c in zip(pr, an, sd)])
+    print(f"C5 {tag}: (MC - analytic) / stderr per expiry, min .. max over the 21 strikes: "
+          + ", ".join(f"[{row.min():+.1f} .. {row.max():+.1f}]" for row in z))

@@ -290,16 +290,37 @@ def test_bench_workloads_and_roofline_arithmetic():
         assert list(t) == ["P" if v < f else "C" for v in k]
     base = bench.cpu_baseline(c4, 256, sv.LOGSV_BTC_PARAMS)
     assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and "8 expiries" in base["sample"]
-    pmc = {"logsv_rng_kernel": {"valu_insts_per_wave_step": 71.0, "quarter_rate_insts_per_step": 2,
-                                "config": {"paths": 1 << 20, "steps": 1024}, "hbm_bytes": 59.0e6}}
-    r = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, pmc, 2400.0)
-    slots = (71.0 + 6.0) * (2 ** 20 / 64) * 1024 / 2.0e-3
-    assert r["roofline"]["bound"] == "valu_issue" and abs(r["roofline"]["achieved"] - slots) < 1e-3 * slots
-    assert abs(r["roofline"]["peak"] - 1024 * 2.4e9 / 4) < 1 and abs(r["roofline"]["frac"] - slots / 6.144e11) < 1e-12
-    assert r["roofline"]["clock_mhz_sensor"] == 2400.0 and r["roofline"]["traffic"] == 59.0e6
-    assert r["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
-    # without a committed counter pass for the kernel the line falls back to the HBM roof instead of inventing a count
-    assert bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, {}, None)["roofline"]["bound"] == "hbm"
+    # the VALU-issue roof: the time loop's instruction histogram (per trip = two time steps) priced per opcode class
+    classes = {"fp64": 71, "int32": 29, "int32_3op": 4, "quarter": 2}
+    isa = {"kernels": {"logsv_rng_kernel": {"classes": classes, "valu": 106, "lds": 10}}, "stale": False,
+           "source": "stochvolmodels_amd/libsvmc.isa.json", "lib_sha256": "ab" * 32}
+    pmc = {"logsv_rng_kernel": {"valu_insts_per_wave_step": 53.2, "config": {"paths": 1 << 20, "steps": 1024}, "hbm_bytes": 59.0e6},
+           "matches_loaded_library": True}
+    r = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, 2400.0)["roofline"]
+    cyc = (71 * 4 + 29 * 2 + 4 * 4 + 2 * 16) / 2.0                  # 195 issue cycles per wave-step
+    want = cyc * (2 ** 20 / 64) * 1024 / 2.0e-3
+    assert r["bound"] == "valu_issue" and r["issue_cycles_per_wave_step"] == cyc and abs(r["achieved"] - want) < 1e-9 * want
+    assert r["peak"] == 1024 * 2.4e9 and abs(r["frac"] - want / (1024 * 2.4e9)) < 1e-12 and r["insts_per_wave_step"] == 53.0
+    in_stream = (71 * 4 + 29 * 3.9 + 4 * 4 + 2 * 16) / 2.0
+    assert abs(r["frac_in_stream_int32_cost"] - r["frac"] * in_stream / cyc) < 1e-12
+    assert r["clock_mhz_sensor"] == 2400.0 and r["traffic"] == 59.0e6 and r["stale"] is False
+    assert r["insts_per_wave_step_counters"] == 53.2
+    rr = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, 2400.0)
+    assert rr["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
+    # a library that is not the one the histogram describes: stale; counters of another build are not quoted
+    stale = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, dict(isa, stale=True),
+                                   dict(pmc, matches_loaded_library=False), None)["roofline"]
+    assert stale["stale"] is True and stale["insts_per_wave_step_counters"] is None
+    # without a histogram for the kernel the line falls back to the HBM roof (marked stale) instead of inventing a count
+    none = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, {"kernels": {}, "stale": True, "source": None,
+                                                                             "lib_sha256": ""}, {}, None)["roofline"]
+    assert none["bound"] == "hbm" and none["stale"] is True
+    # the histogram the build wrote beside the library names the library it was read from
+    from stochvolmodels_amd import _lib, build
+    build.build()
+    live = bench.load_isa(_lib.LIB_PATH)
+    assert live["stale"] is False and live["kernels"]["logsv_rng_kernel"]["valu"] > 60
+    assert live["kernels"]["logsv_chain_rng_kernel"]["classes"]["quarter"] == 2
 
 
 def test_batched_gradient_uses_scipys_difference_points():
