@@ -175,19 +175,23 @@ __device__ __forceinline__ void progress_priority(int stage)
 }
 
 // Optional slice epilogue fused into the stepping kernels: the terminal x (and qvar) is also written to the
-// per-expiry snapshot the payoff pass reads, and the block's [sum F*exp(x), count] goes to partials[block][2]
-// (utils/mc_payoffs.py:61-62) -- one launch and one pass over x less per expiry.
+// per-expiry snapshot the payoff pass reads, and [sum F*exp(x), count] (utils/mc_payoffs.py:61-62) goes out as one row PER
+// WAVE -- partials[wave][ld], wave = global thread index / 64 -- which reduce_columns_kernel adds up in row order: one
+// launch and one pass over x less per expiry.  Rows per wave, not per block: the sum's order of additions is then the same
+// whatever block size a kernel runs (the one-slice generators run 512-thread blocks, the whole-chain kernel 1024, the
+// streamed ones 256, and their results must agree to the bit), and the epilogue needs no LDS and no barrier.
 struct SliceOut {
     double *x_snap;     // nullable
     double *q_snap;     // nullable
-    double *partials;   // nullable: [gridDim.x][ld], this slice's pair at the row start
+    double *partials;   // nullable: [wave_rows(n)][ld], this slice's pair at the row start
     double forward;
-    int ld = 2;         // doubles per block row of `partials` (2 * slices for the whole-chain kernel)
+    int ld = 2;         // doubles per wave row of `partials` (2 * slices for the whole-chain kernel)
 };
+
+static inline unsigned wave_rows(size_t n) { return static_cast<unsigned>((n + 63) / 64); }
 
 __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, bool active, double xv, double q)
 {
-    __shared__ double lds[2 * 16];                         // two values per wave, up to 16 waves per block
     if (active) {
         if (so.x_snap != nullptr) so.x_snap[p] = xv;
         if (so.q_snap != nullptr) so.q_snap[p] = q;
@@ -195,8 +199,12 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
     if (so.partials != nullptr) {
         const double sp = so.forward * exp_full(xv);       // full-range exp: x = +-inf must give inf / 0   :61
         const bool ok = active && (sp == sp);                                                   // nanmean :62
-        double v[2] = {ok ? sp : 0.0, ok ? 1.0 : 0.0};
-        block_sum_store<2>(v, lds, so.partials + static_cast<size_t>(so.ld) * blockIdx.x, 2);
+        const double v0 = wave_sum(ok ? sp : 0.0), v1 = wave_sum(ok ? 1.0 : 0.0);
+        if ((threadIdx.x & 63u) == 0u) {
+            double *row = so.partials + static_cast<size_t>(so.ld) * (p >> 6);
+            row[0] = v0;
+            row[1] = v1;
+        }
     }
 }
 
@@ -330,7 +338,6 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
                              partials + 2 * i, cs.forward[i], 2 * cs.m};
         slice_epilogue(so, path_index(), active, xv, q);
-        __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
     }
     if (active) {
         const size_t p = path_index();
@@ -881,7 +888,6 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
                              partials + 2 * i, cs.forward[i], 2 * cs.m};
         slice_epilogue(so, p, active, xv, q);
-        __syncthreads();
     }
     if (active) {
         x[p] = xv;
@@ -1189,7 +1195,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     return check_launch(fn);
 }
 
-// the [grid][2] spot partials of a fused slice kernel -> spot_sums[2]
+// the [wave][2] spot partials of a fused slice kernel -> spot_sums[2]
 static int finish_slice_sums(const char *fn, unsigned block_rows, double *spot_sums, void *workspace, svmc_stream_t stream)
 {
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
@@ -1202,7 +1208,7 @@ static int check_slice_args(const char *fn, size_t n_path, const double *x_snaps
 {
     if (x_snapshot == nullptr || spot_sums == nullptr || workspace == nullptr)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot / spot_sums / workspace");
-    if (workspace_bytes < static_cast<size_t>(grid_for(n_path)) * 2 * sizeof(double))     // the finer of the two grids
+    if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
     return SVMC_OK;
 }
@@ -1231,7 +1237,7 @@ int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                   vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream))
         return rc;
-    return finish_slice_sums(fn, rng_grid(n_path), spot_sums, workspace, stream);
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
@@ -1252,7 +1258,7 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
     for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
         ChainSlices cs;
         cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
-        if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
+        if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * cs.m * sizeof(double))
             return fail(SVMC_ERR_WORKSPACE, "svmc_logsv_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
         cs.total_steps = 0;
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
@@ -1268,7 +1274,7 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
         hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
                            cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace));
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(cs.total_steps);
     }
@@ -1313,7 +1319,7 @@ int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, in
     if (int rc = logsv_w_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                 vol_backbone_eta, is_spot_measure, W0, W1, ldw, so, stream))
         return rc;
-    return finish_slice_sums(fn, grid_for(n_path), spot_sums, workspace, stream);
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
 }  // extern "C"
@@ -1342,7 +1348,7 @@ int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
     hipLaunchKernelGGL(logsv_w_indirect_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, stream, x, sigma, qvar, n_path,
                        nb_steps, reinterpret_cast<const LogsvConsts *>(consts_dev), W0, W1, ldw, so);
     if (int rc = check_launch(fn)) return rc;
-    return finish_slice_sums(fn, grid_for(n_path), spot_sums, workspace, reinterpret_cast<svmc_stream_t>(stream));
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, reinterpret_cast<svmc_stream_t>(stream));
 }
 
 // every expiry of a chain on resident randoms in one launch + one column reduce (graph-replayed driver, svmc_chain.hip):
@@ -1357,7 +1363,7 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
     if (n_slices < 1 || n_slices > MAX_CHAIN_SLICES || n_path == 0 || ldw < n_path)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
     const unsigned g = grid_for(n_path);
-    if (workspace_bytes < static_cast<size_t>(g) * 2 * n_slices * sizeof(double))
+    if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * n_slices * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
     ChainWSlices cs;
     cs.m = n_slices;
@@ -1374,7 +1380,7 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                        reinterpret_cast<const LogsvConsts *>(consts_dev), vol0_dev, ldw, x_snapshots, qvar_snapshots,
                        static_cast<double *>(workspace));
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_slices), dim3(BLOCK), 0, stream,
-                       static_cast<const double *>(workspace), static_cast<int>(g), 2 * n_slices, spot_sums);
+                       static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * n_slices, spot_sums);
     return check_launch(fn);
 }
 
@@ -1399,7 +1405,7 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
     const unsigned g = grid_for(n_path);
     const int cols = 2 * n_slices * n_sets;
-    if (workspace_bytes < static_cast<size_t>(g) * cols * sizeof(double))
+    if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * cols * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
     ChainWSlices cs;
     cs.m = n_slices;
@@ -1422,7 +1428,7 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
     default: launch_chain_w_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
     }
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
-                       static_cast<int>(g), cols, spot_sums);
+                       static_cast<int>(wave_rows(n_path)), cols, spot_sums);
     return check_launch(fn);
 }
 
@@ -1534,7 +1540,7 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
     if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
                                    call_id, path_offset, step_offset, so, stream))
         return rc;
-    return finish_slice_sums(fn, rng_grid(n_path), spot_sums, workspace, stream);
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
@@ -1555,7 +1561,7 @@ int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, i
     for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
         HestonChainSlices cs;
         cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
-        if (workspace_bytes < static_cast<size_t>(g) * 2 * cs.m * sizeof(double))
+        if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * cs.m * sizeof(double))
             return fail(SVMC_ERR_WORKSPACE, "svmc_heston_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
         int steps = 0;
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
@@ -1577,7 +1583,7 @@ int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, i
                                as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
                                xs, qs, static_cast<double *>(workspace));
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(g), 2 * cs.m, spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(steps);
     }
@@ -1666,7 +1672,7 @@ int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, size_t n_pa
                                     v0_host, theta, kappa1, kappa2, rho, volvol, Z0, Z1, ldw, seed, call_id,
                                     path_offset, step_offset, from_origin, so, stream))
         return rc;
-    return finish_slice_sums(fn, (Z0 == nullptr) ? rng_grid(n_path) : grid_for(n_path), spot_sums, workspace, stream);
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
 int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -1707,7 +1713,7 @@ int svmc_payoff_workspace_bytes(size_t *bytes)
 int svmc_slice_workspace_bytes(size_t n_path, size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_slice_workspace_bytes: null output");
-    const size_t fused = static_cast<size_t>(grid_for(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
+    const size_t fused = static_cast<size_t>(wave_rows(n_path)) * 2 * MAX_CHAIN_SLICES * sizeof(double);
     const size_t payoff = static_cast<size_t>(MAX_REDUCE_GRID) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double);
     *bytes = fused > payoff ? fused : payoff;
     return SVMC_OK;

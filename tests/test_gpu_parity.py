@@ -634,11 +634,11 @@ def test_c_abi_chain_drivers_sharded_on_one_gpu(sv, world):
         if model == "logsv":
             rc = L.svmc_logsv_chain_price(sess, a(ttms), a(fw), a(df), a(etas), 3, a(k_all), c_all.ctypes.data_as(pi8),
                                           offs.ctypes.data_as(psz), P.sigma0, P.theta, P.kappa1, P.kappa2, P.beta, P.volvol,
-                                          1, vt, 200, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
+                                          1, 200, vt, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
         else:
             rc = L.svmc_heston_chain_price(sess, a(ttms), a(fw), a(df), 3, a(k_all), c_all.ctypes.data_as(pi8),
                                            offs.ctypes.data_as(psz), 0.04, 0.05, 2.0, -0.5, 0.4, 0 if model == "heston_euler" else 1,
-                                           vt, 200, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
+                                           200, vt, seed, 5, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp))
         _lib.check(rc)
         return prices, stderrs
 
