@@ -23,9 +23,12 @@ pytestmark = pytest.mark.gpu
 
 BASE_HESTON = dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)        # C1 / HestonParams defaults
 
-# asserted bounds: {configuration: (states, prices, stderrs)} -- the next power of ten above what the round-3 build shows
-BOUNDS = {}
-DEFAULT_BOUND = (1e-9, 1e-9, 1e-9)
+# asserted bounds (states, prices, stderrs).  Observed with the round-3 build (profiles/r03_fullsize_parity.txt): states
+# 3e-16 .. 4.5e-14, prices 1e-15 .. 7e-14, standard errors 5e-17 .. 5e-14 -- SURVEY.md appendix B.7's 1e-12 (stepping) holds
+# for all three everywhere but the inverse payoffs of the BTC set, whose division by the recentred spot shows 1.6e-12 in the
+# prices and 2.4e-11 in the standard errors (B.7's figure for prices is 1e-11)
+DEFAULT_BOUND = (1e-12, 1e-12, 1e-12)
+BOUNDS = {"C4 share IC/IP": (1e-12, 1e-11, 1e-10)}
 
 
 @pytest.fixture(scope="module")
