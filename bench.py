@@ -584,6 +584,7 @@ def main():
             clock_mhz = clk.steady_mhz()
         result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, isa, pmc, clock_mhz))
         result.update(extra)
+        result["rng_stream_version"] = int(svlib.load().svmc_rng_stream_version())
         result["device_prewarm_steps"] = PREWARM
         result["gc_frozen_before_timed_region"] = True
         result["self_launched"] = os.environ.get("SVMC_BENCH_SELF_LAUNCHED") == "1"

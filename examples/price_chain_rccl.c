@@ -50,25 +50,37 @@ int main(int argc, char **argv)
     CHECK(svmc_device_count(&n_dev));
     CHECK(svmc_set_device(rank % n_dev));
 
-    /* the RCCL unique id: rank 0 makes it and publishes it through the file system (write + rename = atomic) */
+    /* the RCCL unique id: rank 0 makes it and publishes it through the file system (write + rename = atomic).  The file
+     * carries the run's token (here: the seed all ranks were started with) in front of the id, and a reader accepts only a
+     * file with ITS token: an id file left behind by a crashed earlier run (rank 0 removes the file only on success) is
+     * neither mistaken for this run's -- the reader keeps waiting for the right one -- nor left in place by rank 0 */
     unsigned char id[SVMC_RCCL_UNIQUE_ID_BYTES];
     if (rank == 0) {
+        unlink(id_file);
         CHECK(svmc_rccl_unique_id(id, sizeof id));
         char tmp[4096];
         snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
         FILE *f = fopen(tmp, "wb");
-        if (f == NULL || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 || rename(tmp, id_file) != 0) {
+        if (f == NULL || fwrite(&seed, sizeof seed, 1, f) != 1 || fwrite(id, 1, sizeof id, f) != sizeof id || fclose(f) != 0 ||
+            rename(tmp, id_file) != 0) {
             perror("publishing the RCCL id");
             return 1;
         }
     } else {
-        FILE *f = NULL;
-        for (int tries = 0; tries < 600 && (f = fopen(id_file, "rb")) == NULL; ++tries) usleep(100000);
-        if (f == NULL || fread(id, 1, sizeof id, f) != sizeof id) {
-            fprintf(stderr, "rank %d: no RCCL id at %s\n", rank, id_file);
+        int have = 0;
+        for (int tries = 0; tries < 600 && !have; ++tries) {
+            FILE *f = fopen(id_file, "rb");
+            uint64_t token = 0;
+            if (f != NULL) {
+                have = fread(&token, sizeof token, 1, f) == 1 && token == seed && fread(id, 1, sizeof id, f) == sizeof id;
+                fclose(f);
+            }
+            if (!have) usleep(100000);
+        }
+        if (!have) {
+            fprintf(stderr, "rank %d: no RCCL id of this run (token %llu) at %s\n", rank, (unsigned long long)seed, id_file);
             return 1;
         }
-        fclose(f);
     }
     svmc_comm_t comm;
     CHECK(svmc_rccl_comm_create(&comm, id, sizeof id, world, rank));

@@ -295,8 +295,8 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8)
  *   r0..r3 = philox4x32_7(ctr, key);  (ra, rb) = (r0, r1) for an even step, (r2, r3) for an odd one
  *   z(r):  t = (int32) r + 1/2 (symmetric about 0, never 0);  j = the segment of |t| -- (low 5 bits of the biased fp64
- *          exponent) << M | (top M mantissa bits), 32 octaves x 2^M equal parts;  d = |t| - (lower edge of segment j);
- *          z = sign(t) * fma(fma(fma(a3, d, a2), d, a1), d, a0)  with {a0..a3}[j] from svo_icdf_table.h, the
+ *          exponent) << M | (top M mantissa bits), 32 octaves x 2^M equal parts;
+ *          z = sign(t) * fma(fma(fma(a3, |t|, a2), |t|, a1), |t|, a0)  with {a0..a3}[j] from svo_icdf_table.h, the
  *          piecewise cubic of -Phi^-1(|t| 2^-32) generated by tools/gen_icdf_table.py (the same bytes as the product's
  *          csrc/svmc_icdf_table.h; tests/test_oracle_golden.py pins the table against scipy's Phi^-1 at
  *          SVMC_ICDF_MAX_ABS_ERROR).  This evaluation order, FMAs included, IS the definition of the stream.
@@ -342,8 +342,8 @@ static inline void philox_draw(uint64_t seed, uint32_t call_id, uint64_t path, u
 }
 
 #include "svo_icdf_table.h"
-#if !SVMC_ICDF_EDGE || SVMC_ICDF_DEG != 3
-#error "the oracle restates the edge-form cubic table"
+#if !SVMC_ICDF_RAW || SVMC_ICDF_DEG != 3
+#error "the oracle restates the raw-form cubic table (coefficients in powers of |t|)"
 #endif
 static const double svo_icdf_p0[SVMC_ICDF_SEGMENTS][2] = { SVMC_ICDF_PIECE0_INIT };    /* {a0, a1} */
 static const double svo_icdf_p1[SVMC_ICDF_SEGMENTS][2] = { SVMC_ICDF_PIECE1_INIT };    /* {a2, a3} */
@@ -356,13 +356,10 @@ double svo_normal_from_word(uint32_t w)
     memcpy(&bits, &t, 8);
     const uint32_t hi = (uint32_t)(bits >> 32);
     const uint32_t j = (hi >> (20 - SVMC_ICDF_M)) & (SVMC_ICDF_SEGMENTS - 1u);
-    const uint64_t ebits = (uint64_t)(hi & (0x7FFFFFFFu & ~((1u << (20 - SVMC_ICDF_M)) - 1u))) << 32;
-    double edge;
-    memcpy(&edge, &ebits, 8);
-    const double d = fabs(t) - edge;                         /* exact */
-    double p = fma(svo_icdf_p1[j][1], d, svo_icdf_p1[j][0]);
-    p = fma(p, d, svo_icdf_p0[j][1]);
-    p = fma(p, d, svo_icdf_p0[j][0]);
+    const double a = fabs(t);
+    double p = fma(svo_icdf_p1[j][1], a, svo_icdf_p1[j][0]);
+    p = fma(p, a, svo_icdf_p0[j][1]);
+    p = fma(p, a, svo_icdf_p0[j][0]);
     return copysign(p, t);
 }
 

@@ -15,7 +15,10 @@ fallback.  Names resolve lazily so importing the package does not load the GPU l
 """
 import importlib
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"
+# the counter-based random stream the generators draw from (include/svmc.h SVMC_RNG_STREAM_VERSION, CHANGELOG.md): results
+# for a given seed are reproducible within one stream version
+RNG_STREAM_VERSION = 3
 
 _EXPORTS = {
     "OptionType": "utils.config", "VariableType": "utils.config",

@@ -31,6 +31,7 @@ def _declare(L: C.CDLL) -> None:
     pf64, pi8 = C.POINTER(f64), C.POINTER(C.c_int8)
     sig = {
         "svmc_version": ([], i32),
+        "svmc_rng_stream_version": ([], i32),
         "svmc_last_error": ([], C.c_char_p),
         "svmc_device_count": ([pi32], i32),
         "svmc_set_device": ([i32], i32),

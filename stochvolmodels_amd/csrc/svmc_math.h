@@ -319,19 +319,20 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
 // SVMC_ICDF_M mantissa bits: 32 octaves x 2^M equal parts, i.e. geometric spacing towards the tail where Phi^-1 is singular
 // -- by one shift and one mask that leave the BYTE offset of the segment's 16-byte pieces; the pieces sit in arrays one
 // after the other so that one address serves all the ds_read_b128 (LDS pipe, beside the VALU stream).
-//   EDGE form (the committed table): c_j = the segment's lower edge = |t| with the mantissa below the segment bits
-//   cleared (a v_and_b32 on the high word over a zero low word), pieces {a0, a1}, {a2, a3}: 10 VALU instructions -- cvt,
-//   add, shift, and, and, subtract (the modulus is an operand modifier), three FMAs, v_bfi_b32 for the sign -- and 32 table
+//   RAW form (the committed table): c_j = 0, the cubic runs in |t| itself, pieces {a0, a1}, {a2, a3}: 8 VALU instructions
+//   -- cvt, add, shift, and, three FMAs on |t| (the modulus is an operand modifier), v_bfi_b32 for the sign -- and 32 table
 //   bytes per normal, where the Box-Muller pair of stream version 2 took 19 instructions per normal.
+//   Edge form: c_j = the segment's lower edge = |t| with the mantissa below the segment bits cleared: 10 instructions.
 //   Midpoint form: c_j from the table, pieces {c, a0}, {a1, a2}, {a3, a4}: 9 instructions but 40 table bytes -- measured
 //   LDS-bound (the LDS pipe 95 % busy, 61 % of it bank conflicts of the randomly indexed reads) and no faster.
+//   (profiles/r03_ab_stream_v3*.jsonl: 2.35 ms for stream v2's loop on C2, 1.86 midpoint, 1.80 edge, 1.70 raw)
 // This evaluation order IS the stream's definition: the CPU twin (oracle/svmc_oracle.c svo_normal_from_word) evaluates the
 // same expression.
 struct alignas(16) IcdfPiece {
     double a, b;
 };
 
-template <int M, int SEGMENTS, int DEG, bool EDGE = false>
+template <int M, int SEGMENTS, int DEG, bool EDGE = false, bool RAW = false>
 SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
 {
     const double t = static_cast<double>(static_cast<int32_t>(w)) + 0.5;
@@ -341,7 +342,16 @@ SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
     const IcdfPiece e0 = *reinterpret_cast<const IcdfPiece *>(base);
     const IcdfPiece e1 = *reinterpret_cast<const IcdfPiece *>(base + 16 * SEGMENTS);
     double p;
-    if (EDGE) {
+    if (RAW) {
+        // pieces {a0, a1}, {a2, a3}: the cubic in |t| ITSELF.  Re-expanding a segment's polynomial about 0 makes its terms
+        // O(1) quantities that cancel to the result -- (c / width)^k = 2^(k M) times the centred terms, i.e. rounding errors of
+        // a few 1e-16 absolute, seven orders below the table's own 7e-10 -- and saves the centre: no table bytes, no v_and, no
+        // subtraction
+        const double a = fabs(t);
+        p = fma(e1.b, a, e1.a);
+        p = fma(p, a, e0.b);
+        p = fma(p, a, e0.a);
+    } else if (EDGE) {
         // pieces {a0, a1}, {a2, a3}: the polynomial runs in |t| - (the segment's lower edge), and the edge is |t| with the
         // mantissa below the segment bits cleared -- one v_and_b32 on the high word instead of 8 table bytes
         const double edge = bits_to_double(0u, hi & (0x7FFFFFFFu & ~((1u << (20 - M)) - 1u)));

@@ -293,13 +293,15 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     return c;
 }
 
-// ln(1 - e) for the martingale correction ln(1 - 2 A a): |e| is O(volvol^2 dt) on any sane grid.  Where the whole wave
-// has |e| < 2^-10 (the C3 base set sits at 2^-11.3) five series terms do (next: e^6 / 6 <= 1.4e-19); below 2^-6 eight
-// (next: e^9 / 9 <= 6e-18 at the switch); larger |e| take the table logarithm.
+// ln(1 - e) for the martingale correction ln(1 - 2 A a): |e| is O(volvol^2 dt) on any sane grid.  Below 2^-10 (the C3 base
+// set sits at 2^-11.3) five series terms do (next: e^6 / 6 <= 1.4e-19); below 2^-6 eight (next: e^9 / 9 <= 6e-18 at the
+// switch); larger |e| take the table logarithm.  The choice is made PER LANE (a wave whose lanes all take one branch skips
+// the others): a path's rounding must not depend on which other paths share its wave -- results are bit-independent of how
+// a job is sharded and where a path sits in a launch.
 __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, const LogTabEntry *tab)
 {
     const double ae = fabs(e);
-    if (__all(ae < 0x1.0p-10)) {
+    if (ae < 0x1.0p-10) {
         double p = 0x1.999999999999ap-3;                  // 1/5
         p = fma_k(p, e, 0x1.0000000000000p-2);            // 1/4
         p = fma_k(p, e, 0x1.5555555555555p-2);            // 1/3

@@ -31,6 +31,9 @@
 #else
 #include "svmc_icdf_table.h"
 #endif
+#ifndef SVMC_ICDF_RAW
+#define SVMC_ICDF_RAW 0
+#endif
 #include "svmc_log_table.h"
 #include "svmc_math.h"
 
@@ -234,8 +237,8 @@ __device__ __forceinline__ double uniform_32(uint32_t k)
 // The two normals of a time step from two words, each by inversion (svmc_math.h normal_icdf32)
 __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double &w0, double &w1)
 {
-    w0 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(ra, t.icdf);
-    w1 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(rb, t.icdf);
+    w0 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(ra, t.icdf);
+    w1 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(rb, t.icdf);
 }
 
 // The time loop of every on-device-RNG generator: time steps [0, nb) of a lane whose first step has the chain-global

@@ -28,6 +28,7 @@ using namespace svmc;
 extern "C" {
 
 int svmc_version(void) { return SVMC_VERSION; }
+int svmc_rng_stream_version(void) { return SVMC_RNG_STREAM_VERSION; }
 
 const char *svmc_last_error(void) { return last_error_ref().c_str(); }
 

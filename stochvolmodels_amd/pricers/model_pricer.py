@@ -3,7 +3,7 @@ ModelParams / ModelPricer: the Monte Carlo part of the reference's pricer interf
 (pricers/model_pricer.py:28-41, :83-265).
 
 Kept: price_chain, price_slice, price_vanilla, compute_chain_prices_with_vols, compute_model_ivols_for_chain, model_mc_price_chain,
-simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols, get_log_return_mc_pdf,
+simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols,
 calibrate_model_params_to_chain with the reference's signatures.  Out of scope: the
 matplotlib plotting methods and the slice / single-option conveniences built on them.
 """
@@ -92,17 +92,3 @@ class ModelPricer(ABC):
         ivols_up = option_chain.compute_model_ivols_from_chain_data(model_prices=ups)
         ivols_down = option_chain.compute_model_ivols_from_chain_data(model_prices=downs)
         return prices, ups, downs, ivols_mid, ivols_up, ivols_down, stds
-
-    def get_log_return_mc_pdf(self, ttm: float, params: ModelParams, x_grid: np.ndarray, nb_path: int = 100000
-                              ) -> np.ndarray:
-        """Gaussian-KDE density of the simulated terminal values on x_grid (reference :243-265)."""
-        from scipy import stats
-        t_values = np.asarray(self.simulate_terminal_values(ttm=ttm, params=params, nb_path=nb_path))
-        cut_off = 1e16
-        nans = np.isnan(t_values)
-        pos = np.logical_and(~nans, t_values > cut_off)
-        neg = np.logical_and(~nans, t_values < -cut_off)
-        print(f"in mc: num -inf = {np.sum(neg)}, num +inf = {np.sum(pos)}, num nans = {np.sum(nans)}")
-        t_values = t_values[np.logical_and(np.logical_and(neg == False, pos == False), nans == False)]  # noqa: E712
-        z = stats.gaussian_kde(t_values)(x_grid)
-        return z / np.nansum(z)

@@ -69,6 +69,12 @@ def next_rng_call(seed: Optional[int] = None) -> Tuple[int, int]:
     with _rng_lock:
         call = _rng_calls
         _rng_calls = (_rng_calls + 1) & 0xFFFFFF
+        if _rng_calls == 0:
+            # the call id occupies 24 bits of the Philox counter (include/svmc.h): after 2^24 un-seeded calls under one
+            # seed the next call would repeat the randoms of call 0
+            import warnings
+            warnings.warn("stochvolmodels_amd: 2^24 un-seeded generator calls under one seed -- the call counter wraps and "
+                          "the next calls repeat earlier randoms; call set_seed() with a new value", RuntimeWarning)
         return _rng_seed, call
 
 

@@ -20,7 +20,7 @@ void probe_rcp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n;
 void probe_normal_icdf32(const uint32_t *w, double *z, size_t n)
 {
     for (size_t i = 0; i < n; ++i)
-        z[i] = svmc::normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0>(w[i], ICDF_TAB);
+        z[i] = svmc::normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(w[i], ICDF_TAB);
 }
 void probe_log_state(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = svmc::log_state(x[i]); }
 }

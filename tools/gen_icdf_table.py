@@ -41,12 +41,13 @@ def exact(t):
     return -ndtri(np.asarray(t, dtype=np.float64) * 2.0 ** -32)
 
 
-def segment(e, i, m, deg, edge=False):
-    """-> (c, coefs[deg + 1]) in powers of d = t - c for t in [lo, hi); c = the midpoint, or the lower edge"""
+def segment(e, i, m, deg, edge=False, raw=False):
+    """-> (c, coefs[deg + 1]) in powers of d = t - c for t in [lo, hi); c = the midpoint, the lower edge, or 0 (raw)"""
     width = 2.0 ** e / 2 ** m
     lo = 2.0 ** e * (1.0 + i / 2 ** m)
     hi = lo + width
-    c = lo if edge else lo + 0.5 * width
+    c = 0.0 if raw else (lo if edge else lo + 0.5 * width)
+    edge = edge or raw
     # lattice points k + 1/2 inside [lo, hi)
     k0 = int(np.ceil(lo - 0.5))
     k1 = int(np.ceil(hi - 0.5)) - 1
@@ -63,22 +64,22 @@ def segment(e, i, m, deg, edge=False):
     cheb = C.chebfit(xn, exact(mid + 0.5 * width * xn), deg)
     mono = C.cheb2poly(cheb)                                    # powers of xi = (t - mid) / (width / 2)
     coefs = np.array([mono[p] / (0.5 * width) ** p for p in range(deg + 1)])
-    if edge:                                                    # re-expand about the lower edge: t - mid = (t - lo) - width / 2
+    if edge:                                                    # re-expand about c: t - mid = (t - c) - (mid - c)
         shifted = np.zeros(deg + 1)
         for p_, a in enumerate(coefs):
-            shifted[:p_ + 1] += a * Pn.polypow([-0.5 * width, 1.0], p_)
+            shifted[:p_ + 1] += a * Pn.polypow([-(mid - c), 1.0], p_)
         coefs = shifted
     return c, coefs
 
 
-def build(m, deg, edge=False):
+def build(m, deg, edge=False, raw=False):
     n = 32 << m
     cen = np.zeros(n)
     co = np.zeros((n, 5))
     for e in range(-1, 31):
         for i in range(2 ** m):
             j = (((1023 + e) & 31) << m) | i
-            c, coefs = segment(e, i, m, deg, edge)
+            c, coefs = segment(e, i, m, deg, edge, raw)
             cen[j] = c
             co[j, :deg + 1] = coefs
     return cen, co
@@ -125,12 +126,14 @@ def main():
     ap.add_argument("--m", type=int, default=4)
     ap.add_argument("--deg", type=int, default=3, choices=(3, 4))
     ap.add_argument("--edge", action="store_true", help="polynomials in |t| - (segment's lower edge), no centre in the table")
+    ap.add_argument("--raw", action="store_true", help="polynomials in |t| itself (no centre at all); implies the edge piece layout")
     ap.add_argument("--out", default=None, help="one output file (A/B variants); default: the product's header "
                     "stochvolmodels_amd/csrc/svmc_icdf_table.h AND the oracle's copy oracle/svo_icdf_table.h (same bytes)")
     args = ap.parse_args()
     outs = [args.out] if args.out else [os.path.join(ROOT, "stochvolmodels_amd", "csrc", "svmc_icdf_table.h"),
                                         os.path.join(ROOT, "oracle", "svo_icdf_table.h")]
-    cen, co = build(args.m, args.deg, args.edge)
+    args.edge = args.edge or args.raw
+    cen, co = build(args.m, args.deg, args.edge, args.raw)
     err = max_error(cen, co, args.m)
     n = 32 << args.m
     import io
@@ -138,9 +141,9 @@ def main():
     if True:
         fh.write("// GENERATED by tools/gen_icdf_table.py -- do not edit.  Piecewise-polynomial inverse normal CDF of random stream\n"
                  f"// version 3: {n} segments (32 octaves of |t| x 2^{args.m}), degree {args.deg}; max |P - exact| on the 32-bit lattice"
-                 f" {err:.2e}\n// (exact = scipy.special.ndtri).  Pieces: " + ("0 = {a0, a1}, 1 = {a2, a3} in powers of |t| - (lower edge of the segment)" if args.edge else "0 = {c, a0}, 1 = {a1, a2}, 2 = {a3, a4} in powers of |t| - c") + ".\n"
+                 f" {err:.2e}\n// (exact = scipy.special.ndtri).  Pieces: " + ("0 = {a0, a1}, 1 = {a2, a3} in powers of |t|" if args.raw else "0 = {a0, a1}, 1 = {a2, a3} in powers of |t| - (lower edge of the segment)" if args.edge else "0 = {c, a0}, 1 = {a1, a2}, 2 = {a3, a4} in powers of |t| - c") + ".\n"
                  "#pragma once\n"
-                 f"#define SVMC_ICDF_M {args.m}\n#define SVMC_ICDF_DEG {args.deg}\n#define SVMC_ICDF_SEGMENTS {n}\n#define SVMC_ICDF_EDGE {int(args.edge)}\n"
+                 f"#define SVMC_ICDF_M {args.m}\n#define SVMC_ICDF_DEG {args.deg}\n#define SVMC_ICDF_SEGMENTS {n}\n#define SVMC_ICDF_EDGE {int(args.edge)}\n#define SVMC_ICDF_RAW {int(args.raw)}\n"
                  f"#define SVMC_ICDF_MAX_ABS_ERROR {err:.3e}\n")
         pieces = ((0, (0, 1)), (1, (2, 3)), (2, (4, 4))) if args.edge else ((0, None), (1, (1, 2)), (2, (3, 4)))
         if args.edge and args.deg == 3:
