@@ -52,6 +52,8 @@ struct Session {
     int max_expiries = 0;
     size_t max_strikes = 0;
     double *x = nullptr, *vol = nullptr, *qvar = nullptr, *snap = nullptr, *spot = nullptr, *sums = nullptr;
+    double *sums_pinned = nullptr;          // page-locked landing buffer of the payoff sums: 3 max_strikes doubles (a copy into
+                                            // pageable memory costs 16 us more per chain: tools/ubench/sync_latency.py)
     void *ws = nullptr;
     size_t ws_bytes = 0;
     hipStream_t stream = nullptr;
@@ -78,6 +80,7 @@ static void session_release(Session *s)
     for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar),
                     static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
         if (p != nullptr) (void)hipFree(p);
+    if (s->sums_pinned != nullptr) (void)hipHostFree(s->sums_pinned);
     if (s->stream != nullptr) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -193,10 +196,9 @@ static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type
     std::vector<double> shifts;
     if (int rc = enqueue_payoff_sums(s, c, variable_type, shifts)) return rc;
     if (int rc = all_reduce(s, s->sums, 3 * c.offsets[c.m])) return rc;
-    std::vector<double> sums(3 * c.offsets[c.m]);
-    SVMC_HIP_TRY(hipMemcpyAsync(sums.data(), s->sums, sums.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    SVMC_HIP_TRY(hipMemcpyAsync(s->sums_pinned, s->sums, 3 * c.offsets[c.m] * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
-    return finalize_prices(s, c, sums.data(), shifts, prices, stderrs);
+    return finalize_prices(s, c, s->sums_pinned, shifts, prices, stderrs);
 }
 
 template <class T>
@@ -233,6 +235,8 @@ int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->spot), 2 * static_cast<size_t>(max_expiries) * sizeof(double));
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->sums), 3 * max_strikes_total * sizeof(double));
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(&s->ws, ws);
+    if (rc == SVMC_OK && e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&s->sums_pinned), 3 * max_strikes_total * sizeof(double), hipHostMallocDefault);
     if (rc != SVMC_OK || e != hipSuccess) {
         session_release(s);
         return rc != SVMC_OK ? rc : fail(SVMC_ERR_HIP, std::string("svmc_session_create: ") + hipGetErrorString(e));
