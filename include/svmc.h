@@ -222,6 +222,34 @@ SVMC_API int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t 
                                    uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
                                    double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
                                    svmc_stream_t stream);
+/* The same four generators started from a UNIFORM state -- every path at (x0, vol0, qvar0), what a chain pricing begins with
+ * (x0 = 0, sigma0 | v0, qvar0 = 0: pricers/logsv_pricer.py:823-826, pricers/heston_pricer.py:303-305) -- passed as three
+ * constants: x / vol / qvar are then outputs only, and the svmc_fill_state launch (and its 24 bytes per path written, written
+ * back and read again) disappears from the call. */
+SVMC_API int svmc_logsv_slice_rng_from(double x0, double sigma0, double qvar0, double *x, double *sigma, double *qvar,
+                                       size_t n_path, int nb_steps, double dt, double theta, double kappa1, double kappa2,
+                                       double beta, double volvol, double vol_backbone_eta, int is_spot_measure,
+                                       uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset,
+                                       double forward, double *x_snapshot, double *qvar_snapshot, double *spot_sums,
+                                       void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+SVMC_API int svmc_logsv_chain_rng_from(double x0, double sigma0, double qvar0, double *x, double *sigma, double *qvar,
+                                       size_t n_path, int n_slices, const int *nb_steps_host, const double *dts_host,
+                                       const double *etas_host, const double *forwards_host, double theta, double kappa1,
+                                       double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed,
+                                       uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
+                                       double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
+                                       svmc_stream_t stream);
+SVMC_API int svmc_heston_slice_rng_from(double x0, double var0, double qvar0, double *x, double *var, double *qvar,
+                                        size_t n_path, int nb_steps, double dt, double theta, double kappa, double rho,
+                                        double volvol, int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                                        uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
+                                        double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+SVMC_API int svmc_heston_chain_rng_from(double x0, double var0, double qvar0, double *x, double *var, double *qvar,
+                                        size_t n_path, int n_slices, const int *nb_steps_host, const double *dts_host,
+                                        const double *forwards_host, double theta, double kappa, double rho, double volvol,
+                                        int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                                        uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                                        void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_heston_terminal_w(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
                            double theta, double kappa, double rho, double volvol, const double *W0,
                            const double *W1, size_t ldw, svmc_stream_t stream);

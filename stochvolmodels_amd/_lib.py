@@ -74,6 +74,14 @@ def _declare(L: C.CDLL) -> None:
         "svmc_rough_logsv_terminal": ([vp, vp, vp, sz, i32, f64, i32, pf64, pf64, pf64, f64, f64, f64, f64, f64, vp, vp, sz,
                                        u64, u32, u64, u32, i32, vp], i32),
         "svmc_heston_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp], i32),
+        "svmc_logsv_slice_rng_from": ([f64, f64, f64, vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, f64, f64, i32, u64, u32, u64,
+                                       u32, f64, vp, vp, vp, vp, sz, vp], i32),
+        "svmc_logsv_chain_rng_from": ([f64, f64, f64, vp, vp, vp, sz, i32, C.POINTER(i32), pf64, pf64, pf64, f64, f64, f64, f64,
+                                       f64, i32, u64, u32, u64, u32, vp, vp, vp, vp, sz, vp], i32),
+        "svmc_heston_slice_rng_from": ([f64, f64, f64, vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
+                                        f64, vp, vp, vp, vp, sz, vp], i32),
+        "svmc_heston_chain_rng_from": ([f64, f64, f64, vp, vp, vp, sz, i32, C.POINTER(i32), pf64, pf64, f64, f64, f64, f64, i32,
+                                        u64, u32, u64, u32, vp, vp, vp, vp, sz, vp], i32),
         "svmc_heston_slice_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32,
                                    f64, vp, vp, vp, vp, sz, vp], i32),
         "svmc_heston_terminal_w": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, vp, vp, sz, vp], i32),

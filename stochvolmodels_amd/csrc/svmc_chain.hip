@@ -307,7 +307,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
     if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
     SVMC_REQUIRE(nb_steps_per_year > 0, "svmc_logsv_chain_price: nb_steps_per_year must be positive");
     const size_t n = s->n_path;
-    if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :832-834
+    // the start state (0, v0, 0) of every path (:832-834) travels as three constants: no fill launch
     double t0 = 0.0;
     std::vector<int> nbs(c.m);
     std::vector<double> dts(c.m);
@@ -316,7 +316,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
         t0 = c.ttms[i];
     }
     if (c.m == 1) {       // a single expiry: the plain slice kernel (same bits, and the one bench.py profiles)
-        if (int rc = svmc_logsv_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
+        if (int rc = svmc_logsv_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
                                           vol_backbone_etas_host ? vol_backbone_etas_host[0] : 1.0, is_spot_measure, seed,
                                           call_id, s->path_offset, 0, c.forwards[0], s->snap,
                                           (variable_type == SVMC_Q_VAR) ? s->snap + n : nullptr, s->spot, s->ws, s->ws_bytes,
@@ -324,7 +324,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
             return rc;
         return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
     }
-    if (int rc = svmc_logsv_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
+    if (int rc = svmc_logsv_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
                                       c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
                                       s->path_offset, 0, s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
                                       s->spot, s->ws, s->ws_bytes, s->stream))
@@ -661,7 +661,7 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
     if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
     SVMC_REQUIRE(nb_steps_per_year > 0, "svmc_heston_chain_price: nb_steps_per_year must be positive");
     const size_t n = s->n_path;
-    if (int rc = svmc_fill_state(s->x, s->vol, s->qvar, n, 0.0, v0, 0.0, s->stream)) return rc;           // :303-305
+    // the start state (0, v0, 0) of every path (:303-305) travels as three constants: no fill launch
     double t0 = 0.0;
     std::vector<int> nbs(c.m);
     std::vector<double> dts(c.m);
@@ -671,11 +671,11 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
     }
     double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
     if (c.m == 1) {
-        if (int rc = svmc_heston_slice_rng(s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
+        if (int rc = svmc_heston_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
                                            call_id, s->path_offset, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
                                            s->stream))
             return rc;
-    } else if (int rc = svmc_heston_chain_rng(s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
+    } else if (int rc = svmc_heston_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
                                               rho, volvol, scheme, seed, call_id, s->path_offset, 0, s->snap, qsnap, s->spot, s->ws,
                                               s->ws_bytes, s->stream)) {
         return rc;

@@ -190,6 +190,15 @@ struct SliceOut {
 
 static inline unsigned wave_rows(size_t n) { return static_cast<unsigned>((n + 63) / 64); }
 
+// Start state of a generator launch: read from x / vol / qvar (uniform = 0), or the same three constants for every path --
+// what a chain pricing starts from (x0 = 0, sigma0 | v0, qvar0 = 0: pricers/logsv_pricer.py:823-826, heston_pricer.py:303-305).
+// The svmc_*_rng_from entry points use it: no fill launch (11 us + the write-back of its 24 bytes per path at the kernel
+// boundary) and no 24-byte read per path ahead of the stepping.
+struct StateInit {
+    int uniform = 0;
+    double x0 = 0.0, vol0 = 0.0, qvar0 = 0.0;
+};
+
 __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, bool active, double xv, double q)
 {
     if (active) {
@@ -211,7 +220,8 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
 __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_RNG_SGPRS))) void logsv_rng_kernel(double *__restrict__ x, double *__restrict__ sigma,
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
-                                                          uint64_t path_offset, uint32_t step_offset, SliceOut so)
+                                                          uint64_t path_offset, uint32_t step_offset, SliceOut so,
+                                                          StateInit init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
@@ -221,9 +231,15 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
     if (active) {
-        xv = x[p];
-        s = sigma[p];
-        q = qvar[p];
+        if (init.uniform) {                                // wave-uniform
+            xv = init.x0;
+            s = init.vol0;
+            q = init.qvar0;
+        } else {
+            xv = x[p];
+            s = sigma[p];
+            q = qvar[p];
+        }
         double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
         double s2 = s * s, acc = 0.0, xacc = 0.0;
         const double s2_start = s2;
@@ -280,7 +296,7 @@ static inline unsigned chain_grid(size_t n) { return static_cast<unsigned>((n + 
 __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAIN_WAVES), amdgpu_num_sgpr(SVMC_CHAIN_SGPRS))) void logsv_chain_rng_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
-    double *__restrict__ partials)
+    double *__restrict__ partials, StateInit init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
@@ -298,7 +314,11 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
     double s = 1.0;
     {
         double xv = 0.0, q = 0.0;
-        if (active) {
+        if (init.uniform) {                                // wave-uniform
+            xv = init.x0;
+            s = init.vol0;
+            q = init.qvar0;
+        } else if (active) {
             const size_t p = path_index();
             xv = x[p];
             s = sigma[p];
@@ -784,7 +804,7 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
                                                            double *__restrict__ qvar, size_t n, int nb_steps,
                                                            HestonConsts c, QeConsts qc, uint64_t seed,
                                                            uint32_t c3, uint64_t path_offset,
-                                                           uint32_t step_offset, SliceOut so)
+                                                           uint32_t step_offset, SliceOut so, StateInit init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
@@ -795,9 +815,15 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
     if (active) {
-        xv = x[p];
-        v = var[p];
-        q = qvar[p];
+        if (init.uniform) {                                // wave-uniform
+            xv = init.x0;
+            v = init.vol0;
+            q = init.qvar0;
+        } else {
+            xv = x[p];
+            v = var[p];
+            q = qvar[p];
+        }
         const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
@@ -841,7 +867,7 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
                                                                  HestonChainSlices cs, uint64_t seed, uint32_t c3,
                                                                  uint64_t path_offset, uint32_t step_offset,
                                                                  double *__restrict__ x_snap, double *__restrict__ q_snap,
-                                                                 double *__restrict__ partials)
+                                                                 double *__restrict__ partials, StateInit init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
@@ -852,9 +878,15 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
     const bool active = p < n;
     double xv = 0.0, v = 1.0, q = 0.0;
     if (active) {
-        xv = x[p];
-        v = var[p];
-        q = qvar[p];
+        if (init.uniform) {                                // wave-uniform
+            xv = init.x0;
+            v = init.vol0;
+            q = init.qvar0;
+        } else {
+            xv = x[p];
+            v = var[p];
+            q = qvar[p];
+        }
     }
     const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
     const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);      // QE's uniforms
@@ -1183,7 +1215,8 @@ int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint6
 static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps,
                             double dt, double theta, double kappa1, double kappa2, double beta, double volvol,
                             double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
-                            uint64_t path_offset, uint32_t step_offset, const SliceOut &so, svmc_stream_t stream)
+                            uint64_t path_offset, uint32_t step_offset, const SliceOut &so, svmc_stream_t stream,
+                            const StateInit &init = StateInit())
 {
     if (int rc = check_state(fn, x, sigma, qvar, nb_steps, dt)) return rc;
     if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
@@ -1191,7 +1224,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
     hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so);
+                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init);
     return check_launch(fn);
 }
 
@@ -1224,42 +1257,70 @@ int svmc_logsv_terminal_rng(double *x, double *sigma, double *qvar, size_t n_pat
                             stream);
 }
 
+}  // extern "C"
+
+static int logsv_slice_rng_impl(const char *fn, const StateInit &init, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
+                         double kappa1, double kappa2, double beta, double volvol, double vol_backbone_eta,
+                         int is_spot_measure, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                         uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
+                         double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
+                                  vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream, init))
+        return rc;
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
+}
+
+extern "C" {
+
 int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
                          double kappa1, double kappa2, double beta, double volvol, double vol_backbone_eta,
                          int is_spot_measure, uint64_t seed, uint32_t call_id, uint64_t path_offset,
                          uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
                          double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
-    const char *fn = "svmc_logsv_slice_rng";
-    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
-    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_logsv_slice_rng: n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
-    if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
-                                  vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream))
-        return rc;
-    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
+    return logsv_slice_rng_impl("svmc_logsv_slice_rng", StateInit(), x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2,
+                                beta, volvol, vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset,
+                                forward, x_snapshot, qvar_snapshot, spot_sums, workspace, workspace_bytes, stream);
 }
 
-int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+int svmc_logsv_slice_rng_from(double x0, double sigma0, double qvar0, double *x, double *sigma, double *qvar, size_t n_path,
+                              int nb_steps, double dt, double theta, double kappa1, double kappa2, double beta, double volvol,
+                              double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                              uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
+                              double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
+                              svmc_stream_t stream)
+{
+    const StateInit init = {1, x0, sigma0, qvar0};
+    return logsv_slice_rng_impl("svmc_logsv_slice_rng_from", init, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2,
+                                beta, volvol, vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset,
+                                forward, x_snapshot, qvar_snapshot, spot_sums, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
                          const double *dts_host, const double *etas_host, const double *forwards_host, double theta,
                          double kappa1, double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed,
                          uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
                          double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
                          svmc_stream_t stream)
 {
-    const char *fn = "svmc_logsv_chain_rng";
-    SVMC_REQUIRE(x && sigma && qvar && x_snapshots && spot_sums && workspace, "svmc_logsv_chain_rng: null pointer");
-    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, "svmc_logsv_chain_rng: null grids / no slices");
-    SVMC_REQUIRE(call_id < (1u << 24), "svmc_logsv_chain_rng: call_id must fit 24 bits");
-    SVMC_REQUIRE(n_path > 0, "svmc_logsv_chain_rng: n_path must be positive");
+    SVMC_REQUIRE(x && sigma && qvar && x_snapshots && spot_sums && workspace, std::string(fn) + ": null pointer");
+    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, std::string(fn) + ": null grids / no slices");
+    SVMC_REQUIRE(call_id < (1u << 24), std::string(fn) + ": call_id must fit 24 bits");
+    SVMC_REQUIRE(n_path > 0, std::string(fn) + ": n_path must be positive");
     for (int i = 0; i < n_slices; ++i)
-        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, "svmc_logsv_chain_rng: nb_steps and dt must be positive");
+        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, std::string(fn) + ": nb_steps and dt must be positive");
     const unsigned g = chain_grid(n_path);
     for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
         ChainSlices cs;
         cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
         if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * cs.m * sizeof(double))
-            return fail(SVMC_ERR_WORKSPACE, "svmc_logsv_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
+            return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
         cs.total_steps = 0;
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
             const int j = (i < cs.m) ? i0 + i : i0;        // unused entries repeat a valid one
@@ -1272,13 +1333,43 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
         hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
-                           cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace));
+                           cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
+                           (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(cs.total_steps);
     }
     return SVMC_OK;
+}
+
+extern "C" {
+
+int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                         const double *dts_host, const double *etas_host, const double *forwards_host, double theta,
+                         double kappa1, double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed,
+                         uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
+                         double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
+                         svmc_stream_t stream)
+{
+    return logsv_chain_rng_impl("svmc_logsv_chain_rng", StateInit(), x, sigma, qvar, n_path, n_slices, nb_steps_host, dts_host,
+                                etas_host, forwards_host, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                                path_offset, step_offset, x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes,
+                                stream);
+}
+
+int svmc_logsv_chain_rng_from(double x0, double sigma0, double qvar0, double *x, double *sigma, double *qvar, size_t n_path,
+                              int n_slices, const int *nb_steps_host, const double *dts_host, const double *etas_host,
+                              const double *forwards_host, double theta, double kappa1, double kappa2, double beta,
+                              double volvol, int is_spot_measure, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                              uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                              void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    const StateInit init = {1, x0, sigma0, qvar0};
+    return logsv_chain_rng_impl("svmc_logsv_chain_rng_from", init, x, sigma, qvar, n_path, n_slices, nb_steps_host, dts_host,
+                                etas_host, forwards_host, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                                path_offset, step_offset, x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes,
+                                stream);
 }
 
 static int logsv_w_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -1498,7 +1589,7 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
 static int heston_rng_launch(const char *fn, double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
                              double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
                              uint32_t call_id, uint64_t path_offset, uint32_t step_offset, const SliceOut &so,
-                             svmc_stream_t stream)
+                             svmc_stream_t stream, const StateInit &init = StateInit())
 {
     if (int rc = check_state(fn, x, var, qvar, nb_steps, dt)) return rc;
     if (scheme != SVMC_HESTON_EULER_FLOOR && scheme != SVMC_HESTON_QE)
@@ -1509,11 +1600,11 @@ static int heston_rng_launch(const char *fn, double *x, double *var, double *qva
     const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
     if (scheme == SVMC_HESTON_QE)
         hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream),
-                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so);
+                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
     else
         hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(rng_grid(n_path)), dim3(rng_block()), 0,
                            as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id),
-                           path_offset, step_offset, so);
+                           path_offset, step_offset, so, init);
     return check_launch(fn);
 }
 
@@ -1527,42 +1618,69 @@ int svmc_heston_terminal_rng(double *x, double *var, double *qvar, size_t n_path
                              scheme, seed, call_id, path_offset, step_offset, none, stream);
 }
 
+}  // extern "C"
+
+static int heston_slice_rng_impl(const char *fn, const StateInit &init, double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
+                          double kappa, double rho, double volvol, int scheme, uint64_t seed, uint32_t call_id,
+                          uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
+                          double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
+                          svmc_stream_t stream)
+{
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
+                                   call_id, path_offset, step_offset, so, stream, init))
+        return rc;
+    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
+}
+
+extern "C" {
+
 int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt, double theta,
                           double kappa, double rho, double volvol, int scheme, uint64_t seed, uint32_t call_id,
                           uint64_t path_offset, uint32_t step_offset, double forward, double *x_snapshot,
                           double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
                           svmc_stream_t stream)
 {
-    const char *fn = "svmc_heston_slice_rng";
-    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
-    SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_heston_slice_rng: n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
-    if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
-                                   call_id, path_offset, step_offset, so, stream))
-        return rc;
-    return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
+    return heston_slice_rng_impl("svmc_heston_slice_rng", StateInit(), x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho,
+                                 volvol, scheme, seed, call_id, path_offset, step_offset, forward, x_snapshot, qvar_snapshot,
+                                 spot_sums, workspace, workspace_bytes, stream);
 }
 
-int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+int svmc_heston_slice_rng_from(double x0, double var0, double qvar0, double *x, double *var, double *qvar, size_t n_path,
+                               int nb_steps, double dt, double theta, double kappa, double rho, double volvol, int scheme,
+                               uint64_t seed, uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double forward,
+                               double *x_snapshot, double *qvar_snapshot, double *spot_sums, void *workspace,
+                               size_t workspace_bytes, svmc_stream_t stream)
+{
+    const StateInit init = {1, x0, var0, qvar0};
+    return heston_slice_rng_impl("svmc_heston_slice_rng_from", init, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho,
+                                 volvol, scheme, seed, call_id, path_offset, step_offset, forward, x_snapshot, qvar_snapshot,
+                                 spot_sums, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
                           const double *dts_host, const double *forwards_host, double theta, double kappa, double rho,
                           double volvol, int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset,
                           uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
                           void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
-    const char *fn = "svmc_heston_chain_rng";
-    SVMC_REQUIRE(x && var && qvar && x_snapshots && spot_sums && workspace, "svmc_heston_chain_rng: null pointer");
-    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, "svmc_heston_chain_rng: null grids / no slices");
-    SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, "svmc_heston_chain_rng: unknown scheme");
-    SVMC_REQUIRE(call_id < (1u << 24), "svmc_heston_chain_rng: call_id must fit 24 bits");
-    SVMC_REQUIRE(n_path > 0, "svmc_heston_chain_rng: n_path must be positive");
+    SVMC_REQUIRE(x && var && qvar && x_snapshots && spot_sums && workspace, std::string(fn) + ": null pointer");
+    SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, std::string(fn) + ": null grids / no slices");
+    SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, std::string(fn) + ": unknown scheme");
+    SVMC_REQUIRE(call_id < (1u << 24), std::string(fn) + ": call_id must fit 24 bits");
+    SVMC_REQUIRE(n_path > 0, std::string(fn) + ": n_path must be positive");
     for (int i = 0; i < n_slices; ++i)
-        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, "svmc_heston_chain_rng: nb_steps and dt must be positive");
+        SVMC_REQUIRE(nb_steps_host[i] > 0 && dts_host[i] > 0.0, std::string(fn) + ": nb_steps and dt must be positive");
     const unsigned g = rng_grid(n_path);
     for (int i0 = 0; i0 < n_slices; i0 += MAX_CHAIN_SLICES) {
         HestonChainSlices cs;
         cs.m = (n_slices - i0 < MAX_CHAIN_SLICES) ? (n_slices - i0) : MAX_CHAIN_SLICES;
         if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * cs.m * sizeof(double))
-            return fail(SVMC_ERR_WORKSPACE, "svmc_heston_chain_rng: workspace too small (svmc_slice_workspace_bytes)");
+            return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
         int steps = 0;
         for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
             const int j = (i < cs.m) ? i0 + i : i0;
@@ -1577,17 +1695,43 @@ int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, i
         if (scheme == SVMC_HESTON_QE)
             hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_QE>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x,
                                var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
-                               static_cast<double *>(workspace));
+                               static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
         else
             hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(g), dim3(rng_block()), 0,
                                as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
-                               xs, qs, static_cast<double *>(workspace));
+                               xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(steps);
     }
     return SVMC_OK;
+}
+
+extern "C" {
+
+int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                          const double *dts_host, const double *forwards_host, double theta, double kappa, double rho,
+                          double volvol, int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset,
+                          uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
+                          void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    return heston_chain_rng_impl("svmc_heston_chain_rng", StateInit(), x, var, qvar, n_path, n_slices, nb_steps_host, dts_host,
+                                 forwards_host, theta, kappa, rho, volvol, scheme, seed, call_id, path_offset, step_offset,
+                                 x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes, stream);
+}
+
+int svmc_heston_chain_rng_from(double x0, double var0, double qvar0, double *x, double *var, double *qvar, size_t n_path,
+                               int n_slices, const int *nb_steps_host, const double *dts_host, const double *forwards_host,
+                               double theta, double kappa, double rho, double volvol, int scheme, uint64_t seed,
+                               uint32_t call_id, uint64_t path_offset, uint32_t step_offset, double *x_snapshots,
+                               double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
+                               svmc_stream_t stream)
+{
+    const StateInit init = {1, x0, var0, qvar0};
+    return heston_chain_rng_impl("svmc_heston_chain_rng_from", init, x, var, qvar, n_path, n_slices, nb_steps_host, dts_host,
+                                 forwards_host, theta, kappa, rho, volvol, scheme, seed, call_id, path_offset, step_offset,
+                                 x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes, stream);
 }
 
 static int rough_logsv_launch(const char *name, double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps,

@@ -13,6 +13,7 @@ class and fails loudly when libsvmc.so or a GPU is missing.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import sys
 import threading
 from typing import List, Optional, Sequence, Tuple
@@ -251,9 +252,12 @@ class HipEngine:
             int(seed), int(call_id), self.path_offset, int(step_offset), self.stream)))
 
     def logsv_slice_rng(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
-                        step_offset, forward, snap_row, qvar_row, spot_ptr) -> None:
-        """advance + snapshot + spot sums of one expiry in one kernel (svmc_logsv_slice_rng)"""
-        self._timed("logsv_rng_kernel", lambda: _lib.check(self.lib.svmc_logsv_slice_rng(
+                        step_offset, forward, snap_row, qvar_row, spot_ptr, start=None) -> None:
+        """advance + snapshot + spot sums of one expiry in one kernel (svmc_logsv_slice_rng).  start = (x0, sigma0, qvar0):
+        every path starts there (svmc_logsv_slice_rng_from: no fill launch, the state buffers are outputs only)"""
+        fn = self.lib.svmc_logsv_slice_rng if start is None else functools.partial(self.lib.svmc_logsv_slice_rng_from,
+                                                                                   *[float(v) for v in start])
+        self._timed("logsv_rng_kernel", lambda: _lib.check(fn(
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
             float(kappa1), float(kappa2), float(beta), float(volvol), float(eta), int(bool(is_spot_measure)),
             int(seed), int(call_id), self.path_offset, int(step_offset), float(forward), self.snapshot_ptr(snap_row),
@@ -262,35 +266,43 @@ class HipEngine:
 
     def logsv_chain_rng(self, nb_steps: Sequence[int], dts: Sequence[float], etas: Sequence[float],
                         forwards: Sequence[float], theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
-                        step_offset, need_qvar: bool, spot_ptr: int) -> None:
+                        step_offset, need_qvar: bool, spot_ptr: int, start=None) -> None:
         """every expiry of a chain in one stepping launch (svmc_logsv_chain_rng): snapshot rows 0..m-1 get the
-        terminal x of each expiry, rows m..2m-1 the quadratic variance (need_qvar), spot_ptr the 2m spot sums"""
+        terminal x of each expiry, rows m..2m-1 the quadratic variance (need_qvar), spot_ptr the 2m spot sums;
+        start = (x0, sigma0, qvar0) as in logsv_slice_rng"""
         m = len(nb_steps)
         dp = C.POINTER(C.c_double)
         nbs = (C.c_int * m)(*[int(v) for v in nb_steps])
         d, e, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (dts, etas, forwards))
-        self._timed("logsv_chain_rng_kernel", lambda: _lib.check(self.lib.svmc_logsv_chain_rng(
+        fn = self.lib.svmc_logsv_chain_rng if start is None else functools.partial(self.lib.svmc_logsv_chain_rng_from,
+                                                                                   *[float(v) for v in start])
+        self._timed("logsv_chain_rng_kernel", lambda: _lib.check(fn(
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, m, nbs, d.ctypes.data_as(dp), e.ctypes.data_as(dp),
             f.ctypes.data_as(dp), float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
             int(bool(is_spot_measure)), int(seed), int(call_id), self.path_offset, int(step_offset), self.snapshot_ptr(0),
             self.snapshot_ptr(m) if need_qvar else None, spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
 
     def heston_chain_rng(self, nb_steps: Sequence[int], dts: Sequence[float], forwards: Sequence[float], theta, kappa,
-                         rho, volvol, scheme, seed, call_id, step_offset, need_qvar: bool, spot_ptr: int) -> None:
-        """every expiry of a Heston chain in one stepping launch (svmc_heston_chain_rng); layout as logsv_chain_rng"""
+                         rho, volvol, scheme, seed, call_id, step_offset, need_qvar: bool, spot_ptr: int, start=None) -> None:
+        """every expiry of a Heston chain in one stepping launch (svmc_heston_chain_rng); layout and `start` as
+        logsv_chain_rng"""
         m = len(nb_steps)
         dp = C.POINTER(C.c_double)
         nbs = (C.c_int * m)(*[int(v) for v in nb_steps])
         d, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (dts, forwards))
-        self._timed("heston_chain_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_chain_rng(
+        fn = self.lib.svmc_heston_chain_rng if start is None else functools.partial(self.lib.svmc_heston_chain_rng_from,
+                                                                                    *[float(v) for v in start])
+        self._timed("heston_chain_rng_kernel", lambda: _lib.check(fn(
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, m, nbs, d.ctypes.data_as(dp), f.ctypes.data_as(dp),
             float(theta), float(kappa), float(rho), float(volvol), int(scheme), int(seed), int(call_id), self.path_offset,
             int(step_offset), self.snapshot_ptr(0), self.snapshot_ptr(m) if need_qvar else None, spot_ptr, self.ws.ptr,
             self.ws_bytes, self.stream)))
 
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
-                         snap_row, qvar_row, spot_ptr) -> None:
-        self._timed("heston_rng_kernel", lambda: _lib.check(self.lib.svmc_heston_slice_rng(
+                         snap_row, qvar_row, spot_ptr, start=None) -> None:
+        fn = self.lib.svmc_heston_slice_rng if start is None else functools.partial(self.lib.svmc_heston_slice_rng_from,
+                                                                                    *[float(v) for v in start])
+        self._timed("heston_rng_kernel", lambda: _lib.check(fn(
             self.x.ptr, self.vol.ptr, self.qvar.ptr, self.n_path, int(nb_steps), float(dt), float(theta),
             float(kappa), float(rho), float(volvol), int(scheme), int(seed), int(call_id), self.path_offset,
             int(step_offset), float(forward), self.snapshot_ptr(snap_row),

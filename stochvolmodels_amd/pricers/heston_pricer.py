@@ -205,16 +205,16 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
         grids.append((nb, dt))
         t0 = ttm
     step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
-    eng.fill_state(0.0, v0, 0.0)
+    start = (0.0, v0, 0.0)     # every path's start state (reference :303-305) goes to the first stepping launch as constants
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         nb, dt = grids[i]
         eng.heston_slice_rng(nb, dt, theta, kappa, rho, volvol, code, rng_seed, call_id, int(step0[i]), forward,
-                             snap_row, qvar_row, spot_ptr)
+                             snap_row, qvar_row, spot_ptr, start=start if i == 0 else None)
 
     def advance_chain(need_qvar: bool, spot_ptr: int) -> None:
         eng.heston_chain_rng([g[0] for g in grids], [g[1] for g in grids], forwards, theta, kappa, rho, volvol, code,
-                             rng_seed, call_id, 0, need_qvar, spot_ptr)
+                             rng_seed, call_id, 0, need_qvar, spot_ptr, start=start)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance,

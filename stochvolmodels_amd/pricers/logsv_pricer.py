@@ -468,16 +468,17 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
         grids.append((nb, dt))
         t0 = ttm
     step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
-    eng.fill_state(0.0, v0, 0.0)
+    start = (0.0, v0, 0.0)     # every path's start state (reference :823-826) goes to the first stepping launch as constants
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
         nb, dt = grids[i]
         eng.logsv_slice_rng(nb, dt, theta, kappa1, kappa2, beta, volvol, float(vol_backbone_etas[i]), is_spot_measure,
-                            rng_seed, call_id, int(step0[i]), forward, snap_row, qvar_row, spot_ptr)
+                            rng_seed, call_id, int(step0[i]), forward, snap_row, qvar_row, spot_ptr,
+                            start=start if i == 0 else None)
 
     def advance_chain(need_qvar: bool, spot_ptr: int) -> None:
         eng.logsv_chain_rng([g[0] for g in grids], [g[1] for g in grids], vol_backbone_etas, forwards, theta, kappa1,
-                            kappa2, beta, volvol, is_spot_measure, rng_seed, call_id, 0, need_qvar, spot_ptr)
+                            kappa2, beta, volvol, is_spot_measure, rng_seed, call_id, 0, need_qvar, spot_ptr, start=start)
 
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
                                  variable_type, advance,

@@ -76,13 +76,17 @@ class FakeEngine:
         self.spot_sums(self.snapshot_ptr(snap_row), forward, spot_ptr)
 
     def logsv_slice_rng(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
-                        step_offset, forward, snap_row, qvar_row, spot_ptr):
+                        step_offset, forward, snap_row, qvar_row, spot_ptr, start=None):
+        if start is not None:
+            self.fill_state(*start)
         self.logsv_rng(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, seed, call_id,
                        step_offset)
         self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
 
     def logsv_chain_rng(self, nb_steps, dts, etas, forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed,
-                        call_id, step_offset, need_qvar, spot_ptr):
+                        call_id, step_offset, need_qvar, spot_ptr, start=None):
+        if start is not None:
+            self.fill_state(*start)
         m, step = len(nb_steps), step_offset
         for i in range(m):
             self.logsv_slice_rng(nb_steps[i], dts[i], theta, kappa1, kappa2, beta, volvol, float(etas[i]), is_spot_measure,
@@ -91,7 +95,9 @@ class FakeEngine:
             step += nb_steps[i]
 
     def heston_chain_rng(self, nb_steps, dts, forwards, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset,
-                         need_qvar, spot_ptr):
+                         need_qvar, spot_ptr, start=None):
+        if start is not None:
+            self.fill_state(*start)
         m, step = len(nb_steps), step_offset
         for i in range(m):
             self.heston_slice_rng(nb_steps[i], dts[i], theta, kappa, rho, volvol, scheme, seed, call_id, step,
@@ -99,7 +105,9 @@ class FakeEngine:
             step += nb_steps[i]
 
     def heston_slice_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset, forward,
-                         snap_row, qvar_row, spot_ptr):
+                         snap_row, qvar_row, spot_ptr, start=None):
+        if start is not None:
+            self.fill_state(*start)
         self.heston_rng(nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset)
         self.finish_slice(forward, snap_row, qvar_row, spot_ptr)
 
