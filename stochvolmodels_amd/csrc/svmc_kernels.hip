@@ -229,6 +229,9 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
+#ifdef SVMC_TAIL_PROBE                                     // tools/r03/tail_probe.py: per-wave start / end stamps instead of the
+    const uint64_t probe_t0 = wall_clock64();              // qvar snapshot (100 MHz s_memrealtime)
+#endif
     double xv = 0.0, s = 1.0, q = 0.0;
     if (active) {
         if (init.uniform) {                                // wave-uniform
@@ -260,6 +263,13 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
         sigma[p] = s;
         qvar[p] = q;
     }
+#ifdef SVMC_TAIL_PROBE
+    if ((threadIdx.x & 63u) == 0u && so.q_snap != nullptr) {
+        so.q_snap[2 * (p >> 6)] = static_cast<double>(probe_t0);
+        so.q_snap[2 * (p >> 6) + 1] = static_cast<double>(wall_clock64());
+    }
+    so.q_snap = nullptr;
+#endif
     slice_epilogue(so, p, active, xv, q);
 }
 
