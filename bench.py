@@ -328,7 +328,9 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
     nb, m = wl["nb_total"], len(wl["grids"])
     hist = isa["kernels"].get(kernel, {})
     prof = pmc.get(kernel, {})
-    alg_bytes = (48.0 + 8.0 * m) * n_local     # 24 B state read + 24 B write per chain, 8 B terminal-x snapshot per expiry
+    # a chain pricing starts every path from the same constants (svmc_*_rng_from): 24 B state written per chain, 8 B terminal-x
+    # snapshot per expiry, no state read
+    alg_bytes = (24.0 + 8.0 * m) * n_local
     traffic = prof.get("hbm_bytes") if prof.get("config") == {"paths": n_local, "steps": nb} else None
     wave_steps = (n_local / 64.0) * nb
     out = {}
@@ -361,11 +363,22 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
         }
         if prof.get("note") and traffic is not None:
             out["roofline"]["traffic_note"] = prof["note"]
+        gui, lds, conf, act = (prof.get(k + "_per_dispatch") for k in ("grbm_gui_active", "sq_lds_idx_active", "sq_lds_bank_conflict",
+                                                                      "sq_active_inst_valu"))
+        if pmc.get("matches_loaded_library") and gui and lds and act:
+            # the second pipe the loop leans on, from the committed counter pass of THIS build: the randomly indexed table reads
+            # of the inverse-CDF draw keep the LDS nearly as busy as the vector ALU
+            cycles = gui / 8.0                                 # GRBM_GUI_ACTIVE counts per XCD
+            out["roofline"]["counters"] = {
+                "valu_busy_frac": 4.0 * act / N_SIMD / cycles,                  # SQ_ACTIVE_INST_VALU ticks in quad-cycles
+                "lds_busy_frac": lds / 256.0 / cycles,                          # SQ_LDS_IDX_ACTIVE: LDS-array cycles, per CU
+                "lds_bank_conflict_share": (conf / lds) if conf else None,
+                "source": "profiles/r03_pmc.json (rocprofv3 --pmc, same library)"}
     hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
     hbm = {"kernel": kernel, "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes, "ms_per_launch": k_ms, "launches": launches,
            "traffic": traffic,
-           "note": "on-device-RNG stepping moves 48 + 8 M bytes per path per chain and nothing inside the time loop: "
+           "note": "on-device-RNG stepping moves 24 + 8 M bytes per path per chain and nothing inside the time loop: "
                    "not HBM-bound by construction"}
     out["roofline_hbm"] = hbm
     if "roofline" not in out:                  # no histogram for this kernel (libsvmc.isa.json missing): report the HBM roof

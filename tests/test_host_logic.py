@@ -306,7 +306,7 @@ def test_bench_workloads_and_roofline_arithmetic():
     assert r["clock_mhz_sensor"] == 2400.0 and r["traffic"] == 59.0e6 and r["stale"] is False
     assert r["insts_per_wave_step_counters"] == 53.2
     rr = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, 2400.0)
-    assert rr["roofline_hbm"]["algorithmic_bytes"] == 56.0 * 2 ** 20
+    assert rr["roofline_hbm"]["algorithmic_bytes"] == 32.0 * 2 ** 20
     # a library that is not the one the histogram describes: stale; counters of another build are not quoted
     stale = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, dict(isa, stale=True),
                                    dict(pmc, matches_loaded_library=False), None)["roofline"]
