@@ -5,17 +5,20 @@ mirror of the reference API and is compared with
   - the CPU oracle on the same inputs / the same Philox stream.
 
 Tolerances (fp64 throughout): the HIP kernels keep the reference's evaluation order but contract a*b+c to
-FMA and use the device libm, so on identical randoms the state agrees to rounding level amplified by the
-path's own dynamics (sigma is an exponential of a sum of ~100-1000 increments): 1e-10 relative on states,
-1e-10 on prices/stderrs.  Normals agree to 1e-14 absolute.  Statistical checks use the reference's own
-criterion |MC - analytic| <= 4 stderr (reference tests/test_logsv_characterization.py:407).
+FMA and use hand-written exp / log / sqrt (<= 1-4 ULP), so on identical randoms the state agrees to rounding level
+amplified by the path's own dynamics (sigma is an exponential of a sum of ~100-1000 increments).  Every tolerance
+below was set from a recording run (SVMC_RECORD_TOLERANCES, tests/conftest.py; the observed deviations are committed as
+profiles/r03_observed_tolerances.txt): the tightest power of ten that is >= 10 x the largest deviation observed, never
+below SURVEY App. B.7's 1e-12 (stepping) -- so 1e-12 on states / sums, ST = 1e-11 on prices and standard errors against
+the reference's golden vectors (numpy's libm on the other side).  Statistical checks use the reference's own criterion
+|MC - analytic| <= 4 stderr (reference tests/test_logsv_characterization.py:407).
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-ST = dict(rtol=1e-10, atol=1e-12)
+ST = dict(rtol=1e-11, atol=1e-13)          # SURVEY App. B.7: prices 1e-11 (stepping states are asserted at 1e-12)
 
 
 def P(v):
@@ -184,8 +187,8 @@ def test_logsv_reference_test_case(sv, golden):
                                                kappa2=p["kappa2"], beta=p["beta"], volvol=p["volvol"], nb_path=n,
                                                W0=W0, W1=W1, dt=float(g["dt"]))
     np.testing.assert_allclose(x[:256], g["x_head"], rtol=1e-11, atol=1e-13)
-    np.testing.assert_allclose(s[:256], g["sigma_head"], rtol=1e-11)
-    np.testing.assert_allclose(q[:256], g["qvar_head"], rtol=1e-11)
+    np.testing.assert_allclose(s[:256], g["sigma_head"], rtol=1e-12)
+    np.testing.assert_allclose(q[:256], g["qvar_head"], rtol=1e-12)
     assert np.all(np.isfinite(x)) and np.all(s > 0) and np.all(q >= 0)
     ttm = float(g["ttm"])
     assert abs(np.mean(np.exp(x)) - 1.0) <= 4.0 * np.std(np.exp(x), ddof=1) / np.sqrt(n)
@@ -239,8 +242,8 @@ def test_heston_euler_nan_variance_propagates(sv, oracle):
     bad = np.zeros(n, dtype=bool)
     bad[[3, 77, 200]] = True
     assert np.all(np.isnan(v[bad])) and np.all(np.isnan(ov[bad])) and np.all(np.isnan(x[bad]))
-    np.testing.assert_allclose(v[~bad], ov[~bad], rtol=1e-10)
-    np.testing.assert_allclose(x[~bad], ox[~bad], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(v[~bad], ov[~bad], rtol=1e-12)
+    np.testing.assert_allclose(x[~bad], ox[~bad], rtol=1e-11, atol=1e-12)
     eng.fill_state(0.0, 0.04, 0.0)
     eng.heston_rng(nb, 0.01, float("nan"), 4.0, -0.5, 0.4, 0, 5, 0, 0)         # theta = NaN
     x, v, q = eng.get_state()
@@ -256,8 +259,8 @@ def test_payoff_vs_reference(sv, golden):
                                            qvar0=g[f"{name}_qvar"], ttm=ttm, forward=fwd,
                                            strikes_ttm=g[f"{name}_strikes"], optiontypes_ttm=g[f"{name}_types"],
                                            discfactor=df, variable_type=sv.VariableType(int(vt)))
-        np.testing.assert_allclose(pr, g[f"{name}_prices"], rtol=1e-11, atol=1e-14, err_msg=str(name))
-        np.testing.assert_allclose(sd, g[f"{name}_stderrs"], rtol=1e-9, atol=1e-14, err_msg=str(name))
+        np.testing.assert_allclose(pr, g[f"{name}_prices"], rtol=1e-12, atol=1e-14, err_msg=str(name))
+        np.testing.assert_allclose(sd, g[f"{name}_stderrs"], rtol=1e-12, atol=1e-14, err_msg=str(name))
 
 
 def test_payoff_reference_known_answers(sv):
@@ -332,8 +335,8 @@ def test_ragged_sizes_and_many_strikes(sv, oracle):
         x, s, q = oracle.logsv_terminal_rng(np.zeros(n), p.sigma0 * np.ones(n), np.zeros(n), nb, dt, p.theta,
                                             p.kappa1, p.kappa2, p.beta, p.volvol, 5)
         opr, osd = oracle.payoff(x, q, 0.05, 1.0, kk, types)
-        np.testing.assert_allclose(pr[0], opr, rtol=1e-9, atol=1e-13)
-        np.testing.assert_allclose(sd[0], osd, rtol=1e-8, atol=1e-13)
+        np.testing.assert_allclose(pr[0], opr, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(sd[0], osd, rtol=1e-12, atol=1e-13)
 
 
 def test_seed_semantics(sv):
@@ -388,9 +391,9 @@ def test_heston_qe(sv, oracle, golden):
         x, v, q = eng.get_state()
         ox, ov, oq = oracle.heston_qe_terminal_w(np.zeros(n), v0 * np.ones(n), np.zeros(n), 0.25 / nb, theta, kappa,
                                                  rho, volvol, Z0, Z1, U)
-        np.testing.assert_allclose(x, ox, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(x, ox, rtol=1e-10, atol=1e-11)
         np.testing.assert_allclose(v, ov, rtol=1e-9, atol=1e-13)
-        np.testing.assert_allclose(q, oq, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(q, oq, rtol=1e-12, atol=1e-13)
         # rng route == oracle rng route
         eng.fill_state(0.0, v0, 0.0)
         eng.heston_rng(nb, 0.25 / nb, theta, kappa, rho, volvol, 1, 3, 0, 0)
@@ -398,7 +401,7 @@ def test_heston_qe(sv, oracle, golden):
         ox, ov, oq = oracle.heston_terminal_rng(np.zeros(n), v0 * np.ones(n), np.zeros(n), nb, 0.25 / nb, theta,
                                                 kappa, rho, volvol, 3, scheme=oracle.HESTON_QE)
         np.testing.assert_allclose(x, ox, rtol=1e-9, atol=1e-11)
-        np.testing.assert_allclose(v, ov, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(v, ov, rtol=1e-11, atol=1e-13)
         eng.close()
         # (b) the scheme against the reference's analytic Heston prices, 4 standard errors, no additive terms: puts
         # without the forward recentring (cases.bounded_put_check -- an honest stderr also for BTC_HESTON_PARAMS, whose
@@ -435,7 +438,7 @@ def test_config_c1_heston_10k_100(sv, oracle):
                                          seed)
     opr, osd = oracle.payoff(x, q, 1.0, 1.0, kk, types)
     np.testing.assert_allclose(pr[0], opr, **ST)
-    np.testing.assert_allclose(sd[0], osd, rtol=1e-9)
+    np.testing.assert_allclose(sd[0], osd, rtol=1e-12)
 
 
 def test_config_c2_full_size_properties(sv, golden):
@@ -449,7 +452,7 @@ def test_config_c2_full_size_properties(sv, golden):
     pricer = sv.LogSVPricer()
     pr, sd = pricer.model_mc_price_chain(chain, p, nb_path=n, nb_steps=1023, seed=20240602)
     call, put = pr[0][:21], pr[0][21:]
-    np.testing.assert_allclose(call - put, 1.0 - kk, atol=1e-10)        # recentring => parity is exact
+    np.testing.assert_allclose(call - put, 1.0 - kk, rtol=0, atol=1e-14)        # recentring => parity is exact
     pr2, sd2 = pricer.model_mc_price_chain(chain, p, nb_path=n, nb_steps=1023, seed=20240602)
     np.testing.assert_array_equal(pr[0], pr2[0])                        # deterministic reductions
     np.testing.assert_array_equal(sd[0], sd2[0])
@@ -484,7 +487,7 @@ def test_ranks_share_one_gpu(oracle, tmp_path, world):
     for r in range(world):
         got = np.load(out + f".rank{r}.npz")
         for key in got.files:
-            np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} rank {r}/{world}")
+            np.testing.assert_allclose(got[key], exp[key], rtol=1e-12, atol=1e-12, err_msg=f"{key} rank {r}/{world}")
 
 
 def test_rccl_group_on_one_rank(oracle, tmp_path):
@@ -510,7 +513,7 @@ def test_rccl_group_on_one_rank(oracle, tmp_path):
         assert p.returncode == 0, p.stdout.decode()
         got = np.load(out + ".rank0.npz")
         for key in got.files:
-            np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=f"{key} ({tag})")
+            np.testing.assert_allclose(got[key], exp[key], rtol=1e-12, atol=1e-12, err_msg=f"{key} ({tag})")
         runs.append({k: got[k] for k in got.files})
     for key in runs[0]:
         np.testing.assert_array_equal(runs[0][key], runs[1][key], err_msg=key)
@@ -550,7 +553,7 @@ def test_rccl_through_the_c_abi_one_rank(oracle, tmp_path):
     assert ok, log
     got = np.load(files[0])
     for key in got.files:
-        np.testing.assert_allclose(got[key], exp[key], rtol=1e-9, atol=1e-12, err_msg=key)
+        np.testing.assert_allclose(got[key], exp[key], rtol=1e-12, atol=1e-12, err_msg=key)
     ok, log, files2 = _run_dist_workers(tmp_path, "torch", 1, 29742, dict(
         SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_EXPECT_BACKEND="nccl"))
     assert ok, log
@@ -780,7 +783,7 @@ def test_vol_paths(sv, oracle, golden):
     for tag, spot in (("spot", True), ("inv", False)):
         sig, grid = sv.simulate_vol_paths(ttm=float(g["ttm"]), nb_path=int(g["n_path"]), nb_steps_per_year=int(g["spy"]),
                                           brownians=g["brownians"], is_spot_measure=spot, **p)
-        np.testing.assert_allclose(sig, g[f"sigma_{tag}"], rtol=1e-11)
+        np.testing.assert_allclose(sig, g[f"sigma_{tag}"], rtol=1e-12)
         np.testing.assert_array_equal(grid, g["grid"])
     t = P(g["test_params"])
     pricer = sv.LogSVPricer()
@@ -798,7 +801,7 @@ def test_vol_paths(sv, oracle, golden):
     osig = oracle.logsv_vol_paths(nb, dt, t["v0"], t["theta"], t["kappa1"], t["kappa2"], t["beta"], t["volvol"], 1000,
                                   seed=12)
     assert sig.shape == (nb + 1, 1000)
-    np.testing.assert_allclose(sig, osig, rtol=1e-11)
+    np.testing.assert_allclose(sig, osig, rtol=1e-12)
 
 
 # ---- analytic side (row a11): libsvmc's Fourier kernels ------------------------------------------------------------
@@ -814,11 +817,11 @@ def test_analytic_logsv_chain(sv, oracle, golden):
             pr = sv.logsv_chain_pricer(params=params, ttms=g["ttms"], forwards=g["forwards"],
                                        discfactors=g["discfactors"], strikes_ttms=strikes, optiontypes_ttms=tuple(ty),
                                        is_spot_measure=spot)
-            np.testing.assert_allclose(np.stack(pr), g[f"{tag}_{mtag}_prices"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(np.stack(pr), g[f"{tag}_{mtag}_prices"], rtol=0, atol=1e-12)
         pr = sv.logsv_chain_pricer(params=params, ttms=g["ttms"], forwards=g["forwards"], discfactors=g["discfactors"],
                                    strikes_ttms=strikes, optiontypes_ttms=tuple(g["types"]),
                                    expansion_order=sv.ExpansionOrder.FIRST)
-        np.testing.assert_allclose(np.stack(pr), g[f"{tag}_first_order_prices"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.stack(pr), g[f"{tag}_first_order_prices"], rtol=0, atol=1e-12)
     # raw coefficients with slice-to-slice carry and a vol backbone
     b = [float(a) for a in g["btc_params"]]
     z = np.zeros(13, dtype=np.complex128)
@@ -826,9 +829,9 @@ def test_analytic_logsv_chain(sv, oracle, golden):
               beta=b[4], volvol=b[5])
     a1, lm1 = sv.compute_logsv_a_mgf_grid(ttm=0.3, vol_backbone_eta=0.9, **kw)
     a2, lm2 = sv.compute_logsv_a_mgf_grid(ttm=0.2, a_t0=a1, vol_backbone_eta=1.1, **kw)
-    np.testing.assert_allclose(a1, g["mgf_a1"], rtol=1e-8, atol=1e-9)
-    np.testing.assert_allclose(a2, g["mgf_a2"], rtol=1e-8, atol=1e-9)
-    np.testing.assert_allclose(lm2, g["mgf_lm2"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(a1, g["mgf_a1"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(a2, g["mgf_a2"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(lm2, g["mgf_lm2"], rtol=1e-10, atol=1e-11)
     # quickstart goldens through the class API
     chain = sv.OptionChain.get_uniform_chain(ttms=np.array([0.25, 0.5]), ids=np.array(["3m", "6m"]),
                                              forwards=np.array([1.0, 1.0]), strikes=np.array([0.8, 0.9, 1.0, 1.1, 1.2]))
@@ -849,7 +852,7 @@ def test_analytic_heston_and_c5_sweep(sv, golden):
         v0, theta, kappa, rho, volvol = (float(v) for v in g[f"heston_{tag}_params"])
         pr = sv.heston_chain_pricer(v0=v0, theta=theta, kappa=kappa, volvol=volvol, rho=rho, ttms=ttms, forwards=one,
                                     strikes_ttms=(kk,) * 4, optiontypes_ttms=(types,) * 4, discfactors=one)
-        np.testing.assert_allclose(np.stack(pr), g[f"heston_{tag}_prices"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.stack(pr), g[f"heston_{tag}_prices"], rtol=0, atol=1e-13)
         hp = sv.HestonParams(v0=v0, theta=theta, kappa=kappa, rho=rho, volvol=volvol)
         chain = sv.OptionChain(ttms=ttms, forwards=one, strikes_ttms=(kk,) * 4, optiontypes_ttms=(types,) * 4, ids=None)
         np.testing.assert_allclose(np.stack(sv.HestonPricer().price_chain(chain, hp)), np.stack(pr), rtol=0, atol=0)
@@ -957,8 +960,8 @@ def test_fixed_randoms_drawn_on_device(sv):
     for u, v in zip(a1 + e1, a2 + e2):
         np.testing.assert_array_equal(u, v)
     b, eb = sv.logsv_mc_chain_pricer(nb_path=n, nb_steps_per_year=360, seed=77, **common, **p)   # (77, call 0): those draws
-    np.testing.assert_allclose(np.concatenate(a1), np.concatenate(b), rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(np.concatenate(e1), np.concatenate(eb), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate(a1), np.concatenate(b), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate(e1), np.concatenate(eb), rtol=1e-12, atol=1e-12)
     res.free()
 
 
@@ -1031,7 +1034,7 @@ def test_implied_vols_from_the_graph(sv, oracle):
             host = black_ivols_native(pr[i], float(ttms[i]), float(common["forwards"][i]), k, ty, float(common["discfactors"][i]))
             assert np.array_equal(np.isnan(iv[i]), np.isnan(host))
             ok = ~np.isnan(host)
-            np.testing.assert_allclose(iv[i][ok], host[ok], rtol=1e-10)
+            np.testing.assert_allclose(iv[i][ok], host[ok], rtol=1e-12)
         assert np.isfinite(np.concatenate(iv)).sum() >= (30 if pp["volvol"] > 1.0 else 8)
     assert np.isnan(np.concatenate(iv)).any()                       # the low-vol set loses its far strikes
     # graph off / per-call upload: the host route gives the same vols
@@ -1040,9 +1043,9 @@ def test_implied_vols_from_the_graph(sv, oracle):
             p["kappa1"], p["kappa2"], p["beta"], p["volvol"], np.ones(4), True, 1)
     on = res.price_logsv_chain(*args, use_graph=True, want_ivols=True)
     off = res.price_logsv_chain(*args, use_graph=False, want_ivols=True)
-    np.testing.assert_allclose(np.concatenate(on[2]), np.concatenate(off[2]), rtol=1e-10)
+    np.testing.assert_allclose(np.concatenate(on[2]), np.concatenate(off[2]), rtol=1e-12)
     _, _, iv_host = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W[0], W1s=W[1], dts=W[2], return_ivols=True, **common, **p)
-    np.testing.assert_allclose(np.concatenate(iv_host), np.concatenate(on[2]), rtol=1e-10)
+    np.testing.assert_allclose(np.concatenate(iv_host), np.concatenate(on[2]), rtol=1e-12)
     with pytest.raises(NotImplementedError):
         sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True,
                                                **dict(common, optiontypes_ttms=(np.where(k >= 1.0, "IC", "P"),) * 4), **p)
@@ -1131,8 +1134,8 @@ def test_config_c4_btc_style_chain(sv, oracle):
                                             step_offset=step0)
         step0, t0, total = step0 + nb, ttm, total + nb
         opr, osd = oracle.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]))
-        np.testing.assert_allclose(pr[i], opr, rtol=1e-9, atol=1e-9 * fw[i], err_msg=f"slice {i}")
-        np.testing.assert_allclose(sd[i], osd, rtol=1e-8, atol=1e-9 * fw[i], err_msg=f"slice {i}")
+        np.testing.assert_allclose(pr[i], opr, rtol=1e-12, atol=1e-13 * fw[i], err_msg=f"slice {i}")
+        np.testing.assert_allclose(sd[i], osd, rtol=1e-12, atol=1e-13 * fw[i], err_msg=f"slice {i}")
     assert total == 1021                                           # sum over the 8 slices of int(dT*1016)+1: the
     #                                                                actual step count is what enters path-steps/s
     # (b) regular chain, full per-rank size
@@ -1148,7 +1151,7 @@ def test_config_c4_btc_style_chain(sv, oracle):
     b, sb = pricer.model_mc_price_chain(chain, P_, nb_path=n, nb_steps=1016, seed=5)
     for i in range(8):
         np.testing.assert_array_equal(a[i], b[i])
-        np.testing.assert_allclose(a[i][:21] - a[i][21:], fw[i] - kk[i], rtol=0, atol=1e-9 * fw[i])   # exact parity
+        np.testing.assert_allclose(a[i][:21] - a[i][21:], fw[i] - kk[i], rtol=0, atol=1e-13 * fw[i])  # exact parity
         assert np.all(np.isfinite(a[i])) and np.all(sa[i] > 0)
     from stochvolmodels_amd.engine import get_engine
     x, s, q = get_engine(n).get_state()
@@ -1198,7 +1201,7 @@ def test_c_host_example(sv, tmp_path):
         np.testing.assert_array_equal(pf[0], out["fixed_prices"][3 * it:3 * it + 3])
     from stochvolmodels_amd.data.option_chain import infer_black_ivols
     iv = infer_black_ivols(np.array(out["fixed_prices"][1:2]), 0.1, 1.0, np.array([1.0]), ["C"], 0.99)
-    np.testing.assert_allclose(out["atm_call_ivol"], iv, rtol=1e-10)
+    np.testing.assert_allclose(out["atm_call_ivol"], iv, rtol=1e-12)
 
 
 def test_reference_heston_and_logsv_mc_ci_tests(sv):
@@ -1251,8 +1254,8 @@ def test_payoff_randomised_against_numpy_semantics(sv, oracle):
             epr, esd = oracle.np_payoff(x, q, ttm, fwd, strikes, types, df, vt)
         pr, sd = sv.compute_mc_vars_payoff(x0=x, sigma0=np.ones(n), qvar0=q, ttm=ttm, forward=fwd, strikes_ttm=strikes,
                                            optiontypes_ttm=types, discfactor=df, variable_type=sv.VariableType(vt))
-        np.testing.assert_allclose(pr, epr, rtol=1e-10, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
-        np.testing.assert_allclose(sd, esd, rtol=1e-8, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
+        np.testing.assert_allclose(pr, epr, rtol=1e-12, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
+        np.testing.assert_allclose(sd, esd, rtol=1e-12, atol=1e-13, err_msg=f"trial {trial} n={n} vt={vt}")
 
 
 @pytest.mark.parametrize("vt", [1, 2])
@@ -1278,8 +1281,8 @@ def test_payoff_every_group_width(sv, oracle, vt):
                 epr, esd = oracle.np_payoff(x, q, ttm, fwd, strikes, types, df, vt)
             pr, sd = sv.compute_mc_vars_payoff(x0=x, sigma0=np.ones(n), qvar0=q, ttm=ttm, forward=fwd, strikes_ttm=strikes,
                                                optiontypes_ttm=types, discfactor=df, variable_type=sv.VariableType(vt))
-            np.testing.assert_allclose(pr, epr, rtol=1e-10, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
-            np.testing.assert_allclose(sd, esd, rtol=1e-8, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
+            np.testing.assert_allclose(pr, epr, rtol=1e-12, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
+            np.testing.assert_allclose(sd, esd, rtol=1e-12, atol=1e-13, err_msg=f"k={k} kinds={kinds} vt={vt}")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -1303,17 +1306,17 @@ def test_rough_logsv_fixed_randoms_vs_reference(sv, golden, tag):
                                                                  nb_steps_per_year=360, seed=10)
     pr, sd = sv.rough_logsv_mc_chain_pricer_fixed_randoms(Z0=Z0, Z1=Z1, timegrids=grids, **kw)
     for i in range(len(kw["ttms"])):
-        np.testing.assert_allclose(pr[i], g[f"{tag}_prices_{i}"], rtol=1e-9, atol=1e-13)
-        np.testing.assert_allclose(sd[i], g[f"{tag}_stderrs_{i}"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(pr[i], g[f"{tag}_prices_{i}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(sd[i], g[f"{tag}_stderrs_{i}"], rtol=1e-12, atol=1e-13)
         if tag == "h010":   # the reference's committed regression prices, at the reference's own tolerance
             np.testing.assert_allclose(pr[i], g[f"reference_regression_prices_{i}"], rtol=1e-7)
     # terminal state of the last expiry is still resident
     from stochvolmodels_amd.engine import get_engine
     eng = get_engine(nb_path)
     ls, _, y = eng.get_state()
-    np.testing.assert_allclose(ls[:128], g[f"{tag}_log_s_head"], rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(eng.get_factors(kw["nodes"].size)[:, :128], g[f"{tag}_vol_head"], rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(y[:128], g[f"{tag}_y_head"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(ls[:128], g[f"{tag}_log_s_head"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(eng.get_factors(kw["nodes"].size)[:, :128], g[f"{tag}_vol_head"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(y[:128], g[f"{tag}_y_head"], rtol=1e-12, atol=1e-11)
 
 
 def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
@@ -1330,8 +1333,8 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
                                                     kw["kappa1"], kw["kappa2"], kw["beta"], kw["orthog_vol"],
                                                     kw["weights"], kw["nodes"], grids)
     for i in range(len(grids)):
-        np.testing.assert_allclose(pr[i], po[i], rtol=1e-9, atol=1e-13)
-        np.testing.assert_allclose(sd[i], so[i], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(pr[i], po[i], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(sd[i], so[i], rtol=1e-12, atol=1e-13)
     # Q_VAR payoffs on the same paths, and the two draws statistically consistent with the fixed-randoms golden
     pq, _ = sv.rough_logsv_mc_chain_pricer(nb_path=n, nb_steps_per_year=360, seed=seed,
                                            variable_type=sv.VariableType.Q_VAR,
@@ -1343,7 +1346,7 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
                                                     kw["sigma0"], kw["theta"], kw["kappa1"], kw["kappa2"], kw["beta"],
                                                     kw["orthog_vol"], kw["weights"], kw["nodes"], grids, variable_type=2)
     for i in range(len(grids)):
-        np.testing.assert_allclose(pq[i], pqo[i], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(pq[i], pqo[i], rtol=1e-12, atol=1e-13)
     for i in range(len(grids)):
         err = np.sqrt(sd[i] ** 2 / n + g[f"h010_stderrs_{i}"] ** 2 / 10000)    # second return = payoff std here
         assert np.all(np.abs(pr[i] - g[f"h010_prices_{i}"]) <= 4.5 * err + 1e-12)
@@ -1357,7 +1360,7 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
     pr2, _ = sv.LogSVPricer().model_mc_price_chain(option_chain=chain, params=params, nb_path=10000, nb_steps=360,
                                                    use_rough_mc=True, seed=10)
     for i in range(4):
-        np.testing.assert_allclose(pr2[i], g[f"h010_prices_{i}"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(pr2[i], g[f"h010_prices_{i}"], rtol=1e-12, atol=1e-13)
     with pytest.raises(AssertionError):
         sv.LogSVPricer().model_mc_price_chain(option_chain=chain, params=params, nb_path=100, use_rough_mc=True)
     p05 = sv.LogSvParams(H=0.5)
@@ -1373,7 +1376,7 @@ def test_rough_logsv_device_rng_and_pricer_route(sv, oracle, golden):
                                                    use_rough_mc=True, seed=10)
     if np.allclose(auto.nodes, kw["nodes"], rtol=1e-6) and np.allclose(auto.weights, kw["weights"], rtol=1e-6):
         for i in range(4):                     # the golden case used this very rule: the same prices
-            np.testing.assert_allclose(pr3[i], g[f"h010_prices_{i}"], rtol=1e-6, atol=1e-10)
+            np.testing.assert_allclose(pr3[i], g[f"h010_prices_{i}"], rtol=1e-12, atol=1e-10)
     assert all(np.all(np.isfinite(p_)) and np.all(p_ >= 0.0) for p_ in pr3)
 
 
@@ -1427,7 +1430,7 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
         fit0 = plain.calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start), disp=False,
                                                      batched_gradient=False, **kw)
         assert plain.last_calibration["n_gradient_batches"] == 0
-        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-12, atol=1e-12)
     if tag in ("mc5", "rough4"):
         # the same calibration on fixed randoms drawn in HBM instead of by NumPy: another sample of the same estimator
         fit_dev = sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start),
@@ -1443,7 +1446,7 @@ def test_logsv_calibration_vs_reference(sv, golden, tag):
         fit0 = plain.calibrate_model_params_to_chain(option_chain=chain, params0=sv.LogSvParams(**start), disp=False,
                                                      batched_gradient=False, **kw)
         assert plain.last_calibration["n_gradient_batches"] == 0
-        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(_vec(fit), _vec(fit0), rtol=1e-12, atol=1e-12)
         assert abs(n_eval_batched - plain.last_calibration["n_eval"]) <= 2
     if tag == "mc4c":       # the constraints hold at the optimum
         assert fit.kappa2 - 2.0 * fit.beta >= -1e-8
@@ -1521,9 +1524,9 @@ def test_rough_cabi_continuation_and_errors(sv, oracle, golden):
     P = oracle._p
     oracle.lib().svo_rough_logsv_terminal_w(n, nb, h, 3, P(np.ascontiguousarray(nodes)), P(np.ascontiguousarray(weights)),
                                             P(v0), 0.347, 1.29, 1.93, 0.8, 3.0, P(ls), P(vol), P(y), P(Z0), P(Z1), n)
-    np.testing.assert_allclose(full[0], ls, rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(full[3], vol, rtol=1e-9, atol=1e-12)
-    np.testing.assert_allclose(full[2], y, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(full[0], ls, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(full[3], vol, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(full[2], y, rtol=1e-12, atol=1e-12)
     with pytest.raises(ValueError):
         eng.rough_logsv(nb, h, np.ones(4), np.ones(4), np.ones(4), 0.3, 1.0, 1.0, 0.5, 1.0)        # 4 factors
     with pytest.raises(ValueError):
@@ -1706,7 +1709,7 @@ def test_heston_analytic_qvar_vs_reference(sv, golden, tag):
     kw = dict(v0=v0, theta=theta, kappa=kappa, volvol=volvol, rho=rho, ttms=g["ttms"], forwards=g["forwards"],
               strikes_ttms=(kk,) * 3, optiontypes_ttms=(ty,) * 3, discfactors=g["discfactors"])
     pr = sv.heston_chain_pricer(variable_type=sv.VariableType.Q_VAR, **kw)
-    np.testing.assert_allclose(np.stack(pr), g[f"{tag}_prices"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.stack(pr), g[f"{tag}_prices"], rtol=1e-10, atol=1e-12)
     chain = sv.OptionChain(ttms=g["ttms"], forwards=g["forwards"], strikes_ttms=(kk,) * 3, optiontypes_ttms=(ty,) * 3,
                            discfactors=g["discfactors"], ids=np.array(["a", "b", "c"]))
     pr2 = sv.HestonPricer().price_chain(chain, sv.HestonParams(v0=v0, theta=theta, kappa=kappa, rho=rho, volvol=volvol),
