@@ -7,10 +7,7 @@
 // transcendentals (DESIGN.md "Rooflines").
 #include "svmc_internal.h"
 
-#include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include <utility>
 #include "svmc_black.h"
 #include "svmc_models.h"
@@ -247,7 +244,7 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
             q = qvar[p];
         }
         double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
-        double s2 = s * s, acc = 0.0, xacc = 0.0;
+        double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
         const double s2_start = s2;
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
         const int quarter = (nb_steps + 3) >> 2;
@@ -261,7 +258,7 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
                     next_stage_t += quarter;
                 }
             });
-        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s * s);
+        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
         x[p] = xv;
         sigma[p] = s;
         qvar[p] = q;
@@ -274,180 +271,6 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     so.q_snap = nullptr;
 #endif
     slice_epilogue(so, p, active, xv, q);
-}
-
-// The same generator as a PERSISTENT launch over dynamically handed-out work units.  A launch of more path groups than
-// the chip holds waves (2^20 paths = 16384 groups of 64 on 8192 wave slots) runs in rounds, and its last round ends in a
-// ramp-down in which late, lone waves run at a quarter of the saturated rate (a lone wave issues one dependent fp64
-// instruction per ~17 cycles): 6-9 % of a 2^20 x 1024 launch (profiles/r03_launch_tail.txt).  Here the time axis of each
-// group is cut into segments of `seg_steps` steps; a unit is (group, segment), units are handed out by atomic ticket
-// counters (one queue per XCD) in the order segment-major, and only as many blocks are launched as the chip holds.  A wave that finishes a
-// unit takes the next ticket; the state of the group (L, acc, xacc: 24 bytes per path) is handed from the wave that ran
-// segment k to whichever wave draws segment k + 1 through the x / sigma / qvar arrays themselves -- which a launch that
-// starts from constants (StateInit.uniform) only writes at the very end -- as agent-scope atomics, published by a
-// per-group flag.  The ramp-down is then bounded by one segment instead of one whole path.  Deadlock-free without any
-// residency assumption: the unit a wave waits for was ticketed EARLIER, i.e. by a wave that is running.
-// Results are the bits of logsv_rng_kernel: the per-step arithmetic is the same and the state round trip is exact
-// (sigma is re-derived as exp2u_tab(L), the very expression that produced it).
-struct DynUnits {
-    unsigned long long *ctl;        // UNITS_* words below; zero between launches (the launch cleans up after itself)
-    uint32_t groups, segments, seg_steps, spin_limit, queues, waves;
-};
-constexpr int UNITS_QUEUE_STRIDE = 32;     // ctl[32 q]: ticket counter of queue q, a 256-byte line each
-constexpr int UNITS_MAX_QUEUES = 8;
-constexpr int UNITS_EXIT_AT = 256;         // waves that have left the launch
-constexpr int UNITS_STUCK_AT = 264;        // [4]: the first wait that gave up (count, unit, flag seen, flag wanted)
-constexpr int UNITS_FLAGS_AT = 288;        // [groups]: segments completed of the group
-
-#ifndef SVMC_UNIT_PRIORITIES
-#define SVMC_UNIT_PRIORITIES 1         // A/B hook: quarter-point progress priorities inside a unit
-#endif
-#ifndef SVMC_UNIT_PREFETCH
-#define SVMC_UNIT_PREFETCH 0           // A/B hook: the next ticket is drawn before the unit's steps instead of after them
-#endif
-#ifndef SVMC_UNITS_SGPRS
-#define SVMC_UNITS_SGPRS SVMC_RNG_SGPRS
-#endif
-#define HW_REG_XCC_ID 20
-
-// one double handed from wave to wave: agent-scope relaxed atomics (sc1 accesses -- coherent across the XCDs' L2s on their
-// own, no L2-wide write-back / invalidate), ordered against the flag by the waits below
-__device__ __forceinline__ void unit_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double unit_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// A wave's ticket: ONE atomic add by lane 0 (exec narrowed inside the asm), its old value broadcast.  Written out because
-// none of the source-level forms survives the compiler: `if (lane == 0) atomicAdd(..., 1)` followed by readfirstlane has the
-// lane-0 path threaded through the loop body (the readfirstlane then reads lane 1's zero and the wave never leaves unit 0:
-// tools/ubench/handoff_probe.hip), and an add by every lane -- of (lane == 0 ? 1 : 0), or of 1 with ticket = old / 64 -- is
-// left as 64 serialised atomics per ticket inside the loop (7 x slower launches).  `counter` must be wave-uniform and the
-// wave whole.
-__device__ __forceinline__ uint32_t unit_ticket(unsigned long long *counter)
-{
-    unsigned long long old, saved;
-    asm volatile("s_mov_b64 %1, exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "global_atomic_add_x2 %0, %2, %3, %4 sc0\n\t"
-                 "s_mov_b64 exec, %1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(old), "=&s"(saved)
-                 : "v"(0u), "v"(1ull), "s"(counter)
-                 : "memory");
-    return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(old));
-}
-
-__global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(SVMC_UNITS_SGPRS))) void logsv_rng_units_kernel(
-    double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, int nb_steps, LogsvFast c,
-    uint64_t seed, uint32_t c3, uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init, DynUnits du)
-{
-    __shared__ RngTablesLds s_tab;
-    __shared__ double s_exp[256];
-    const RngTables tab = stage_tables(s_tab, s_exp);
-    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };
-    const uint32_t lane_id = threadIdx.x & 63u;
-    // queue q holds the groups g = q (mod queues), segment-major; a wave starts on the queue of its XCD (tickets and
-    // hand-offs then stay inside one L2) and moves on to the next queue when its own is exhausted, until all are
-    uint32_t q = 0, failed = 0;
-    if (du.queues > 1u) q = (__builtin_amdgcn_s_getreg(HW_REG_XCC_ID | (0 << 6) | ((4 - 1) << 11)) & 15u) % du.queues;
-    uint32_t pending = unit_ticket(du.ctl + UNITS_QUEUE_STRIDE * q);
-    unsigned long long *const flags = du.ctl + UNITS_FLAGS_AT;
-    for (;;) {
-        const uint32_t u = pending;
-        const uint32_t count_q = (du.groups - q + du.queues - 1u) / du.queues;
-        if (u >= count_q * du.segments) {
-            if (++failed == du.queues) break;
-            q = (q + 1u == du.queues) ? 0u : q + 1u;
-            pending = unit_ticket(du.ctl + UNITS_QUEUE_STRIDE * q);
-            continue;
-        }
-        const uint32_t k = u / count_q, g = q + du.queues * (u - k * count_q);
-        const size_t p = static_cast<size_t>(g) * 64u + lane_id;
-        const bool active = p < n;
-        const bool first = k == 0u, last = k + 1u == du.segments;
-        if (!first) {
-            uint32_t polls = 0;
-            unsigned long long seen;
-            while ((seen = __hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != k) {
-                if (++polls > du.spin_limit) {             // a unit that never completes: say so and go on, do not hang
-                    if (unit_ticket(du.ctl + UNITS_STUCK_AT) == 0u && lane_id == 0u) {
-                        du.ctl[UNITS_STUCK_AT + 1] = (static_cast<unsigned long long>(q) << 32) | u;
-                        du.ctl[UNITS_STUCK_AT + 2] = seen;
-                        du.ctl[UNITS_STUCK_AT + 3] = k;
-                    }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            asm volatile("" ::: "memory");                 // the state loads below are issued after the flag was seen
-        }
-        double xv = 0.0, q_var = 0.0;
-        double L = 0.0, s = 1.0, acc = 0.0, xacc = 0.0;
-        if (active) {
-            if (first) {
-                s = init.vol0;
-                L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
-            } else {
-                L = unit_load(x + p);
-                acc = unit_load(sigma + p);
-                xacc = unit_load(qvar + p);
-            }
-        }
-#if SVMC_UNIT_PREFETCH
-        pending = unit_ticket(du.ctl + UNITS_QUEUE_STRIDE * q);               // in flight while this unit steps
-#endif
-        if (active) {
-            if (!first) s = exp_of(L);
-            double s2 = 0.0;
-            const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
-            const int t0 = static_cast<int>(k * du.seg_steps);
-            const int nb = last ? nb_steps - t0 : static_cast<int>(du.seg_steps);
-#if SVMC_UNIT_PRIORITIES
-            const int quarter = (nb + 3) >> 2;
-            int stage = 0, next_stage_t = 0;
-            rng_time_loop(
-                lane, step_offset + static_cast<uint32_t>(t0), nb, tab,
-                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); },
-                [&](int t) {
-                    if (t >= next_stage_t) {               // wave-uniform
-                        progress_priority(stage++);
-                        next_stage_t += quarter;
-                    }
-                });
-#else
-            rng_time_loop(lane, step_offset + static_cast<uint32_t>(t0), nb, tab,
-                          [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); });
-#endif
-            if (last) {
-                xv = init.x0;
-                q_var = init.qvar0;
-                logsv_fold_acc(c, xv, q_var, xacc, acc, init.vol0 * init.vol0, s * s);
-                x[p] = xv;
-                sigma[p] = s;
-                qvar[p] = q_var;
-            } else {
-                unit_store(x + p, L);
-                unit_store(sigma + p, acc);
-                unit_store(qvar + p, xacc);
-            }
-        }
-        if (last) {
-            slice_epilogue(so, p, active, xv, q_var);
-            if (!first && lane_id == 0u)                                // the group is done: its flag is zero for the next launch
-                __hip_atomic_store(flags + g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the whole wave's state stores are acknowledged ...
-            if (lane_id == 0u)                                          // ... then the flag
-                __hip_atomic_store(flags + g, static_cast<unsigned long long>(k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#if !SVMC_UNIT_PREFETCH
-        pending = unit_ticket(du.ctl + UNITS_QUEUE_STRIDE * q);
-#endif
-    }
-    // the last wave out zeroes the ticket counters: the next launch of the context starts clean, with the same arguments
-    if (unit_ticket(du.ctl + UNITS_EXIT_AT) == du.waves - 1u && lane_id == 0u) {
-        for (uint32_t i = 0; i < du.queues; ++i)
-            __hip_atomic_store(du.ctl + UNITS_QUEUE_STRIDE * i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(du.ctl + UNITS_EXIT_AT, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 // All expiries of a chain in ONE stepping launch: the slice loop runs inside the kernel, each slice with its own
@@ -524,7 +347,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
             // would be divergent values (vector registers, exec-masked branches in the time loop)
             const LogsvFast c = cs.c[i];
             double L = log_state(s) * LOG_UNITS_PER_NAT;                                              // :1039
-            double s2 = s * s, acc = 0.0, xacc = 0.0;
+            double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
             const double s2_start = s2;
             rng_time_loop(
                 lane, step_offset + static_cast<uint32_t>(tg), nb, tab,
@@ -537,7 +360,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
                 });
             xv = s_park[threadIdx.x];                      // a lane reads back what it alone wrote: no barrier needed
             q = s_park[CHAIN_BLOCK + threadIdx.x];
-            logsv_fold_acc(c, xv, q, xacc, acc, s2_start, s * s);
+            logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
             s_park[threadIdx.x] = xv;
             s_park[CHAIN_BLOCK + threadIdx.x] = q;
         }
@@ -1399,75 +1222,6 @@ int svmc_fill_uniforms(double *U, size_t ldw, size_t n_path, int nb_steps, uint6
     return check_launch("svmc_fill_uniforms");
 }
 
-// ---- persistent launches over dynamic units (logsv_rng_units_kernel) ------------------------------------------------
-// One control block per (device, stream): launches on a stream are ordered, so they can share the ticket counters and the
-// flag array; a launch leaves both zeroed, so nothing is reset in between and the kernel arguments do not change.
-namespace {
-
-struct UnitsContext {
-    unsigned long long *dev = nullptr;         // UNITS_* layout of svmc::DynUnits::ctl
-    size_t groups_cap = 0;
-};
-
-std::mutex g_units_mutex;
-std::map<std::pair<int, hipStream_t>, UnitsContext> g_units;
-int g_cu_count[64] = {};
-
-int env_int(const char *name, int fallback)
-{
-    const char *v = getenv(name);
-    return (v != nullptr && *v != '\0') ? atoi(v) : fallback;
-}
-
-}  // namespace
-
-// decides whether a generator launch runs as dynamic units; blocks = 0: no (the one-round kernel)
-static int plan_units(const StateInit &init, size_t n_path, int nb_steps, hipStream_t stream, DynUnits &du, unsigned &blocks)
-{
-    blocks = 0;
-    static const int seg_env = env_int("SVMC_UNIT_STEPS", 0);       // 0 (default): off -- measured slower than the one-round kernel
-    static const int queues_env = env_int("SVMC_UNIT_QUEUES", UNITS_MAX_QUEUES);
-    static const int force_env = env_int("SVMC_UNIT_FORCE", 0);     // experiments: also launches of one segment / one round
-    if (!init.uniform || seg_env <= 0) return SVMC_OK;
-    int device = 0;
-    SVMC_HIP_TRY(hipGetDevice(&device));
-    if (device < 0 || device >= 64) return SVMC_OK;
-    std::lock_guard<std::mutex> lock(g_units_mutex);
-    if (g_cu_count[device] == 0)
-        SVMC_HIP_TRY(hipDeviceGetAttribute(&g_cu_count[device], hipDeviceAttributeMultiprocessorCount, device));
-    const size_t wave_slots = static_cast<size_t>(g_cu_count[device]) * 32u;            // 8 waves on each of 4 SIMDs
-    const size_t groups = wave_rows(n_path);
-    const int seg = (seg_env + 1) & ~1;                                                  // even: whole Philox calls
-    if (!force_env && (groups <= wave_slots || nb_steps < 2 * seg)) return SVMC_OK;
-    if (groups >= (1ull << 24)) return SVMC_OK;
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    SVMC_HIP_TRY(hipStreamIsCapturing(stream, &capturing));
-    if (capturing != hipStreamCaptureStatusNone) return SVMC_OK;        // a graph may replay on another stream: no shared block
-    UnitsContext &ctx = g_units[std::make_pair(device, stream)];
-    if (ctx.groups_cap < groups) {
-        if (ctx.dev != nullptr) SVMC_HIP_TRY(hipFree(ctx.dev));         // synchronises: rare (the first launch of a size)
-        ctx.dev = nullptr;
-        const size_t cap = groups + groups / 2;
-        SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.dev), (UNITS_FLAGS_AT + cap) * sizeof(unsigned long long)));
-        SVMC_HIP_TRY(hipMemsetAsync(ctx.dev, 0, (UNITS_FLAGS_AT + cap) * sizeof(unsigned long long), stream));
-        ctx.groups_cap = cap;
-    }
-    const int segments = (nb_steps + seg - 1) / seg;
-    const int per = (((nb_steps + segments - 1) / segments) + 1) & ~1;                   // even, segments of equal length
-    du.ctl = ctx.dev;
-    du.groups = static_cast<uint32_t>(groups);
-    du.seg_steps = static_cast<uint32_t>(per);
-    du.segments = static_cast<uint32_t>((nb_steps + per - 1) / per);
-    du.queues = static_cast<uint32_t>(queues_env < 1 ? 1 : (queues_env > UNITS_MAX_QUEUES ? UNITS_MAX_QUEUES : queues_env));
-    if (du.queues > du.groups) du.queues = 1;
-    const size_t resident = wave_slots / (rng_block() / 64);
-    blocks = static_cast<unsigned>(resident < rng_grid(n_path) ? resident : rng_grid(n_path));
-    du.waves = blocks * (rng_block() / 64);
-    static const int spin_env = env_int("SVMC_UNIT_SPIN_LIMIT", 1 << 24);     // ~ 20 s of polling
-    du.spin_limit = static_cast<uint32_t>(spin_env);
-    return SVMC_OK;
-}
-
 static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qvar, size_t n_path, int nb_steps,
                             double dt, double theta, double kappa1, double kappa2, double beta, double volvol,
                             double vol_backbone_eta, int is_spot_measure, uint64_t seed, uint32_t call_id,
@@ -1479,28 +1233,6 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (n_path == 0) return SVMC_OK;
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
-    DynUnits du;
-    unsigned blocks = 0;
-    if (int rc = plan_units(init, n_path, nb_steps, as_stream(stream), du, blocks)) return rc;
-    if (blocks != 0u) {
-        hipLaunchKernelGGL(logsv_rng_units_kernel, dim3(blocks), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                           n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, du);
-        if (int rc = check_launch(fn)) return rc;
-        static const int debug_env = env_int("SVMC_UNITS_DEBUG", 0);
-        if (debug_env) {                                   // synchronises: what the launch left in the control block
-            unsigned long long diag[UNITS_FLAGS_AT];
-            SVMC_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
-            SVMC_HIP_TRY(hipMemcpy(diag, du.ctl, sizeof(diag), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[svmc units] %u groups x %u segments of %u steps, %u queues, %u blocks: counters left %llu %llu exit %llu, waits given up %llu",
-                    du.groups, du.segments, du.seg_steps, du.queues, blocks, diag[0], diag[UNITS_QUEUE_STRIDE], diag[UNITS_EXIT_AT],
-                    diag[UNITS_STUCK_AT]);
-            if (diag[UNITS_STUCK_AT] != 0)
-                fprintf(stderr, " -- first: queue/unit %llx saw flag %llu, wanted %llu", diag[UNITS_STUCK_AT + 1], diag[UNITS_STUCK_AT + 2],
-                        diag[UNITS_STUCK_AT + 3]);
-            fprintf(stderr, "\n");
-        }
-        return SVMC_OK;
-    }
     hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
                        n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init);
     return check_launch(fn);

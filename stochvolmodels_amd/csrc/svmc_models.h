@@ -152,6 +152,18 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc,
     (void)s2;                                     // sigma^2 is not carried: the fold squares the terminal sigma itself
 }
 
+// sigma^2 as a rounded product of its own: without this the compiler may fuse the multiplication into the subtraction of
+// logsv_fold_acc (s2_start - sigma_T^2 as one FMA) in one kernel and not in another -- whichever way the inlined code around
+// it falls -- and the one-slice, whole-chain and streamed generators must agree to the bit (a persistent-launch variant of
+// the generator differed from the one-round kernel in 180 of 2^20 paths by exactly this, profiles/r03_launch_tail.txt)
+__device__ __forceinline__ double square_rn(double v)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return v * v;
+}
+
 // fold the accumulator of logsv_step_acc into x and qvar (s2_start = sigma^2 when acc was last zero); a path whose
 // sigma overflowed keeps the reference's outcome (x -> -+inf, qvar -> inf) instead of inf - inf
 __device__ __forceinline__ void logsv_fold_acc(const LogsvFast &f, double &x, double &qvar, double xacc, double acc,
