@@ -1143,10 +1143,22 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
 {
     __shared__ double lds[4];
     const int j = blockIdx.x;
-    // four rows per trip, their loads in flight together (a row is one 8-byte read at a stride of ld: latency, not
-    // bandwidth); fixed order of additions, hence deterministic
+    // four rows per trip into four accumulators; fixed order of additions, hence deterministic.  A row is one 8-byte read
+    // at a stride of ld -- latency, not bandwidth -- so the loads of FOUR trips are put in flight together where that many
+    // remain (the whole-chain generators leave 2^15 rows: 32 round trips per thread became 8, 35 us became ~10); the
+    // additions keep the order of the one-trip loop, so the sums are the same bits
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     int r = threadIdx.x;
+    for (; r + 15 * BLOCK < n_rows; r += 16 * BLOCK) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += t[4 * k + u];
+        }
+    }
     for (; r + 3 * BLOCK < n_rows; r += 4 * BLOCK) {
         double t[4];
 #pragma unroll

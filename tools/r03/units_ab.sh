@@ -1,3 +1,4 @@
+# (goes with commit e53a51a, where the dynamic-units launch lived: SVMC_UNIT_* are read by that build only)
 # A/B of the dynamic-units launch against the one-round kernel (tools/ubench/build_variants.sh builds the libraries)
 run() { # lib, env...
   local lib=$1; shift

@@ -1,4 +1,5 @@
-"""A/B of the dynamic-units launch of the LogSV generator (SVMC_UNIT_STEPS=0: one-round kernel): kernel time by HIP events
+"""(goes with commit e53a51a, where the dynamic-units launch lived: SVMC_UNIT_* are read by that build only)
+A/B of the dynamic-units launch of the LogSV generator (SVMC_UNIT_STEPS=0: one-round kernel): kernel time by HIP events
 and a digest of the outputs (x, sigma, qvar, snapshot, spot sums) -- the two launch forms must agree to the bit.
 usage: [SVMC_UNIT_STEPS=...] units_probe.py [log2 sizes ...] [--steps N]"""
 import ctypes as C, hashlib, json, os, sys
