@@ -176,16 +176,16 @@ __device__ __forceinline__ void progress_priority(int stage)
 
 // Optional slice epilogue fused into the stepping kernels: the terminal x (and qvar) is also written to the
 // per-expiry snapshot the payoff pass reads, and [sum F*exp(x), count] (utils/mc_payoffs.py:61-62) goes out as one row PER
-// WAVE -- partials[wave][ld], wave = global thread index / 64 -- which reduce_columns_kernel adds up in row order: one
+// WAVE -- partials[column][wave], wave = global thread index / 64 -- which reduce_columns_kernel adds up in row order: one
 // launch and one pass over x less per expiry.  Rows per wave, not per block: the sum's order of additions is then the same
 // whatever block size a kernel runs (the one-slice generators run 512-thread blocks, the whole-chain kernel 1024, the
 // streamed ones 256, and their results must agree to the bit), and the epilogue needs no LDS and no barrier.
 struct SliceOut {
     double *x_snap;     // nullable
     double *q_snap;     // nullable
-    double *partials;   // nullable: [wave_rows(n)][ld], this slice's pair at the row start
+    double *partials;   // nullable: this slice's two COLUMNS, [2][rows] -- column-major, so that the reduction reads them coalesced
     double forward;
-    int ld = 2;         // doubles per wave row of `partials` (2 * slices for the whole-chain kernel)
+    size_t rows = 0;    // column stride of `partials`: wave_rows(n) of the launch
 };
 
 static inline unsigned wave_rows(size_t n) { return static_cast<unsigned>((n + 63) / 64); }
@@ -209,10 +209,9 @@ __device__ __forceinline__ void slice_epilogue(const SliceOut &so, size_t p, boo
         const double sp = so.forward * exp_full(xv);       // full-range exp: x = +-inf must give inf / 0   :61
         const bool ok = active && (sp == sp);                                                   // nanmean :62
         const double v0 = wave_sum(ok ? sp : 0.0), v1 = wave_sum(ok ? 1.0 : 0.0);
-        if ((threadIdx.x & 63u) == 0u) {
-            double *row = so.partials + static_cast<size_t>(so.ld) * (p >> 6);
-            row[0] = v0;
-            row[1] = v1;
+        if ((threadIdx.x & 63u) == 0u && (p >> 6) < so.rows) {        // a launch's last block may hold waves past the last path
+            so.partials[p >> 6] = v0;
+            so.partials[so.rows + (p >> 6)] = v1;
         }
     }
 }
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
         }
         tg += nb;
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
-                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+                             partials + 2 * static_cast<size_t>(i) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
         slice_epilogue(so, path_index(), active, xv, q);
     }
     if (active) {
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_indirect_kernel(double *_
             });
         }
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
-                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+                             partials + 2 * static_cast<size_t>(i) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
         slice_epilogue(so, p, active, xv, q);
         __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
     }
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_sets_kernel(size_t n, Cha
         for (int s = 0; s < P; ++s) {
             const int row = s * cs.m + i;
             const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
-                                 partials + 2 * row, cs.forward[i], 2 * rows};
+                                 partials + 2 * static_cast<size_t>(row) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
             slice_epilogue(so, p, active, xv[s], q[s]);
             __syncthreads();                               // the epilogue's LDS scratch is reused by the next one
         }
@@ -928,7 +927,7 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
         }
         step += static_cast<uint32_t>(nb);
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
-                             partials + 2 * i, cs.forward[i], 2 * cs.m};
+                             partials + 2 * static_cast<size_t>(i) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
         slice_epilogue(so, p, active, xv, q);
     }
     if (active) {
@@ -1138,11 +1137,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
 }
 
 // out[j] = sum_r partials[r * ld + j]; one block per column j
-__global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials, int n_rows,
-                                                               int ld, double *__restrict__ out)
+// element (row r, column j) sits at partials[r * row_stride + j * col_stride]: row-major block partials pass (ld, 1), the
+// generators' per-wave spot partials are column-major and pass (1, rows)
+__global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials_base, int n_rows,
+                                                               size_t row_stride, size_t col_stride, double *__restrict__ out)
 {
     __shared__ double lds[4];
     const int j = blockIdx.x;
+    const double *__restrict__ partials = partials_base + static_cast<size_t>(j) * col_stride;
+    const size_t ld = row_stride;
     // four rows per trip into four accumulators; fixed order of additions, hence deterministic.  A row is one 8-byte read
     // at a stride of ld -- latency, not bandwidth -- so the loads of FOUR trips are put in flight together where that many
     // remain (the whole-chain generators leave 2^15 rows: 32 round trips per thread became 8, 35 us became ~10); the
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
     for (; r + 15 * BLOCK < n_rows; r += 16 * BLOCK) {
         double t[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld + j];
+        for (int u = 0; u < 16; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -1162,11 +1165,11 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
     for (; r + 3 * BLOCK < n_rows; r += 4 * BLOCK) {
         double t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld + j];
+        for (int u = 0; u < 4; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] += t[u];
     }
-    for (; r < n_rows; r += BLOCK) a[0] += partials[static_cast<size_t>(r) * ld + j];
+    for (; r < n_rows; r += BLOCK) a[0] += partials[static_cast<size_t>(r) * ld];
     double v[1] = {(a[0] + a[1]) + (a[2] + a[3])};
     block_sum_store<1>(v, lds, out + j, 1);
 }
@@ -1254,7 +1257,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
 static int finish_slice_sums(const char *fn, unsigned block_rows, double *spot_sums, void *workspace, svmc_stream_t stream)
 {
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
-                       static_cast<const double *>(workspace), static_cast<int>(block_rows), 2, spot_sums);
+                       static_cast<const double *>(workspace), static_cast<int>(block_rows), size_t(1), static_cast<size_t>(block_rows), spot_sums);
     return check_launch(fn);
 }
 
@@ -1289,7 +1292,7 @@ static int logsv_slice_rng_impl(const char *fn, const StateInit &init, double *x
 {
     if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                   vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream, init))
         return rc;
@@ -1358,7 +1361,7 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
                            cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
                            (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(cs.total_steps);
     }
@@ -1428,7 +1431,7 @@ int svmc_logsv_slice_w(double *x, double *sigma, double *qvar, size_t n_path, in
     const char *fn = "svmc_logsv_slice_w";
     if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_logsv_slice_w: n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = logsv_w_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                 vol_backbone_eta, is_spot_measure, W0, W1, ldw, so, stream))
         return rc;
@@ -1457,7 +1460,7 @@ int logsv_slice_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
     if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
     if (W0 == nullptr || W1 == nullptr || ldw < n_path || nb_steps <= 0 || n_path == 0)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad randoms / sizes");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     hipLaunchKernelGGL(logsv_w_indirect_kernel, dim3(grid_for(n_path)), dim3(BLOCK), 0, stream, x, sigma, qvar, n_path,
                        nb_steps, reinterpret_cast<const LogsvConsts *>(consts_dev), W0, W1, ldw, so);
     if (int rc = check_launch(fn)) return rc;
@@ -1493,7 +1496,7 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                        reinterpret_cast<const LogsvConsts *>(consts_dev), vol0_dev, ldw, x_snapshots, qvar_snapshots,
                        static_cast<double *>(workspace));
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_slices), dim3(BLOCK), 0, stream,
-                       static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * n_slices, spot_sums);
+                       static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
 }
 
@@ -1541,7 +1544,7 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
     default: launch_chain_w_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
     }
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
-                       static_cast<int>(wave_rows(n_path)), cols, spot_sums);
+                       static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
 }
 
@@ -1650,7 +1653,7 @@ static int heston_slice_rng_impl(const char *fn, const StateInit &init, double *
 {
     if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
                                    call_id, path_offset, step_offset, so, stream, init))
         return rc;
@@ -1723,7 +1726,7 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
                                as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
                                xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), 2 * cs.m, spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(steps);
     }
@@ -1833,7 +1836,7 @@ int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, size_t n_pa
     const char *fn = "svmc_rough_logsv_slice";
     if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, "svmc_rough_logsv_slice: n_path and nb_steps must be positive");
-    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward};
+    const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = rough_logsv_launch(fn, log_s, vol, qvar, n_path, nb_steps, h, n_factors, nodes_host, weights_host,
                                     v0_host, theta, kappa1, kappa2, rho, volvol, Z0, Z1, ldw, seed, call_id,
                                     path_offset, step_offset, from_origin, so, stream))
@@ -1895,7 +1898,7 @@ int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_
     double *partials = static_cast<double *>(workspace);
     hipLaunchKernelGGL(spot_sums_kernel, dim3(g), dim3(BLOCK), 0, as_stream(stream), x, n_path, forward, partials);
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream), partials, static_cast<int>(g),
-                       2, spot_sums);
+                       size_t(2), size_t(1), spot_sums);
     return check_launch("svmc_spot_sums");
 }
 
@@ -1962,7 +1965,7 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
         else
             launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(gx), 3 * cols, sums + 3 * first_strike);
+                           static_cast<int>(gx), static_cast<size_t>(3 * cols), size_t(1), sums + 3 * first_strike);
         first_strike += static_cast<size_t>(cols);
         n_groups = cols = kt = 0;
         has_inv = false;
