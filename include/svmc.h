@@ -290,6 +290,10 @@ SVMC_API int svmc_payoff_sums_chain(const double *const *x_snapshots_host, const
                                     size_t workspace_bytes, svmc_stream_t stream);
 SVMC_API int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, size_t n_strikes,
                          double discfactor, double n_path_total, double *prices_host, double *stderrs_host);
+/* the same for all the strikes of a chain in one call: discfactors_host[k] is the discount factor of strike k's expiry
+ * (the host mirror's chain driver finalises 8 x 21 strikes in one call instead of eight) */
+SVMC_API int svmc_payoff_finalize_chain(const double *sums_host, const double *shifts_host, const double *discfactors_host,
+                               size_t n_strikes, double n_path_total, double *prices_host, double *stderrs_host);
 
 /* ---- fused single-GPU chain drivers: one call per option chain -----------------------------------------------
  * logsv_mc_chain_pricer (pricers/logsv_pricer.py:806-867) and heston_mc_chain_pricer (pricers/heston_pricer.py:

@@ -115,6 +115,7 @@ def _declare(L: C.CDLL) -> None:
         "svmc_heston_chain_price": ([vp, pf64, pf64, pf64, i32, pf64, pi8, psz, f64, f64, f64, f64, f64, i32, i32, i32,
                                      u64, u32, pf64, pf64], i32),
         "svmc_payoff_finalize": ([pf64, pf64, sz, f64, f64, pf64, pf64], i32),
+        "svmc_payoff_finalize_chain": ([pf64, pf64, pf64, sz, f64, pf64, pf64], i32),
         "svmc_rccl_available": ([], i32),
         "svmc_rccl_origin": ([], C.c_char_p),
         "svmc_rccl_unique_id": ([vp, sz], i32),

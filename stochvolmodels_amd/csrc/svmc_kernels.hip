@@ -2050,4 +2050,14 @@ int svmc_payoff_finalize(const double *sums_host, const double *shifts_host, siz
     return SVMC_OK;
 }
 
+int svmc_payoff_finalize_chain(const double *sums_host, const double *shifts_host, const double *discfactors_host,
+                               size_t n_strikes, double n_path_total, double *prices_host, double *stderrs_host)
+{
+    SVMC_REQUIRE(sums_host && discfactors_host && prices_host && stderrs_host, "svmc_payoff_finalize_chain: null pointer");
+    for (size_t k = 0; k < n_strikes; ++k)
+        payoff_finalize_one(sums_host[3 * k], sums_host[3 * k + 1], sums_host[3 * k + 2], shifts_host ? shifts_host[k] : 0.0,
+                            discfactors_host[k], n_path_total, prices_host + k, stderrs_host + k);
+    return SVMC_OK;
+}
+
 }  // extern "C"

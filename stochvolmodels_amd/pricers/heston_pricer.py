@@ -21,7 +21,7 @@ from ..engine import HESTON_EULER_FLOOR, HESTON_QE, get_engine
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
-from ..utils.funcs import next_rng_call, set_time_grid, timer
+from ..utils.funcs import next_rng_call, set_time_grid, time_grid_steps, timer
 from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
 from ..utils import mgf_pricer as mgfp
 from .logsv_pricer import _broadcast_state
@@ -102,7 +102,7 @@ class HestonPricer(ModelPricer):
     def simulate_terminal_values(self, params: HestonParams, ttm: float = 1.0, nb_path: int = 100000,
                                  x0: float = 0.0, **kwargs) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """returns (x, VARIANCE, qvar) like the reference (:89-108); the x0 argument is ignored there too."""
-        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=360)
+        nb_steps, dt = time_grid_steps(ttm=ttm, nb_steps_per_year=360)
         rng_seed, call_id = next_rng_call(kwargs.get("seed"))
         eng = get_engine(nb_path)
         eng.fill_state(0.0, params.v0, 0.0)           # constant initial state written on the device (reference :98-107)
@@ -172,7 +172,7 @@ def simulate_heston_x_vol_terminal(ttm: float, x0: np.ndarray, var0: np.ndarray,
     eng = get_engine(nb_path)
     eng.set_state(x0, var0, qvar0)
     if W0 is None and W1 is None:
-        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
+        nb_steps, dt = time_grid_steps(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
         rng_seed, call_id = next_rng_call(seed)
         eng.heston_rng(nb_steps, dt, theta, kappa, rho, volvol, code, rng_seed, call_id, 0)
     else:
@@ -201,7 +201,7 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
     rng_seed, call_id = next_rng_call(seed)
     grids, t0 = [], 0.0
     for ttm in ttms:
-        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
         grids.append((nb, dt))
         t0 = ttm
     step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])

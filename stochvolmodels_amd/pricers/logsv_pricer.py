@@ -23,7 +23,7 @@ from ..engine import DeviceRandoms, get_engine, option_type_codes, payoff_finali
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
-from ..utils.funcs import next_rng_call, set_time_grid, timer
+from ..utils.funcs import next_rng_call, set_time_grid, time_grid_steps, timer
 from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
 from ..utils import mgf_pricer as mgfp
 from .logsv.affine_expansion import ExpansionOrder, _order_code
@@ -332,7 +332,7 @@ class LogSVPricer(ModelPricer):
                                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         # same as simulate_logsv_x_vol_terminal(x0=zeros, sigma0=sigma0*ones, qvar0=zeros, ...) (reference :600-610),
         # with the constant initial state written on the device instead of uploaded
-        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=360)
+        nb_steps, dt = time_grid_steps(ttm=ttm, nb_steps_per_year=360)
         rng_seed, call_id = next_rng_call(kwargs.get("seed"))
         eng = get_engine(nb_path)
         eng.fill_state(0.0, params.sigma0, 0.0)
@@ -417,7 +417,7 @@ def simulate_logsv_x_vol_terminal(ttm: float, x0: np.ndarray, sigma0: np.ndarray
     eng = get_engine(nb_path)
     eng.set_state(x0, sigma0, qvar0)
     if W0 is None and W1 is None:
-        nb_steps, dt, _ = set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
+        nb_steps, dt = time_grid_steps(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
         rng_seed, call_id = next_rng_call(seed)
         eng.logsv_rng(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure,
                       rng_seed, call_id, 0)
@@ -464,10 +464,12 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
     rng_seed, call_id = next_rng_call(seed)
     grids, t0 = [], 0.0
     for ttm in ttms:
-        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
         grids.append((nb, dt))
         t0 = ttm
-    step0 = np.concatenate([[0], np.cumsum([g[0] for g in grids])])
+    step0 = [0]
+    for g in grids:
+        step0.append(step0[-1] + g[0])
     start = (0.0, v0, 0.0)     # every path's start state (reference :823-826) goes to the first stepping launch as constants
 
     def advance(i: int, forward: float, snap_row: int, qvar_row, spot_ptr: int) -> None:
@@ -492,7 +494,7 @@ def get_randoms_for_chain_valuation(ttms: np.ndarray, nb_path: int = 100000, nb_
     rng = np.random.RandomState(seed)
     W0s, W1s, dts, t0 = [], [], [], 0.0
     for ttm in ttms:
-        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
         W0s.append(rng.normal(0, 1, size=(nb, nb_path)))
         W1s.append(rng.normal(0, 1, size=(nb, nb_path)))
         dts.append(dt)
@@ -520,7 +522,7 @@ def draw_fixed_randoms_on_device(ttms: np.ndarray, nb_path: int = 100000, nb_ste
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     grids, t0 = [], 0.0
     for ttm in ttms:
-        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
+        nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
         grids.append((nb, dt))
         t0 = ttm
     get_engine(n_local, path_offset=offset)               # the library and the device are up before the first launch

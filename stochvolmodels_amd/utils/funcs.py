@@ -28,6 +28,15 @@ def set_time_grid(ttm: float, nb_steps_per_year: int = 360) -> Tuple[int, float,
     return nb_steps, float(dt), grid_t
 
 
+def time_grid_steps(ttm: float, nb_steps_per_year: int = 360) -> Tuple[int, float]:
+    """(nb_steps, dt) of set_time_grid without building the grid: the second point of an (nb_steps + 1)-point
+    np.linspace over [0, ttm] is 1.0 * (ttm / nb_steps) + 0.0, i.e. exactly ttm / nb_steps (tests/test_host_logic.py checks
+    it against set_time_grid bit for bit).  The chain drivers call this once per expiry ahead of their first launch,
+    where np.linspace's 5 us per expiry were time with nothing queued on the GPU."""
+    nb_steps = int(ttm * nb_steps_per_year) + 1
+    return nb_steps, float(ttm) / nb_steps
+
+
 # ---------------------------------------------------------------------------------------------------
 # seeding.  The reference seeds Numba's hidden per-thread MT19937 (set_seed) and its high-level wrappers
 # expose no seed.  Here the generators are counter-based (Philox4x32-7 keyed by a 64-bit seed and a

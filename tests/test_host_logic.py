@@ -28,6 +28,37 @@ def test_time_grid_rule(golden):
         assert (nb, d) == (int(n), dt) and grid.shape == (nb + 1,) and grid[0] == 0.0
 
 
+def test_time_grid_steps_is_the_grid_rule_without_the_grid(golden):
+    """the chain drivers' (nb_steps, dt) must be set_time_grid's, bit for bit: the reference-generated cases and a sweep"""
+    cases = [(float(t), int(s)) for t, s, _, _ in golden("time_grid")["cases"]]
+    rng = np.random.default_rng(3)
+    cases += [(float(rng.random() * 3.0), int(rng.integers(1, 4000))) for _ in range(3000)]
+    cases += [(k / 8.0, 1016) for k in range(1, 9)] + [(0.125, 1016), (1.0 / 52, 1016), (1e-5, 360), (0.0, 360)]
+    for ttm, spy in cases:
+        nb, dt, _ = funcs.set_time_grid(ttm, spy)
+        assert funcs.time_grid_steps(ttm, spy) == (nb, dt), (ttm, spy)
+
+
+def test_payoff_finalize_chain_equals_the_per_expiry_calls():
+    """svmc_payoff_finalize_chain (all strikes of a chain, one discount factor per strike) against svmc_payoff_finalize
+    expiry by expiry: the same arithmetic per strike, hence the same bits -- NaN sums and empty counts included"""
+    from stochvolmodels_amd.engine import payoff_finalize, payoff_finalize_chain
+    rng = np.random.default_rng(1)
+    counts = [13, 1, 21, 5]
+    sums = rng.random(3 * sum(counts)) + 1.0
+    sums[2::3] = 1e5
+    sums[5], sums[3], sums[11] = 0.0, np.nan, 0.0              # 0 / 0 and NaN must come out as NumPy's nanmean gives them
+    shifts = [rng.random(k) for k in counts]
+    dfs = rng.random(len(counts))
+    p, e = payoff_finalize_chain(sums, np.concatenate(shifts), np.repeat(dfs, counts), 1e5)
+    lo = 0
+    for k, sh, df in zip(counts, shifts, dfs):
+        a, b = payoff_finalize(sums[3 * lo:3 * (lo + k)], sh, df, 1e5)
+        np.testing.assert_array_equal(p[lo:lo + k], a)
+        np.testing.assert_array_equal(e[lo:lo + k], b)
+        lo += k
+
+
 def test_option_codes_and_errors():
     np.testing.assert_array_equal(option_type_codes(np.array(["C", "P", "IC", "IP"])), [0, 1, 2, 3])
     with pytest.raises(ValueError, match="payoff"):            # utils/mc_payoffs.py:84
