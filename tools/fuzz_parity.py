@@ -51,7 +51,7 @@ def main(n_cases=None, seed=None):
     if seed is None:
         seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
-    worst = 0.0
+    worst, ranking = 0.0, []
     for case in range(n_cases):
         model = ("logsv", "heston")[case % 2]
         m = int(rng.integers(1, 7))
@@ -91,8 +91,15 @@ def main(n_cases=None, seed=None):
             ok = np.isfinite(y)
             err = np.max(np.abs(x[ok] - y[ok]) / (np.abs(y[ok]) + 1e-8), initial=0.0)
             worst = max(worst, err)
+            if err > 0.0:
+                k = int(np.argmax(np.where(ok, np.abs(x - y) / (np.abs(y) + 1e-8), 0.0)))
+                ranking.append((err, case, model, vt.name, kw.get("is_spot_measure", True), kw.get("scheme", ""),
+                                str(np.asarray(kw["optiontypes_ttms"][[id(p) for p in a].index(id(x))])[k]), float(y[k]),
+                                float(x[k] - y[k])))
             assert err < 1e-8 and np.array_equal(np.isfinite(x), ok), (case, model, err, x, y)
         print(f"case {case:3d} {model:6s} m={m} n={kw['nb_path']:5d} {vt.name:10s} ok")
+    for err, case, model, vname, spot, scheme, ty, price, diff in sorted(ranking, reverse=True)[:8]:
+        print(f"  worst: {err:.2e} case {case} {model} {scheme} {vname} spot_measure={spot} type {ty} oracle price {price:.6e} gpu - oracle {diff:+.2e}")
     print(f"{n_cases} cases, worst relative deviation from the CPU oracle {worst:.2e}")
     return worst
 
