@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.svo_rough_logsv_terminal_w.restype = None
         L.svo_logsv_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, f64, i32, i32, f64, _dp, _dp, f64, f64]
         L.svo_logsv_mgf_grid.restype = None
+        L.svo_logsv_ode_rhs.argtypes = [f64, f64, f64, f64, f64, i32, i32, f64, _dp, _dp, _dp, _dp]
+        L.svo_logsv_ode_rhs.restype = None
         L.svo_heston_mgf_grid.argtypes = [sz, _dp, _dp, f64, f64, f64, f64, f64, f64, _dp, _dp, i32, _dp]
         L.svo_heston_mgf_grid.restype = None
         L.svo_mgf_qvar_slice.argtypes = [sz, _dp, _dp, f64, sz, _dp, C.POINTER(C.c_int8), f64, _dp]
@@ -363,6 +365,17 @@ def logsv_mgf_grid(phi, psi, ttm, sigma0, theta, kappa1, kappa2, beta, volvol, a
                              int(bool(is_spot_measure)), int(expansion_order), float(vol_backbone_eta), _cp(a), _cp(lm),
                              rtol, atol)
     return a, lm
+
+
+def logsv_ode_rhs(phi, psi, A, theta, kappa1, kappa2, beta, volvol, is_spot_measure=True, expansion_order=2, eta=1.0):
+    """A' of the affine-expansion coefficient ODE at one grid point (svmc_oracle_analytic.c ode_rhs)"""
+    ph = np.array([complex(phi).real, complex(phi).imag])
+    ps = np.array([complex(psi).real, complex(psi).imag])
+    a = np.ascontiguousarray(np.asarray(A, dtype=np.complex128))
+    out = np.empty(5, dtype=np.complex128)
+    lib().svo_logsv_ode_rhs(theta, kappa1, kappa2, beta, volvol, int(bool(is_spot_measure)), int(expansion_order), eta,
+                            _p(ph), _p(ps), _cp(a), _cp(out))
+    return out
 
 
 def heston_mgf_grid(phi, psi, ttm, v0, theta, kappa, volvol, rho, a_t0=None, b_t0=None):

@@ -115,6 +115,10 @@ void svo_rough_logsv_terminal_w(size_t n_path, int nb_steps, double h, int n_fac
                                 const double *Z1, size_t ldw);
 
 /* ---- analytic side (svmc_oracle_analytic.c); complex arrays are interleaved (re, im) like numpy.complex128 ---- */
+/* the right-hand side of that ODE on its own (A, out: 5 complex numbers as (re, im) pairs): the check of the device's
+ * one-component-per-lane form (stochvolmodels_amd/csrc/svmc_ode.h) */
+void svo_logsv_ode_rhs(double theta, double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
+                       int expansion_order, double eta, const double *phi, const double *psi, const double *A, double *out);
 void svo_logsv_mgf_grid(size_t n_grid, const double *phi, const double *psi, double ttm, double sigma0, double theta,
                         double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
                         int expansion_order, double vol_backbone_eta, double *a, double *log_mgf, double rtol, double atol);

@@ -88,6 +88,21 @@ static void ode_rhs(const ode_consts *c, cd phi, cd psi, const cd A[5], cd out[5
     }
 }
 
+/* the right-hand side on its own: tests/test_math_accuracy.py checks the device's one-component-per-lane rows
+ * (stochvolmodels_amd/csrc/svmc_ode.h) against it.  A and out: 5 complex numbers as (re, im) pairs. */
+void svo_logsv_ode_rhs(double theta, double kappa1, double kappa2, double beta, double volvol, int is_spot_measure,
+                       int expansion_order, double eta, const double *phi, const double *psi, const double *A, double *out)
+{
+    const ode_consts c = make_ode_consts(theta, kappa1, kappa2, beta, volvol, is_spot_measure, expansion_order, eta);
+    cd a[5], o[5];
+    for (int i = 0; i < 5; ++i) a[i] = A[2 * i] + I * A[2 * i + 1];
+    ode_rhs(&c, phi[0] + I * phi[1], psi[0] + I * psi[1], a, o);
+    for (int i = 0; i < 5; ++i) {
+        out[2 * i] = creal(o[i]);
+        out[2 * i + 1] = cimag(o[i]);
+    }
+}
+
 /* Dormand-Prince 5(4), FSAL, per-component mixed error scale, RMS norm; returns the number of accepted steps */
 static int dopri5(const ode_consts *c, cd phi, cd psi, double ttm, cd y[5], double rtol, double atol)
 {

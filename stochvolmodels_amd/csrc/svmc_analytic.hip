@@ -1,34 +1,23 @@
 // svmc_analytic.hip -- the analytic (Fourier) side of the chain pricers on gfx950: SURVEY.md row a11 / config C5.
 //
-//   logsv_mgf_grid_kernel     one lane per transform-grid point Phi_j: the 5-dim complex quadratic ODE
-//                             A' = A^T M A + L A + H of the affine expansion (pricers/logsv/affine_expansion.py:
-//                             67-205, 229-303, 570-685), integrated from the previous expiry's A with an embedded
-//                             Dormand-Prince 5(4) pair and per-lane step control; log E = sum_k A_k (sigma0-theta)^k
+//   logsv_mgf_grid_kernel     one 16-lane DPP row per transform-grid point Phi_j, one COMPONENT per lane: the 5-dim
+//                             complex quadratic ODE A' = A^T M A + L A + H of the affine expansion (pricers/logsv/
+//                             affine_expansion.py:67-205, 229-303, 570-685; svmc_ode.h), integrated from the previous
+//                             expiry's A with an embedded Dormand-Prince 5(4) pair and per-point step control;
+//                             log E = sum_k A_k (sigma0-theta)^k
 //   heston_mgf_grid_kernel    closed-form Heston MGF (pricers/heston_pricer.py:183-214)
 //   mgf_vanilla_slice_kernel  one block per strike: Simpson-weighted sum over the grid of
 //                             Re[ w_j / (pi (p_j^2 + 1/4)) exp(-x_K Phi_j + log E_j) ]   (utils/mgf_pricer.py:174-221)
 //
 // The reference runs a Python loop of 1000 scipy.solve_ivp calls per expiry (~4 s); here every grid point is a
-// lane and an expiry is one launch.  The work is tiny (1000 lanes) and latency-bound; it is on the GPU so that the
+// row of lanes and an expiry is one launch.  The work is tiny (1000 points) and latency-bound; it is on the GPU so that the
 // analytic-vs-MC sweep of config C5 needs no host ODE solver.  CPU twin: oracle/svmc_oracle_analytic.c.
 #include "svmc_internal.h"
 #include "svmc_math.h"
+#include "svmc_ode.h"
 
 namespace svmc {
 
-struct cd {
-    double re, im;
-};
-__device__ __forceinline__ cd C(double re, double im = 0.0) { return cd{re, im}; }
-__device__ __forceinline__ cd operator+(cd a, cd b) { return cd{a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cd operator-(cd a, cd b) { return cd{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cd operator-(cd a) { return cd{-a.re, -a.im}; }
-__device__ __forceinline__ cd operator*(cd a, cd b) { return cd{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cd operator*(double s, cd a) { return cd{s * a.re, s * a.im}; }
-__device__ __forceinline__ cd operator+(cd a, double s) { return cd{a.re + s, a.im}; }
-__device__ __forceinline__ cd operator+(double s, cd a) { return cd{a.re + s, a.im}; }
-__device__ __forceinline__ cd operator-(cd a, double s) { return cd{a.re - s, a.im}; }
-__device__ __forceinline__ cd operator-(double s, cd a) { return cd{s - a.re, -a.im}; }
 __device__ __forceinline__ double cabs_(cd a) { return hypot(a.re, a.im); }
 __device__ __forceinline__ cd operator/(cd a, cd b)
 {
@@ -52,72 +41,42 @@ __device__ __forceinline__ cd csqrt_(cd z)   // principal branch
 }
 __device__ __forceinline__ cd clog_(cd z) { return cd{log(cabs_(z)), atan2(z.im, z.re)}; }
 
-struct OdeConsts {
-    double theta, theta2, vartheta2, qv, qv2, b, eta2, lamda, kappa2_p, kappa_p;
-    int spot, second;
-};
+// ---- one grid point per 16-lane DPP row ---------------------------------------------------------------------------
+constexpr int ODE_ROW = 16;                 // lanes per grid point: components 0..4 work, 5..15 ride along on zero rows
+constexpr int ODE_POINTS_PER_BLOCK = 4;     // a block is one wave
 
-// pricers/logsv/affine_expansion.py:126-182
-inline OdeConsts make_ode_consts(double theta, double kappa1, double kappa2, double beta, double volvol,
-                                 int is_spot_measure, int expansion_order, double eta)
+// lane N of the caller's row, to every lane of the row: v_mov_b32_dpp row_newbcast (two per double).  All 16 lanes of a row
+// take every branch together, so the source lane is always enabled.
+template <int N>
+__device__ __forceinline__ double row_bcast(double v)
 {
-    OdeConsts c;
-    c.theta = theta;
-    c.theta2 = theta * theta;
-    c.vartheta2 = beta * beta + volvol * volvol;
-    c.qv = theta * c.vartheta2;
-    c.qv2 = c.theta2 * c.vartheta2;
-    c.b = beta * eta;
-    c.eta2 = eta * eta;
-    c.spot = is_spot_measure;
-    c.second = (expansion_order == 2);
-    if (is_spot_measure) {
-        c.lamda = 0.0;
-        c.kappa2_p = kappa2;
-        c.kappa_p = kappa1 + kappa2 * theta;
-    } else {
-        c.lamda = beta * c.theta2 * eta;
-        c.kappa2_p = kappa2 - beta * eta;
-        c.kappa_p = kappa1 + kappa2 * theta - 2.0 * beta * theta * eta;
-    }
-    return c;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ cd row_bcast(cd v)
+{
+    return cd{row_bcast<N>(v.re), row_bcast<N>(v.im)};
 }
 
-// A' = A^T M^(k) A + L^(k) A + H^(k): the non-zero entries of :146-182 written out
-__device__ __forceinline__ void ode_rhs(const OdeConsts &c, cd phi, cd psi, const cd (&A)[5], cd (&out)[5])
+// the lane's derivative at the state whose component it holds in `v`
+__device__ __forceinline__ cd ode_rhs_row(const OdeLane &k, cd v, bool second)
 {
-    const double qv = c.qv, qv2 = c.qv2, v2 = c.vartheta2, th = c.theta, th2 = c.theta2;
-    const cd bphi = c.b * phi;
-    const cd A1 = A[1], A2 = A[2];
-    const cd rhs = (c.spot ? phi * (phi + 1.0) : phi * (phi - 1.0)) - 2.0 * psi;
-    const cd L01 = c.lamda - th2 * bphi;
-    const cd L11 = -c.kappa_p - 2.0 * th * bphi, L12 = 2.0 * ((c.lamda + qv) - th2 * bphi);
-    const cd L21 = -c.kappa2_p - bphi, L22 = (v2 - 2.0 * c.kappa_p) - 4.0 * th * bphi;
-    const cd A11 = A1 * A1, A12 = A1 * A2, A22 = A2 * A2;
-    out[0] = 0.5 * qv2 * A11 + L01 * A1 + qv2 * A2 + 0.5 * th2 * c.eta2 * rhs;
-    out[1] = qv * A11 + 2.0 * qv2 * A12 + L11 * A1 + L12 * A2 + th * c.eta2 * rhs;
-    out[2] = 0.5 * v2 * A11 + 2.0 * qv2 * A22 + 4.0 * qv * A12 + L21 * A1 + L22 * A2 + 0.5 * c.eta2 * rhs;
-    if (c.second) {
-        const cd A3 = A[3], A4 = A[4];
-        const cd kb = c.kappa2_p + bphi;
-        const cd L23 = 3.0 * (2.0 * qv - th2 * bphi);
-        const cd L33 = 3.0 * ((v2 - c.kappa_p) - 2.0 * th * bphi), L34 = 4.0 * (3.0 * qv - th2 * bphi);
-        const cd A13 = A1 * A3, A14 = A1 * A4, A23 = A2 * A3, A24 = A2 * A4;
-        out[1] = out[1] + 3.0 * qv2 * A3;
-        out[2] = out[2] + 3.0 * qv2 * A13 + L23 * A3 + 6.0 * qv2 * A4;
-        out[3] = 4.0 * qv * A22 + 2.0 * v2 * A12 + 6.0 * qv * A13 + 4.0 * qv2 * A14 + 6.0 * qv2 * A23 - 2.0 * (kb * A2) +
-                 L33 * A3 + L34 * A4;
-        out[4] = 2.0 * v2 * A22 + 4.5 * qv2 * (A3 * A3) + 3.0 * v2 * A13 + 8.0 * qv * A14 + 12.0 * qv * A23 + 8.0 * qv2 * A24 -
-                 3.0 * (kb * A3) + 2.0 * (L22 * A4);
-    } else {
-        out[3] = C(0.0);
-        out[4] = C(0.0);
+    const cd A1 = row_bcast<1>(v), A2 = row_bcast<2>(v);
+    cd A3 = C(0.0), A4 = C(0.0);
+    if (second) {                                          // wave-uniform
+        A3 = row_bcast<3>(v);
+        A4 = row_bcast<4>(v);
     }
+    return ode_rhs_lane(k, A1, A2, A3, A4, second);
 }
 
-// Dormand-Prince 5(4), FSAL, mixed error scale, RMS norm -- the CPU twin's dopri5() (same tableau, same controller; the
-// error norm and the step factor are evaluated as noted below)
-__device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5], double rtol, double atol)
+// Dormand-Prince 5(4), FSAL, mixed error scale, RMS norm over the five components -- the CPU twin's dopri5() (same tableau,
+// same controller), each lane carrying ONE component: y, the seven stage derivatives and the trial states are single
+// complex numbers here.  The error norm is the sum of the five lanes' terms taken in component order by every lane of the
+// row, so the whole row sees the same number and takes the same decision.
+__device__ void dopri5_row(const OdeLane &k, bool second, double ttm, cd &y, double rtol, double atol)
 {
     constexpr double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
                      a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729,
@@ -125,64 +84,44 @@ __device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
                      a65 = -5103.0 / 18656, b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784,
                      b6 = 11.0 / 84, e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
                      e6 = 22.0 / 525, e7 = -1.0 / 40;
-    cd k1[5], k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], yt[5], yn[5];
     double t = 0.0, h = ttm / 32.0;
     int tries = 0;
-    ode_rhs(c, phi, psi, y, k1);
+    cd k1 = ode_rhs_row(k, y, second);
     while (t < ttm && tries < 1000000) {
         ++tries;
         if (t + h > ttm) h = ttm - t;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a21 * k1[i]);
-        ode_rhs(c, phi, psi, yt, k2);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
-        ode_rhs(c, phi, psi, yt, k3);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
-        ode_rhs(c, phi, psi, yt, k4);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
-        ode_rhs(c, phi, psi, yt, k5);
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            yt[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
-        ode_rhs(c, phi, psi, yt, k6);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) yn[i] = y[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
-        ode_rhs(c, phi, psi, yn, k7);
-        // the error norm of the twin, err = sqrt(mean_i (|e_i| / sc_i)^2) with sc_i = atol + rtol max(|y_i|, |yn_i|), kept
-        // SQUARED: one square root per component (of the larger squared modulus) instead of three hypot() calls, and the
-        // step factor 0.9 err^(-1/5) = 0.9 exp(-0.1 ln err^2) from the package's own exp / log -- a fifth of the 2100
-        // instructions of a step were the libm hypot / pow of this block
-        double err2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const cd e = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
-            const double m2 = fmax(fma(y[i].re, y[i].re, y[i].im * y[i].im), fma(yn[i].re, yn[i].re, yn[i].im * yn[i].im));
-            const double sc = fma(rtol, sqrt_pos0_1g(m2), atol);
-            err2 += fma(e.re, e.re, e.im * e.im) * rcp_1n(sc * sc);
-        }
+        const cd k2 = ode_rhs_row(k, y + h * (a21 * k1), second);
+        const cd k3 = ode_rhs_row(k, y + h * (a31 * k1 + a32 * k2), second);
+        const cd k4 = ode_rhs_row(k, y + h * (a41 * k1 + a42 * k2 + a43 * k3), second);
+        const cd k5 = ode_rhs_row(k, y + h * (a51 * k1 + a52 * k2 + a53 * k3 + a54 * k4), second);
+        const cd k6 = ode_rhs_row(k, y + h * (a61 * k1 + a62 * k2 + a63 * k3 + a64 * k4 + a65 * k5), second);
+        const cd yn = y + h * (b1 * k1 + b3 * k3 + b4 * k4 + b5 * k5 + b6 * k6);
+        const cd k7 = ode_rhs_row(k, yn, second);
+        // the twin's err = sqrt(mean_i (|e_i| / sc_i)^2) with sc_i = atol + rtol max(|y_i|, |yn_i|), kept SQUARED: one square
+        // root per component (of the larger squared modulus), and the step factor 0.9 err^(-1/5) = 0.9 exp(-0.1 ln err^2)
+        // from the package's own exp / log
+        const cd e = h * (e1 * k1 + e3 * k3 + e4 * k4 + e5 * k5 + e6 * k6 + e7 * k7);
+        const double m2 = fmax(fma(y.re, y.re, y.im * y.im), fma(yn.re, yn.re, yn.im * yn.im));
+        const double sc = fma(rtol, sqrt_pos0_1g(m2), atol);
+        const double term = fma(e.re, e.re, e.im * e.im) * rcp_1n(sc * sc);
+        const double err2 = (((row_bcast<0>(term) + row_bcast<1>(term)) + row_bcast<2>(term)) + row_bcast<3>(term)) + row_bcast<4>(term);
         const double err_sq = err2 * 0.2;                                   // err^2
-        if (err_sq <= 1.0) {
+        if (err_sq <= 1.0) {                               // row-uniform
             t += h;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                y[i] = yn[i];
-                k1[i] = k7[i];
-            }
+            y = yn;
+            k1 = k7;
         }
         const double fac = (err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0;
         h *= fmin(5.0, fmax(0.2, fac));
     }
 }
 
-constexpr int AB = 64;  // one wave per block: 1000 grid points spread over 16 CUs
+constexpr int AB = 64;  // one wave per block
 constexpr int MAX_ODE_SETS = 16;       // parameter sets per launch (kernel-argument block: 16 x 112 B)
 
 // The parameter sets of one launch: blockIdx.y picks the set, every set has its own transform grid (the grid scale
-// follows sigma0), coefficients and output.  One set's 1000 lanes occupy 16 of the chip's 1024 SIMDs for the latency
-// of its slowest lane; independent sets -- the five of config C5, the bumps of a finite-difference gradient -- cost
+// follows sigma0), coefficients and output.  One set's 1000 points are 250 one-wave blocks, busy for the latency of
+// their slowest point; independent sets -- the five of config C5, the bumps of a finite-difference gradient -- cost
 // nothing extra side by side.
 struct OdeBatch {
     OdeConsts c[MAX_ODE_SETS];
@@ -194,23 +133,37 @@ __global__ __launch_bounds__(AB) void logsv_mgf_grid_kernel(const cd *__restrict
                                                             cd *__restrict__ a, cd *__restrict__ log_mgf, double rtol,
                                                             double atol)
 {
-    const size_t j = static_cast<size_t>(blockIdx.x) * AB + threadIdx.x;
-    if (j >= n_grid) return;
+    const int comp = threadIdx.x & (ODE_ROW - 1);
+    const size_t j = static_cast<size_t>(blockIdx.x) * ODE_POINTS_PER_BLOCK + (threadIdx.x / ODE_ROW);
+    if (j >= n_grid) return;                               // whole rows leave together
     const OdeConsts c = sets.c[blockIdx.y];
     const double y0 = sets.y0[blockIdx.y];
     const size_t g = static_cast<size_t>(blockIdx.y) * n_grid + j;     // this set's grid point
-    const int n = c.second ? 5 : 3;
-    cd A[5] = {C(0.0), C(0.0), C(0.0), C(0.0), C(0.0)};
-    for (int k = 0; k < n; ++k) A[k] = a[g * n + k];
-    dopri5(c, phi[g], psi[g], ttm, A, rtol, atol);
-    cd lm = C(0.0);
-    double yk = 1.0;
-    for (int k = 0; k < n; ++k) {
-        a[g * n + k] = A[k];
-        lm = lm + yk * A[k];                                          // affine_expansion.py:674-685
+    const bool second = c.second != 0;
+    const int n = second ? 5 : 3;
+    const bool mine = comp < n;
+    const OdeLane k = make_ode_lane(c, phi[g], psi[g], mine ? comp : -1);
+    cd y = mine ? a[g * n + comp] : C(0.0);
+    dopri5_row(k, second, ttm, y, rtol, atol);
+    if (mine) a[g * n + comp] = y;
+    // log E = sum_k A_k (sigma0 - theta)^k, affine_expansion.py:674-685, in component order
+    const cd A0 = row_bcast<0>(y), A1 = row_bcast<1>(y), A2 = row_bcast<2>(y), A3 = row_bcast<3>(y), A4 = row_bcast<4>(y);
+    if (comp == 0) {
+        cd lm = C(0.0);
+        double yk = 1.0;
+        lm = lm + yk * A0;
         yk *= y0;
+        lm = lm + yk * A1;
+        yk *= y0;
+        lm = lm + yk * A2;
+        if (second) {
+            yk *= y0;
+            lm = lm + yk * A3;
+            yk *= y0;
+            lm = lm + yk * A4;
+        }
+        log_mgf[g] = lm;
     }
-    log_mgf[g] = lm;
 }
 
 __global__ __launch_bounds__(AB) void heston_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
@@ -338,7 +291,8 @@ int svmc_logsv_mgf_grid_batch(const double *phi, const double *psi, size_t n_gri
             sets.y0[i] = p[0] - p[1];
         }
         const size_t off = static_cast<size_t>(s0) * n_grid;
-        hipLaunchKernelGGL(logsv_mgf_grid_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB), static_cast<unsigned>(m)),
+        hipLaunchKernelGGL(logsv_mgf_grid_kernel,
+                           dim3(static_cast<unsigned>((n_grid + ODE_POINTS_PER_BLOCK - 1) / ODE_POINTS_PER_BLOCK), static_cast<unsigned>(m)),
                            dim3(AB), 0, as_stream(stream), reinterpret_cast<const cd *>(phi) + off,
                            reinterpret_cast<const cd *>(psi) + off, n_grid, ttm, sets, reinterpret_cast<cd *>(a) + off * n_coef,
                            reinterpret_cast<cd *>(log_mgf) + off, rtol, atol);

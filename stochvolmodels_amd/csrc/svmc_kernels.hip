@@ -557,7 +557,6 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_sets_kernel(size_t n, Cha
         sg[s] = init[s];
         q[s] = 0.0;
     }
-    const int rows = cs.m * P;
     for (int i = 0; i < cs.m; ++i) {
         __syncthreads();                                   // everybody is done with the previous slice's constants
         {

@@ -189,3 +189,34 @@ def test_log_state(probe):
     got = _call(probe, "probe_log_state", np.array([0.0, np.inf, np.nan, -1.0, -np.inf, 1.0, 5e-324]))
     assert got[0] == -np.inf and got[1] == np.inf and np.isnan(got[2]) and np.isnan(got[3]) and np.isnan(got[4])
     assert got[5] == 0.0 and abs(got[6] - np.log(5e-324)) < 1e-12
+
+
+def test_ode_rows_equal_the_twins_right_hand_side(tmp_path_factory, oracle):
+    """svmc_ode.h: the LogSV coefficient ODE one component per lane (make_ode_lane + ode_rhs_lane, host build) against the CPU
+    twin's right-hand side (oracle/svmc_oracle_analytic.c ode_rhs): both measures, both expansion orders, backbones"""
+    so = str(tmp_path_factory.mktemp("probe") / "libode_probe.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "stochvolmodels_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "ode_probe.cpp"), "-o", so], check=True)
+    lib = C.CDLL(so)
+    lib.probe_ode_rhs_lanes.argtypes = [C.c_double] * 5 + [C.c_int, C.c_int, C.c_double] + [DP] * 4
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for trial in range(400):
+        theta, k1, k2 = rng.uniform(0.2, 1.5), rng.uniform(0.5, 5.0), rng.uniform(0.0, 12.0)
+        beta, volvol, eta = rng.uniform(-1.0, 0.5), rng.uniform(0.3, 2.5), rng.uniform(0.8, 1.2)
+        spot, order = bool(trial & 1), 1 + ((trial >> 1) & 1)
+        phi = complex(rng.choice([-0.5, 0.5, rng.uniform(-1, 1)]), rng.uniform(-40, 40))
+        psi = complex(rng.uniform(-1, 1), rng.uniform(-40, 40)) if trial % 3 == 0 else 0j
+        A = rng.normal(size=5) * 3.0 + 1j * rng.normal(size=5) * 3.0
+        if order == 1:
+            A[3:] = 0.0
+        want = oracle.logsv_ode_rhs(phi, psi, A, theta, k1, k2, beta, volvol, spot, order, eta)
+        got = np.empty(5, dtype=np.complex128)
+        ph, ps = np.array([phi.real, phi.imag]), np.array([psi.real, psi.imag])
+        a = np.ascontiguousarray(A)
+        lib.probe_ode_rhs_lanes(theta, k1, k2, beta, volvol, int(spot), order, eta, ph.ctypes.data_as(DP), ps.ctypes.data_as(DP),
+                                a.view(np.float64).ctypes.data_as(DP), got.view(np.float64).ctypes.data_as(DP))
+        scale = np.max(np.abs(want)) + 1e-300
+        worst = max(worst, float(np.max(np.abs(got - want)) / scale))
+    assert worst < 1e-13, worst
