@@ -202,6 +202,10 @@ def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
     if torch.cuda.is_available():
         device = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(device)
+        # ... and through libsvmc itself: its engines take the HIP runtime's current device, which must be this rank's GPU
+        # whatever torch does about initialising lazily
+        from . import _lib
+        _lib.check(_lib.load().svmc_set_device(device))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
