@@ -50,8 +50,9 @@ constexpr int ODE_POINTS_PER_BLOCK = 4;     // a block is one wave
 template <int N>
 __device__ __forceinline__ double row_bcast(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false);
+    // mov_dpp with bound_ctrl: no "old" value to preserve, so no register initialisation ahead of each of the ~100 moves a step
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int N>
