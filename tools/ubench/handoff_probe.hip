@@ -1,5 +1,6 @@
 // Micro-benchmark: handing a wave's state to ANOTHER wave (possibly on another XCD) through device memory inside one
-// launch -- the synchronisation skeleton of logsv_rng_units_kernel without the stepping.
+// launch -- the synchronisation skeleton of the dynamic-units generator experiment (commit e53a51a, profiles/r03_launch_tail.txt)
+// without the stepping.
 //
 //   hipcc --offload-arch=gfx950 -O3 handoff_probe.hip -o handoff_probe && ./handoff_probe
 //
