@@ -13,6 +13,9 @@
 // row of lanes and an expiry is one launch.  The work is tiny (1000 points) and latency-bound; it is on the GPU so that the
 // analytic-vs-MC sweep of config C5 needs no host ODE solver.  CPU twin: oracle/svmc_oracle_analytic.c.
 #include "svmc_internal.h"
+
+#include <cstdlib>
+
 #include "svmc_math.h"
 #include "svmc_ode.h"
 
@@ -40,6 +43,106 @@ __device__ __forceinline__ cd csqrt_(cd z)   // principal branch
     return cd{fabs(z.im) / (2.0 * t), copysign(t, z.im)};
 }
 __device__ __forceinline__ cd clog_(cd z) { return cd{log(cabs_(z)), atan2(z.im, z.re)}; }
+
+// ---- one grid point per LANE: the form for LONG grids ----------------------------------------------------------------
+// The row form below wins on latency (a lone wave per SIMD, a third of the instructions per step) and loses on volume: it
+// spends 16 lanes per point.  The 40 000-point psi grid of the quadratic-variance transform fills the chip either way --
+// 625 waves one lane per point, 10 000 waves in rows -- and is then bound by total instruction issue, where a point costs
+// 1850 instructions per step here against 16 x 800 / 5 useful in rows.  svmc_logsv_mgf_grid_batch picks by grid length.
+// A' = A^T M^(k) A + L^(k) A + H^(k): the non-zero entries of :146-182 written out
+__device__ __forceinline__ void ode_rhs(const OdeConsts &c, cd phi, cd psi, const cd (&A)[5], cd (&out)[5])
+{
+    const double qv = c.qv, qv2 = c.qv2, v2 = c.vartheta2, th = c.theta, th2 = c.theta2;
+    const cd bphi = c.b * phi;
+    const cd A1 = A[1], A2 = A[2];
+    const cd rhs = (c.spot ? phi * (phi + 1.0) : phi * (phi - 1.0)) - 2.0 * psi;
+    const cd L01 = c.lamda - th2 * bphi;
+    const cd L11 = -c.kappa_p - 2.0 * th * bphi, L12 = 2.0 * ((c.lamda + qv) - th2 * bphi);
+    const cd L21 = -c.kappa2_p - bphi, L22 = (v2 - 2.0 * c.kappa_p) - 4.0 * th * bphi;
+    const cd A11 = A1 * A1, A12 = A1 * A2, A22 = A2 * A2;
+    out[0] = 0.5 * qv2 * A11 + L01 * A1 + qv2 * A2 + 0.5 * th2 * c.eta2 * rhs;
+    out[1] = qv * A11 + 2.0 * qv2 * A12 + L11 * A1 + L12 * A2 + th * c.eta2 * rhs;
+    out[2] = 0.5 * v2 * A11 + 2.0 * qv2 * A22 + 4.0 * qv * A12 + L21 * A1 + L22 * A2 + 0.5 * c.eta2 * rhs;
+    if (c.second) {
+        const cd A3 = A[3], A4 = A[4];
+        const cd kb = c.kappa2_p + bphi;
+        const cd L23 = 3.0 * (2.0 * qv - th2 * bphi);
+        const cd L33 = 3.0 * ((v2 - c.kappa_p) - 2.0 * th * bphi), L34 = 4.0 * (3.0 * qv - th2 * bphi);
+        const cd A13 = A1 * A3, A14 = A1 * A4, A23 = A2 * A3, A24 = A2 * A4;
+        out[1] = out[1] + 3.0 * qv2 * A3;
+        out[2] = out[2] + 3.0 * qv2 * A13 + L23 * A3 + 6.0 * qv2 * A4;
+        out[3] = 4.0 * qv * A22 + 2.0 * v2 * A12 + 6.0 * qv * A13 + 4.0 * qv2 * A14 + 6.0 * qv2 * A23 - 2.0 * (kb * A2) +
+                 L33 * A3 + L34 * A4;
+        out[4] = 2.0 * v2 * A22 + 4.5 * qv2 * (A3 * A3) + 3.0 * v2 * A13 + 8.0 * qv * A14 + 12.0 * qv * A23 + 8.0 * qv2 * A24 -
+                 3.0 * (kb * A3) + 2.0 * (L22 * A4);
+    } else {
+        out[3] = C(0.0);
+        out[4] = C(0.0);
+    }
+}
+
+// Dormand-Prince 5(4), FSAL, mixed error scale, RMS norm -- the CPU twin's dopri5() (same tableau, same controller; the
+// error norm and the step factor are evaluated as noted below)
+__device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5], double rtol, double atol)
+{
+    constexpr double a21 = 1.0 / 5, a31 = 3.0 / 40, a32 = 9.0 / 40, a41 = 44.0 / 45, a42 = -56.0 / 15, a43 = 32.0 / 9,
+                     a51 = 19372.0 / 6561, a52 = -25360.0 / 2187, a53 = 64448.0 / 6561, a54 = -212.0 / 729,
+                     a61 = 9017.0 / 3168, a62 = -355.0 / 33, a63 = 46732.0 / 5247, a64 = 49.0 / 176,
+                     a65 = -5103.0 / 18656, b1 = 35.0 / 384, b3 = 500.0 / 1113, b4 = 125.0 / 192, b5 = -2187.0 / 6784,
+                     b6 = 11.0 / 84, e1 = 71.0 / 57600, e3 = -71.0 / 16695, e4 = 71.0 / 1920, e5 = -17253.0 / 339200,
+                     e6 = 22.0 / 525, e7 = -1.0 / 40;
+    cd k1[5], k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], yt[5], yn[5];
+    double t = 0.0, h = ttm / 32.0;
+    int tries = 0;
+    ode_rhs(c, phi, psi, y, k1);
+    while (t < ttm && tries < 1000000) {
+        ++tries;
+        if (t + h > ttm) h = ttm - t;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a21 * k1[i]);
+        ode_rhs(c, phi, psi, yt, k2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
+        ode_rhs(c, phi, psi, yt, k3);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+        ode_rhs(c, phi, psi, yt, k4);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+        ode_rhs(c, phi, psi, yt, k5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            yt[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+        ode_rhs(c, phi, psi, yt, k6);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) yn[i] = y[i] + h * (b1 * k1[i] + b3 * k3[i] + b4 * k4[i] + b5 * k5[i] + b6 * k6[i]);
+        ode_rhs(c, phi, psi, yn, k7);
+        // the error norm of the twin, err = sqrt(mean_i (|e_i| / sc_i)^2) with sc_i = atol + rtol max(|y_i|, |yn_i|), kept
+        // SQUARED: one square root per component (of the larger squared modulus) instead of three hypot() calls, and the
+        // step factor 0.9 err^(-1/5) = 0.9 exp(-0.1 ln err^2) from the package's own exp / log -- a fifth of the 2100
+        // instructions of a step were the libm hypot / pow of this block
+        double err2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const cd e = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+            const double m2 = fmax(fma(y[i].re, y[i].re, y[i].im * y[i].im), fma(yn[i].re, yn[i].re, yn[i].im * yn[i].im));
+            const double sc = fma(rtol, sqrt_pos0_1g(m2), atol);
+            err2 += fma(e.re, e.re, e.im * e.im) * rcp_1n(sc * sc);
+        }
+        const double err_sq = err2 * 0.2;                                   // err^2
+        if (err_sq <= 1.0) {
+            t += h;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                y[i] = yn[i];
+                k1[i] = k7[i];
+            }
+        }
+        const double fac = (err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0;
+        h *= fmin(5.0, fmax(0.2, fac));
+    }
+}
+
 
 // ---- one grid point per 16-lane DPP row ---------------------------------------------------------------------------
 constexpr int ODE_ROW = 16;                 // lanes per grid point: components 0..4 work, 5..15 ride along on zero rows
@@ -167,6 +270,30 @@ __global__ __launch_bounds__(AB) void logsv_mgf_grid_kernel(const cd *__restrict
     }
 }
 
+__global__ __launch_bounds__(AB) void logsv_mgf_grid_lane_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
+                                                            size_t n_grid, double ttm, OdeBatch sets,
+                                                            cd *__restrict__ a, cd *__restrict__ log_mgf, double rtol,
+                                                            double atol)
+{
+    const size_t j = static_cast<size_t>(blockIdx.x) * AB + threadIdx.x;
+    if (j >= n_grid) return;
+    const OdeConsts c = sets.c[blockIdx.y];
+    const double y0 = sets.y0[blockIdx.y];
+    const size_t g = static_cast<size_t>(blockIdx.y) * n_grid + j;     // this set's grid point
+    const int n = c.second ? 5 : 3;
+    cd A[5] = {C(0.0), C(0.0), C(0.0), C(0.0), C(0.0)};
+    for (int k = 0; k < n; ++k) A[k] = a[g * n + k];
+    dopri5(c, phi[g], psi[g], ttm, A, rtol, atol);
+    cd lm = C(0.0);
+    double yk = 1.0;
+    for (int k = 0; k < n; ++k) {
+        a[g * n + k] = A[k];
+        lm = lm + yk * A[k];                                          // affine_expansion.py:674-685
+        yk *= y0;
+    }
+    log_mgf[g] = lm;
+}
+
 __global__ __launch_bounds__(AB) void heston_mgf_grid_kernel(const cd *__restrict__ phi, const cd *__restrict__ psi,
                                                              size_t n_grid, double ttm, double v0, double theta,
                                                              double kappa, double volvol, double rho, cd *__restrict__ a,
@@ -292,11 +419,19 @@ int svmc_logsv_mgf_grid_batch(const double *phi, const double *psi, size_t n_gri
             sets.y0[i] = p[0] - p[1];
         }
         const size_t off = static_cast<size_t>(s0) * n_grid;
-        hipLaunchKernelGGL(logsv_mgf_grid_kernel,
-                           dim3(static_cast<unsigned>((n_grid + ODE_POINTS_PER_BLOCK - 1) / ODE_POINTS_PER_BLOCK), static_cast<unsigned>(m)),
-                           dim3(AB), 0, as_stream(stream), reinterpret_cast<const cd *>(phi) + off,
-                           reinterpret_cast<const cd *>(psi) + off, n_grid, ttm, sets, reinterpret_cast<cd *>(a) + off * n_coef,
-                           reinterpret_cast<cd *>(log_mgf) + off, rtol, atol);
+        // rows while the launch stays within two waves per SIMD (8192 points at one set), lanes beyond: see above
+        static const size_t row_max = getenv("SVMC_MGF_ROW_MAX_POINTS") ? strtoull(getenv("SVMC_MGF_ROW_MAX_POINTS"), nullptr, 10) : 8192;
+        if (n_grid * static_cast<size_t>(m) <= row_max)
+            hipLaunchKernelGGL(logsv_mgf_grid_kernel,
+                               dim3(static_cast<unsigned>((n_grid + ODE_POINTS_PER_BLOCK - 1) / ODE_POINTS_PER_BLOCK), static_cast<unsigned>(m)),
+                               dim3(AB), 0, as_stream(stream), reinterpret_cast<const cd *>(phi) + off,
+                               reinterpret_cast<const cd *>(psi) + off, n_grid, ttm, sets, reinterpret_cast<cd *>(a) + off * n_coef,
+                               reinterpret_cast<cd *>(log_mgf) + off, rtol, atol);
+        else
+            hipLaunchKernelGGL(logsv_mgf_grid_lane_kernel, dim3(static_cast<unsigned>((n_grid + AB - 1) / AB), static_cast<unsigned>(m)),
+                               dim3(AB), 0, as_stream(stream), reinterpret_cast<const cd *>(phi) + off,
+                               reinterpret_cast<const cd *>(psi) + off, n_grid, ttm, sets, reinterpret_cast<cd *>(a) + off * n_coef,
+                               reinterpret_cast<cd *>(log_mgf) + off, rtol, atol);
     }
     return check_launch_a(fn);
 }
