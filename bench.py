@@ -29,11 +29,21 @@ the CPU oracle (a port of the reference's algorithm) timed on one host core on a
 `n1_share_value` (this rank's shard priced WITHOUT the group: the denominator of the weak-scaling ratio),
 `c4_full_one_gpu` (all N x 2^21 paths on ONE device: the denominator of the strong-scaling ratio), `rccl_ranks_seen` and
 `rccl_route` (the same chain timed through libsvmc's own RCCL entry points, the route a C host takes).
+Every line carries `c_abi_route`: the same workload through ONE call of the fused C driver svmc_logsv_chain_price per step
+(the boundary's headline entry point; include/svmc.h), its prices compared with the Python route's.
+
+The N > 1 line PROVES ITSELF (exit status != 0 when a proof fails, the line still printed with `self_check.failed`):
+`sharded_vs_one_gpu_max_rel_dev` -- the sharded job and the whole job on rank 0's device, same seed, must agree to
+reduction-order rounding (<= 1e-12); on the RCCL backend `rccl_ranks_seen` must equal --gpus; `kernel_ms_over_ranks`
+shows a slow GPU.  A rank that never arrives at the rendezvous, an RCCL initialisation that does not return within
+SVMC_BENCH_INIT_TIMEOUT (120 s) or a leg that overruns its deadline ends the rank with its traceback on stderr (and
+torch.distributed.run then ends the others): the command returns non-zero instead of hanging.
 See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
 import argparse
+import faulthandler
 import gc
 import glob
 import hashlib
@@ -90,6 +100,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip n1_share / c4_full_one_gpu / all-cores legs")
+    ap.add_argument("--no-c-abi-route", action="store_true", help="skip the fused C driver leg (svmc_logsv_chain_price)")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="N > 1: skip the sharded-vs-one-GPU price comparison (it prices the whole job on rank 0's device)")
     ap.add_argument("--cpu-sample-paths", type=int, default=1 << 19)
     return ap.parse_args()
 
@@ -321,7 +334,19 @@ def streamed_roofline(eng, P, nb_steps: int, pmc) -> dict:
             "config": {"paths": n, "steps": nb_steps, "bytes_per_path_step": 16}}
 
 
-def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, isa, pmc, clock_mhz) -> dict:
+def clock_from_stamps(stamps) -> dict:
+    """svmc_clock_probe_read's stamps -> the shader clock the first / last block's wave 0 saw between kernel entry and the
+    end of its time loop: s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz)"""
+    out = {}
+    for tag, (t0, r0, t1, r1) in (("first_block", stamps[0:4]), ("last_block", stamps[4:8])):
+        if r1 > r0 and t1 > t0:
+            out[tag] = {"mhz": 100.0 * (t1 - t0) / (r1 - r0), "wave_lifetime_ms": (r1 - r0) / 1e5}
+    if out:
+        out["mhz"] = float(np.mean([v["mhz"] for v in out.values()]))
+    return out
+
+
+def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, isa, pmc, clock_mhz, stamps=None) -> dict:
     """the stepping kernel of one chain call against (a) the VALU issue port -- the roof that binds it: the time loop's
     instructions by opcode class (from the loaded library's assembly) x the measured issue cost of each class, (b) HBM,
     (c) SURVEY's flop-equivalent estimate"""
@@ -361,6 +386,20 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
             "clock_mhz_sensor": clock_mhz, "ms_per_launch": k_ms, "launches": launches,
             "traffic": traffic, "algorithmic_bytes": alg_bytes,
         }
+        clk = clock_from_stamps(stamps) if stamps is not None else {}
+        if clk.get("mhz"):
+            # the clock MEASURED INSIDE the last timed launch (s_memtime against the 100 MHz s_memrealtime, wave 0 of the
+            # launch's first and last block): the same issue cycles against the cycles the chip actually delivered in the
+            # kernel's time -- what is left of 1 is idle issue, not clock
+            sustained = N_SIMD * clk["mhz"] * 1e6
+            out["roofline"].update({
+                "clock_mhz_in_kernel": clk["mhz"], "clock_probe": clk,
+                "frac_at_sustained_clock": achieved / sustained,
+                "frac_in_stream_at_sustained_clock": cyc_in_stream * wave_steps / (k_ms * 1e-3) / sustained,
+                "clock_note": "frac = issue cycles / (1024 SIMDs x 2400 MHz x kernel time); frac_at_sustained_clock = the same "
+                              "cycles / (1024 SIMDs x clock_mhz_in_kernel x kernel time)"})
+        else:
+            out["roofline"].update({"clock_mhz_in_kernel": None, "frac_at_sustained_clock": None})
         if prof.get("note") and traffic is not None:
             out["roofline"]["traffic_note"] = prof["note"]
         gui, lds, conf, act = (prof.get(k + "_per_dispatch") for k in ("grbm_gui_active", "sq_lds_idx_active", "sq_lds_bank_conflict",
@@ -394,6 +433,120 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
     return out
 
 
+class Watchdog:
+    """fail fast instead of hanging: arm(seconds, what) gives the phase that follows a deadline; when it passes, the C-level
+    timer thread of `faulthandler` (it needs no GIL, so it fires even while the main thread sits inside a HIP / RCCL call)
+    dumps every thread's traceback to stderr and ends the process with status 1 -- torch.distributed.run then tears the
+    other ranks down and the command returns non-zero.  A best-effort Python timer names the phase one second earlier."""
+
+    def __init__(self, rank: int):
+        self.rank, self._timer = rank, None
+
+    def arm(self, seconds: float, what: str) -> None:
+        self.disarm()
+        faulthandler.dump_traceback_later(seconds, exit=True, file=sys.stderr)
+        self._timer = threading.Timer(max(seconds - 1.0, 0.0), self._announce, (seconds, what))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _announce(self, seconds, what):
+        sys.stderr.write(f"bench.py rank {self.rank}: '{what}' did not finish within {seconds:.0f} s -- aborting this rank "
+                         f"(exit status 1; traceback follows)\n")
+        sys.stderr.flush()
+
+    def disarm(self) -> None:
+        faulthandler.cancel_dump_traceback_later()
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+
+def max_rel_dev(got, ref) -> float:
+    """largest |got - ref| / |ref| over the entries of two lists of arrays; an entry with ref == 0 counts as 0 when got is
+    0 too and as inf otherwise (nothing is silently dropped)"""
+    worst = 0.0
+    for a, b in zip(got, ref):
+        a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+        if a.shape != b.shape:
+            return float("inf")
+        nz = b != 0.0
+        if np.any(nz):
+            worst = max(worst, float(np.nanmax(np.abs(a[nz] / b[nz] - 1.0))))
+        if np.any(~nz) and np.any(a[~nz] != 0.0):
+            return float("inf")
+        if np.any(np.isnan(a) != np.isnan(b)):
+            return float("inf")
+    return worst
+
+
+class CAbiChain:
+    """the workload through the fused C driver of the boundary: ONE svmc_logsv_chain_price call per chain on a
+    svmc_session_t (include/svmc.h; what examples/price_chain.c and price_chain_rccl.c call) -- host arrays in, prices
+    out, every launch queued inside the library.  With `comm` (an svmc_comm_t) the session holds this rank's shard."""
+
+    def __init__(self, svlib, wl, P, n_local: int, comm_handle=None, rank: int = 0, world: int = 1, n_total: int = 0,
+                 offset: int = 0):
+        import ctypes as C
+        self.C, self.svlib, self.L = C, svlib, svlib.load()
+        self.P, self.wl = P, wl
+        m = len(wl["ttms"])
+        f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)                                    # noqa: E731
+        self.ttms, self.fw, self.df, self.eta = f64(wl["ttms"]), f64(wl["forwards"]), f64(wl["dfs"]), np.ones(m)
+        self.kk = f64(np.concatenate(wl["strikes"]))
+        codes = {"C": 0, "P": 1, "IC": 2, "IP": 3}
+        self.codes = np.ascontiguousarray([codes[str(t)] for t in np.concatenate(wl["types"])], dtype=np.int8)
+        self.offs = np.concatenate([[0], np.cumsum([len(k) for k in wl["strikes"]])]).astype(np.uintp)
+        self.counts = [len(k) for k in wl["strikes"]]
+        self.prices, self.errs = np.empty(self.kk.size), np.empty(self.kk.size)
+        self.sess = C.c_void_p()
+        svlib.check(self.L.svmc_session_create(C.byref(self.sess), n_local, m, int(self.kk.size)))
+        if comm_handle is not None:
+            svlib.check(self.L.svmc_session_set_comm(self.sess, comm_handle, rank, world, n_total, offset))
+        dp = C.POINTER(C.c_double)
+        self._args = (self.ttms.ctypes.data_as(dp), self.fw.ctypes.data_as(dp), self.df.ctypes.data_as(dp),
+                      self.eta.ctypes.data_as(dp), m, self.kk.ctypes.data_as(dp),
+                      self.codes.ctypes.data_as(C.POINTER(C.c_int8)), self.offs.ctypes.data_as(C.POINTER(C.c_size_t)))
+        self._out = (self.prices.ctypes.data_as(dp), self.errs.ctypes.data_as(dp))
+
+    def price(self, seed: int):
+        P = self.P
+        self.svlib.check(self.L.svmc_logsv_chain_price(self.sess, *self._args, P.sigma0, P.theta, P.kappa1, P.kappa2, P.beta,
+                                                       P.volvol, 1, self.wl["spy"], 1, seed, 0, *self._out))
+        return np.split(self.prices.copy(), np.cumsum(self.counts)[:-1]), np.split(self.errs.copy(), np.cumsum(self.counts)[:-1])
+
+    def close(self):
+        if self.sess is not None:
+            self.L.svmc_session_destroy(self.sess)
+            self.sess = None
+
+
+def c_abi_route_leg(make_chain, python_step, calls: int, n_paths_job: int, nb: int, barrier, max_over_ranks) -> dict:
+    """`calls` chains through CAbiChain.price, each timed on the host clock; the Python route's prices on the last seed
+    beside it.  The timed region runs with the garbage collector frozen (main() did that before its own timed region)."""
+    chain = make_chain()
+    try:
+        for i in range(3):
+            chain.price(7 + i)
+        barrier()
+        ts = []
+        for i in range(calls):
+            t0 = time.perf_counter()
+            p_c, e_c = chain.price(20240602 + i)
+            ts.append(time.perf_counter() - t0)
+        barrier()
+        p_py, e_py = python_step(calls - 1)
+        ts = np.array(ts)
+        med = max_over_ranks(float(np.median(ts)))
+        return {"entry_point": "svmc_logsv_chain_price (one C-ABI call per chain, svmc_session_t)", "calls": calls,
+                "ms_per_step": 1e3 * med, "ms_per_step_max": 1e3 * max_over_ranks(float(ts.max())),
+                "ms_per_step_mean": 1e3 * max_over_ranks(float(ts.mean())), "value": n_paths_job * nb / med,
+                "prices_equal_python_route": bool(all(np.array_equal(a, b) for a, b in zip(p_c, p_py))
+                                                  and all(np.array_equal(a, b) for a, b in zip(e_c, e_py))),
+                "max_rel_dev_vs_python_route": max_rel_dev(p_c, p_py)}
+    finally:
+        chain.close()
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
@@ -403,8 +556,10 @@ def free_port() -> int:
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the driver's
     own command does -- one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- and pass their output
-    through (rank 0 prints the line)."""
+    through (rank 0 prints the line).  The launch runs under an overall deadline (SVMC_BENCH_TIMEOUT, 1500 s -- below the
+    driver's own 1800 s): past it the whole process group is killed and the command returns 124 instead of hanging."""
     import ctypes as C
+    import signal
 
     from stochvolmodels_amd import _lib
     count = C.c_int(0)
@@ -416,7 +571,18 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVMC_BENCH_SELF_LAUNCHED="1")
-    return subprocess.run(cmd, env=env).returncode
+    limit = float(os.environ.get("SVMC_BENCH_TIMEOUT", "1500"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: the ranks did not finish within {limit:.0f} s -- killing them\n")
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)        # the launcher and every rank it started (its own session)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        return 124
 
 
 def main():
@@ -435,23 +601,60 @@ def main():
     from stochvolmodels_amd import dist as svdist
     from stochvolmodels_amd.engine import get_engine
 
-    comm = svdist.init_from_env()
+    # deadlines (seconds): every rank must reach the rendezvous (the slowest rank's `import torch` on a cold box is inside
+    # this one), the collective layer must initialise, and each leg of the run must end
+    wd = Watchdog(rank)
+    t_rdv = float(os.environ.get("SVMC_BENCH_RENDEZVOUS_TIMEOUT", "300"))
+    t_init = float(os.environ.get("SVMC_BENCH_INIT_TIMEOUT", "120"))
+    t_leg = float(os.environ.get("SVMC_BENCH_LEG_TIMEOUT", "600"))
+    if os.environ.get("SVMC_BENCH_FAULT") == f"hang_init:{rank}":        # test hook: this rank never reaches the rendezvous
+        wd.arm(t_init, "fault injection: hang before the rendezvous")
+        time.sleep(10 * t_init + 60)
+
+    def on_phase(name):
+        if name == "rendezvous":
+            wd.arm(t_rdv, "rendezvous of the ranks (torch.distributed.init_process_group)")
+        elif name == "collective_init":
+            wd.arm(t_init, "initialisation of the collective layer (RCCL communicator + first all-reduce)")
+        else:
+            wd.disarm()
+
+    comm = svdist.init_from_env(on_phase=on_phase if world > 1 else None)
     if world == 1:
         torch.cuda.set_device(0)
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    grouped = torch.distributed.is_initialized()
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
-        if torch.distributed.is_initialized():
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v: float) -> float:
-        if world == 1:
+        if not grouped:
             return v
-        t = torch.tensor([v], dtype=torch.float64,
-                         device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([v], dtype=torch.float64, device=coll_dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_over_ranks(v: float) -> list:
+        if not grouped:
+            return [float(v)]
+        t = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        t[rank] = v
+        torch.distributed.all_reduce(t)
+        return [float(x) for x in t.cpu().tolist()]
+
+    def all_ranks_ok(ok: bool) -> bool:
+        """agree on success across the ranks: a leg that failed on SOME ranks must be abandoned by ALL of them, or the
+        failing ranks wait in a barrier while the others wait inside a collective"""
+        if not grouped:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=coll_dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
 
     P = sv.LOGSV_BTC_PARAMS
     cfg = args.config or ("c2" if world == 1 else "c4")
@@ -467,6 +670,7 @@ def main():
     def step(i):
         return price(sv, wl, P, n_total, 20240602 + i)
 
+    wd.arm(t_leg, "first call + warm-up")
     step(-2000)                                # first call: library load, buffers, first launches
     # no full garbage collection inside the timed region: everything alive now (the imports' ~70 000 container objects)
     # moves to the permanent generation, so the collector's passes over what the steps allocate stay in the microseconds.
@@ -480,6 +684,7 @@ def main():
         step(-1 - i)
     offset, n_local = svdist.shard_range(n_total, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)
+    wd.arm(t_leg, "timed region")
     barrier()
     if os.environ.get("SVMC_BENCH_NO_KERNEL_EVENTS") != "1":     # diagnostics: the HIP events around the stepping launches
         eng.start_kernel_timing()
@@ -494,53 +699,132 @@ def main():
     final_barrier_ms = 1e3 * (time.perf_counter() - t_b)
     per_step_ms = 1e3 * np.diff(np.array([t0] + step_ends))
     kernel_ms = (eng.stop_kernel_timing() if eng._prof is not None else {}).get(kernel, [float("nan")])
+    # the shader clock the LAST timed launch ran at, stamped inside the kernel (svmc_clock_probe_read)
+    import ctypes as C
+    stamps = (C.c_uint64 * 8)()
+    svlib.check(svlib.load().svmc_clock_probe_read(stamps, eng.stream))
     elapsed = max_over_ranks(elapsed)
     value = float(n_total) * nb * args.steps / elapsed
+    k_ms_all = gather_over_ranks(float(np.mean(kernel_ms)))
 
     extra = {}
+    failures = []
     single = svdist.SingleComm()
     if world > 1 and isinstance(comm, svdist.TorchComm):
         # the stream-ordering shortcut of TorchComm (no host synchronisation around the all-reduces) against the
         # host-synchronised fallback, with real peers: the bits must be identical
+        wd.arm(t_leg, "stream-ordered vs host-synchronised collectives")
         os.environ["SVMC_DIST_STRICT_SYNC"] = "1"
         p_strict, _ = step(424242)
         os.environ["SVMC_DIST_STRICT_SYNC"] = "0"
         p_ordered, _ = step(424242)
         extra["stream_ordered_equals_strict_sync"] = bool(all(np.array_equal(a, b) for a, b in zip(p_strict, p_ordered)))
     extra["comm"] = type(comm).__name__
-    extra["backend"] = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    extra["backend"] = backend
+    extra["kernel_ms_over_ranks"] = {"min": min(k_ms_all), "max": max(k_ms_all), "per_rank": [round(v, 4) for v in k_ms_all]}
+    if grouped:
+        # the ranks the process group itself sees (a sum all-reduce of ones): must be --gpus on any backend
+        t = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        torch.distributed.all_reduce(t)
+        extra["group_ranks_seen"] = int(round(float(t.item())))
+        if extra["group_ranks_seen"] != world:
+            failures.append(f"group_ranks_seen {extra['group_ranks_seen']} != --gpus {world}")
     extra["rccl_ranks_seen"] = None
     if isinstance(comm, svdist.RcclComm):
         extra["rccl_ranks_seen"] = comm.ranks_seen()
-    if torch.distributed.is_initialized() and not isinstance(comm, svdist.RcclComm) and not args.no_extra_legs:
+
+    # ---- the fused C driver of the boundary on the line's own workload (single GPU: here; N > 1: inside the RCCL leg)
+    if world == 1 and not args.no_c_abi_route:
+        wd.arm(t_leg, "c_abi_route")
+        extra["c_abi_route"] = c_abi_route_leg(lambda: CAbiChain(svlib, wl, P, n_local), step, max(3, min(args.steps, 20)),
+                                               n_total, nb, barrier, max_over_ranks)
+
+    dev_count = C.c_int(0)
+    svlib.check(svlib.load().svmc_device_count(C.byref(dev_count)))
+    ranks_share_a_device = world > dev_count.value
+    want_rccl_leg = grouped and not isinstance(comm, svdist.RcclComm) and (backend == "nccl" or not args.no_extra_legs)
+    if want_rccl_leg and ranks_share_a_device:
+        # the gloo test mode (several ranks on one GPU): RCCL refuses two ranks per device (ncclCommInitRank: invalid
+        # usage; tests/test_gpu_parity.py::test_two_rccl_ranks_on_one_gpu records the refusal) -- nothing to time
+        extra["rccl_route"] = {"skipped": f"{world} ranks share {dev_count.value} device(s): RCCL needs one device per rank"}
+    elif want_rccl_leg:
         # the same chain through libsvmc's OWN RCCL entry points (include/svmc.h svmc_rccl_*: the route a C / C++ host
         # takes; dist.RcclComm drives it from Python): a second communicator built from a unique id that the torch group
         # ships, the two all-reduces issued by libsvmc on the engine's stream.  ncclCommCount says how many ranks RCCL
-        # itself sees.  Refused where two ranks share a device (the gloo test mode): reported, not fatal.
+        # itself sees.  Every step that can fail on SOME ranks is followed by an agreement across ALL ranks.
+        wd.arm(t_init + t_leg, "rccl_route (svmc_rccl_comm_create + timed chains)")
+        rc, err = None, None
         try:
             box = [svdist.RcclComm.unique_id() if rank == 0 else None]
             torch.distributed.broadcast_object_list(box, src=0)
             rc = svdist.RcclComm(rank, world, box[0])
+        except Exception as exc:                             # noqa: BLE001
+            err = f"{type(exc).__name__}: {exc}"[:300]
+        if not all_ranks_ok(err is None):
+            extra["rccl_route"] = {"error": err or "RcclComm creation failed on another rank"}
+            if rc is not None:
+                rc.close()
+        else:
             extra["rccl_ranks_seen"] = rc.ranks_seen()
-            k = max(3, min(args.steps, 20))
-            for i in range(3):
-                price(sv, wl, P, n_total, 7 + i, comm=rc)
-            barrier()
-            t0r = time.perf_counter()
-            for i in range(k):
-                p_rccl, _ = price(sv, wl, P, n_total, 20240602 + i, comm=rc)
-            barrier()
-            t_rccl = max_over_ranks((time.perf_counter() - t0r) / k)
-            p_torch, _ = price(sv, wl, P, n_total, 20240602 + k - 1)
-            extra["rccl_route"] = {"comm": "RcclComm (svmc_rccl_* through the C ABI)", "value": n_total * nb / t_rccl,
-                                   "ms_per_step": 1e3 * t_rccl, "steps": k, "origin": rc.origin(),
-                                   "prices_equal_torch_route": bool(all(np.array_equal(a, b) for a, b in zip(p_rccl, p_torch)))}
+            try:
+                k = max(3, min(args.steps, 20))
+                for i in range(3):
+                    price(sv, wl, P, n_total, 7 + i, comm=rc)
+                barrier()
+                t0r = time.perf_counter()
+                for i in range(k):
+                    p_rccl, _ = price(sv, wl, P, n_total, 20240602 + i, comm=rc)
+                barrier()
+                t_rccl = (time.perf_counter() - t0r) / k
+            except Exception as exc:                         # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"[:300]
+            if not all_ranks_ok(err is None):
+                extra["rccl_route"] = {"error": err or "the RcclComm chains failed on another rank"}
+            else:
+                t_rccl = max_over_ranks(t_rccl)
+                p_torch, _ = step(k - 1)
+                extra["rccl_route"] = {"comm": "RcclComm (svmc_rccl_* through the C ABI)", "value": n_total * nb / t_rccl,
+                                       "ms_per_step": 1e3 * t_rccl, "steps": k, "origin": rc.origin(),
+                                       "prices_equal_torch_route": bool(all(np.array_equal(a, b) for a, b in zip(p_rccl, p_torch)))}
+                if not args.no_c_abi_route:
+                    # ... and through the fused C driver with that communicator attached (svmc_session_set_comm): what
+                    # examples/price_chain_rccl.c does, one C-ABI call per chain and rank
+                    try:
+                        leg = c_abi_route_leg(lambda: CAbiChain(svlib, wl, P, n_local, rc.handle, rank, world, n_total, offset),
+                                              step, k, n_total, nb, barrier, max_over_ranks)
+                    except Exception as exc:                 # noqa: BLE001
+                        leg, err = None, f"{type(exc).__name__}: {exc}"[:300]
+                    extra["c_abi_route"] = leg if all_ranks_ok(leg is not None) else {"error": err or "failed on another rank"}
             rc.close()
-        except Exception as exc:                             # noqa: BLE001  (e.g. ncclCommInitRank: two ranks on one device)
-            extra["rccl_route"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            if torch.distributed.is_initialized():
-                torch.distributed.barrier()
+    if backend == "nccl" and extra["rccl_ranks_seen"] != world:
+        failures.append(f"rccl_ranks_seen {extra['rccl_ranks_seen']} != --gpus {world} on the RCCL backend")
+
+    if world > 1 and not args.no_self_check:
+        # ---- the line proves itself: the sharded job against the WHOLE job on one device (rank 0's), same seed.  The paths
+        # are keyed by their global id, so the two differ by the order of the reductions' additions only
+        wd.arm(t_leg, "self-check: sharded job vs the whole job on one GPU")
+        p_sh, e_sh = step(777)
+        check = {"seed": 20240602 + 777, "tolerance": 1e-12}
+        if rank == 0:
+            p_one, e_one = price(sv, wl, P, n_total, 20240602 + 777, comm=single)
+            check["sharded_vs_one_gpu_max_rel_dev"] = max_rel_dev(p_sh, p_one)
+            check["sharded_vs_one_gpu_max_rel_dev_stderr"] = max_rel_dev(e_sh, e_one)
+            worst = max(check["sharded_vs_one_gpu_max_rel_dev"], check["sharded_vs_one_gpu_max_rel_dev_stderr"])
+            if not worst <= check["tolerance"]:
+                failures.append(f"sharded prices deviate from the one-GPU job by {worst:.3e} > 1e-12")
+        # every rank must hold the same prices (they all hold the all-reduced sums)
+        digest = float(np.sum([np.sum(a) for a in p_sh]))
+        spread = gather_over_ranks(digest)
+        check["ranks_agree_bitwise"] = bool(all(v == spread[0] for v in spread))
+        if not check["ranks_agree_bitwise"]:
+            failures.append("the ranks returned different prices")
+        extra["self_check"] = check
+        if rank == 0:
+            extra["sharded_vs_one_gpu_max_rel_dev"] = check["sharded_vs_one_gpu_max_rel_dev"]
+        if grouped:
+            torch.distributed.barrier()
     if not args.no_extra_legs and (world > 1 or cfg == "c4"):
+        wd.arm(2 * t_leg, "n1_share / full-job-on-one-GPU legs")
         # (a) this rank's shard WITHOUT the group: same kernels, no collectives -- the N = 1 rate the weak-scaling ratio
         #     is formed from (all ranks run it concurrently, each on its own GPU; the slowest rank's figure is reported)
         k = max(3, min(args.steps, 20))
@@ -569,11 +853,12 @@ def main():
             extra["c4_full_one_gpu" if cfg == "c4" else "full_job_one_gpu"] = {
                 "paths": n_total, "value": n_total * nb / t_full, "ms_per_step": 1e3 * t_full,
                 "speedup_of_this_run": value / (n_total * nb / t_full)}
-        if torch.distributed.is_initialized():
+        if grouped:
             torch.distributed.barrier()
 
     result = None
     if rank == 0:
+        wd.arm(2 * t_leg, "roofline legs + CPU baselines (rank 0)")
         k_ms = float(np.mean(kernel_ms))
         result = {
             "metric": "MC path-steps/sec", "value": value, "unit": "path-steps/s", "n_gpus": world,
@@ -595,7 +880,7 @@ def main():
                     step(10_000 + i)
                     i += 1
             clock_mhz = clk.steady_mhz()
-        result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, isa, pmc, clock_mhz))
+        result.update(kernel_rooflines(kernel, k_ms, len(kernel_ms), n_local, wl, isa, pmc, clock_mhz, list(stamps)))
         result.update(extra)
         result["rng_stream_version"] = int(svlib.load().svmc_rng_stream_version())
         result["device_prewarm_steps"] = PREWARM
@@ -616,11 +901,22 @@ def main():
             if world == 1 and not args.no_extra_legs:
                 result["cpu_baseline_all_cores"] = cpu_baseline_all_cores(1024, P)
                 result["cpu_baseline_numpy"] = cpu_baseline_numpy(1024, P)
-    if torch.distributed.is_initialized():     # world > 1, or a lone rank under SVMC_DIST_SINGLE_RANK_GROUP=1
+        if failures:
+            result["self_check_failed"] = failures
+    # ranks > 0 get here while rank 0 still runs its roofline legs and the CPU baselines: their deadline covers that
+    wd.arm(t_init if rank == 0 else 2 * t_leg + t_init, "final barrier + process-group teardown")
+    n_fail = len(failures)
+    if grouped:                                # world > 1, or a lone rank under SVMC_DIST_SINGLE_RANK_GROUP=1
+        n_fail = int(round(max_over_ranks(float(n_fail))))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    wd.disarm()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    if n_fail:
+        for f in failures:
+            sys.stderr.write(f"bench.py rank {rank}: SELF-CHECK FAILED: {f}\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -95,6 +95,12 @@ SVMC_API int svmc_event_create(svmc_event_t *event);
 SVMC_API int svmc_event_destroy(svmc_event_t event);
 SVMC_API int svmc_event_record(svmc_event_t event, svmc_stream_t stream);
 SVMC_API int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms); /* synchronises on `stop` */
+/* The shader clock the LAST on-device-RNG LogSV stepping launch (svmc_logsv_*_rng*) ran at, measured inside that kernel
+ * (no reference counterpart: measurement plumbing of bench.py's roofline): thread 0 of the launch's first and
+ * last block stamp s_memtime (tick = shader cycle) and s_memrealtime (100 MHz) at kernel entry and after the time loop.
+ * stamps[8] = [first block | last block][t_entry, r_entry, t_exit, r_exit]; clock = (t_exit - t_entry) / (r_exit -
+ * r_entry) x 100 MHz.  Synchronises `stream` (the launch's stream) first; the stamps are per device, latest launch wins. */
+SVMC_API int svmc_clock_probe_read(uint64_t *stamps, svmc_stream_t stream);
 
 /* ---- state ----------------------------------------------------------------------------------------
  * x0 = zeros, sigma0 = v0 * ones, qvar0 = zeros of pricers/logsv_pricer.py:832-834 and
@@ -405,7 +411,8 @@ SVMC_API int svmc_session_set_comm(svmc_session_t session, svmc_comm_t comm, int
 /* The same sharding with the two sum all-reduces handed to the CALLER: fn(user, device_buf, n, stream) must leave in
  * device_buf (n doubles, written by kernels queued on `stream`) the element-wise sum over all ranks, visible to work queued
  * on `stream` afterwards, and return SVMC_OK -- MPI, a host-staged exchange, or several sessions of ONE process on one GPU
- * summing through host memory (tests/test_gpu_parity.py runs 2- and 3-shard jobs that way and requires the unsharded bits).
+ * summing through host memory (tests/test_gpu_parity.py runs 2- and 3-shard jobs that way and requires the unsharded
+ * session's prices to reduction-order rounding, 1e-12: the per-wave partial rows depend on where a shard starts).
  * fn == NULL detaches, as svmc_session_set_comm(session, NULL, ...). */
 typedef int (*svmc_all_reduce_fn)(void *user, double *device_buf, size_t n, svmc_stream_t stream);
 SVMC_API int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn fn, void *user, int rank, int world,

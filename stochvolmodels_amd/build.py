@@ -63,6 +63,30 @@ def file_sha256(path: str) -> str:
     return h.hexdigest()
 
 
+def kernel_metadata(asm_dir: str) -> dict:
+    """{kernel symbol: {vgpr, sgpr, scratch_bytes, lds_bytes}} of every kernel of this build, read off the amdhsa metadata the
+    compiler appends to its assembly -- a spill (scratch_bytes > 0) is visible in the build, not only in a profile"""
+    import glob
+    import re
+    out = {}
+    for path in sorted(glob.glob(os.path.join(asm_dir, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))):
+        text = open(path).read()
+        start = text.find("amdhsa.kernels:")
+        if start < 0:
+            continue
+        for block in re.split(r"\n  - ", text[start:])[1:]:
+            def field(key, block=block):
+                m = re.search(r"\." + key + r":\s*(\S+)", block)
+                return m.group(1) if m else None
+            name = field("name")
+            if name is None:
+                continue
+            out[name] = {"vgpr": int(field("vgpr_count") or 0), "sgpr": int(field("sgpr_count") or 0),
+                         "scratch_bytes": int(field("private_segment_fixed_size") or 0),
+                         "lds_bytes": int(field("group_segment_fixed_size") or 0)}
+    return out
+
+
 def write_isa_json(asm_path: str) -> None:
     """per-kernel instruction histogram of the time loops (tools/isa_histogram.py) + the library's hash"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -78,7 +102,8 @@ def write_isa_json(asm_path: str) -> None:
         except (SystemExit, ValueError) as exc:             # a kernel renamed away: leave it out, bench.py says so
             kernels[name] = {"error": str(exc)}
     with open(ISA_JSON, "w") as fh:
-        json.dump({"lib_sha256": file_sha256(LIB), "flags": flags(), "kernels": kernels}, fh, indent=1)
+        json.dump({"lib_sha256": file_sha256(LIB), "flags": flags(), "kernels": kernels,
+                   "metadata": kernel_metadata(os.path.dirname(asm_path))}, fh, indent=1)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -224,6 +224,10 @@ int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries
     s->max_strikes = max_strikes_total;
     size_t ws = 0;
     int rc = svmc_slice_workspace_bytes(n_path, &ws);
+    // the multi-set replay (svmc_logsv_chain_price_fixed_sets) writes two partial columns per (expiry, set): a session created
+    // for m x P chains (max_expiries = m P) holds them all, whatever n_path -- the slice workspace alone covers 16 columns pairs
+    const size_t fused_sets = static_cast<size_t>(wave_rows(n_path)) * 2 * static_cast<size_t>(max_expiries) * sizeof(double);
+    if (fused_sets > ws) ws = fused_sets;
     s->ws_bytes = ws;
     const size_t nb = n_path * sizeof(double);
     hipError_t e = hipSuccess;
@@ -511,7 +515,7 @@ int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms
     // session not sized for n_sets chains): the sets one after the other through the single-set entry -- the same numbers
     const bool batched = s->use_graphs && !s->sharded() && n_sets >= 2 && n_sets <= MAX_FUSED_SETS && c.m <= MAX_FUSED_SLICES &&
                          c.m * n_sets <= s->max_expiries && K * static_cast<size_t>(n_sets) <= s->max_strikes &&
-                         ((s->n_path + 255) / 256) * 2 * static_cast<size_t>(c.m) * n_sets * sizeof(double) <= s->ws_bytes;
+                         static_cast<size_t>(wave_rows(s->n_path)) * 2 * static_cast<size_t>(c.m) * n_sets * sizeof(double) <= s->ws_bytes;
     if (!batched) {
         for (int q = 0; q < n_sets; ++q) {
             const double *pr = params_host + row * q;

@@ -26,6 +26,10 @@ int fail(int code, const std::string &msg);
 
 inline hipStream_t as_stream(svmc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// rows of the generators' per-WAVE spot partials ([column][wave], svmc_kernels.hip SliceOut): one per 64 paths.  A fused launch
+// writes 2 columns per (expiry, parameter set), so its workspace holds wave_rows(n) x 2 x columns doubles
+inline unsigned wave_rows(size_t n) { return static_cast<unsigned>((n + 63) / 64); }
+
 // svmc_kernels.hip: launches whose model constants live in device memory (graph replay, svmc_chain.hip)
 constexpr int LOGSV_CONSTS_DOUBLES = 13;
 int fill_state_indirect(double *x, double *vol, double *qvar, size_t n_path, const double *vol0_dev, hipStream_t stream);

@@ -34,6 +34,28 @@ static inline unsigned rng_grid(size_t n) { return static_cast<unsigned>((n + rn
 
 static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
 
+// In-kernel clock probe of the on-device-RNG LogSV generators (svmc_clock_probe_read; bench.py roofline.clock_mhz_in_kernel).
+// Thread 0 of the launch's FIRST and LAST block stamp s_memtime (tick = shader cycle) and s_memrealtime (100 MHz, chip-wide)
+// at kernel entry and again after the time loop: (t_exit - t_entry) / (r_exit - r_entry) x 100 MHz is the shader clock that
+// wave saw while it stepped -- measured in the timed launch itself, where the SMU's sysfs sensor (absent on some boxes of the
+// pool) lags and averages.  First block = the launch's first residency round, last block = its last one.  A dozen scalar /
+// lane-0 instructions outside the time loop, nothing held in registers across it (the entry stamps go straight to memory).
+// Layout: [which = 0 first block | 1 last block][t_entry, r_entry, t_exit, r_exit]; the latest launch wins.
+__device__ uint64_t g_clock_probe[8];
+
+__device__ __forceinline__ void clock_probe_stamp(int at_exit)
+{
+    const bool first = blockIdx.x == 0u, last = blockIdx.x == gridDim.x - 1u;        // wave-uniform
+    if (first || last) {
+        const uint64_t t = __builtin_readcyclecounter(), r = wall_clock64();
+        if (threadIdx.x == 0u) {
+            uint64_t *o = g_clock_probe + (first ? 0 : 4) + 2 * at_exit;
+            o[0] = t;
+            o[1] = r;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void fill_state_kernel(double *__restrict__ x, double *__restrict__ vol,
                                                            double *__restrict__ qvar, size_t n, double x0,
@@ -188,7 +210,6 @@ struct SliceOut {
     size_t rows = 0;    // column stride of `partials`: wave_rows(n) of the launch
 };
 
-static inline unsigned wave_rows(size_t n) { return static_cast<unsigned>((n + 63) / 64); }
 
 // Start state of a generator launch: read from x / vol / qvar (uniform = 0), or the same three constants for every path --
 // what a chain pricing starts from (x0 = 0, sigma0 | v0, qvar0 = 0: pricers/logsv_pricer.py:823-826, heston_pricer.py:303-305).
@@ -225,6 +246,7 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
+    clock_probe_stamp(0);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -262,6 +284,7 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
         sigma[p] = s;
         qvar[p] = q;
     }
+    clock_probe_stamp(1);
 #ifdef SVMC_TAIL_PROBE
     if ((threadIdx.x & 63u) == 0u && so.q_snap != nullptr) {
         so.q_snap[2 * (p >> 6)] = static_cast<double>(probe_t0);
@@ -311,6 +334,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
     __shared__ double s_exp[256];
     __shared__ double s_park[2 * CHAIN_BLOCK];             // [0, B): x, [B, 2B): qvar -- lane t owns elements t and B + t
     const RngTables tab = stage_tables(s_tab, s_exp);
+    clock_probe_stamp(0);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     // the path index is re-derived from threadIdx.x wherever it is needed (opaque to CSE): one VGPR across the time loop
     // instead of the 64-bit index and the addresses formed from it
@@ -374,6 +398,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
         sigma[p] = s;
         qvar[p] = s_park[CHAIN_BLOCK + threadIdx.x];
     }
+    clock_probe_stamp(1);
 }
 
 // Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
@@ -519,7 +544,6 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_indirect_kernel(double *_
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
                              partials + 2 * static_cast<size_t>(i) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
         slice_epilogue(so, p, active, xv, q);
-        __syncthreads();                                   // the epilogue's LDS scratch is reused by the next slice
     }
     if (active) {
         x[p] = xv;
@@ -589,7 +613,6 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_sets_kernel(size_t n, Cha
             const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
                                  partials + 2 * static_cast<size_t>(row) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
             slice_epilogue(so, p, active, xv[s], q[s]);
-            __syncthreads();                               // the epilogue's LDS scratch is reused by the next one
         }
     }
 }
@@ -1138,7 +1161,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
 // out[j] = sum_r partials[r * ld + j]; one block per column j
 // element (row r, column j) sits at partials[r * row_stride + j * col_stride]: row-major block partials pass (ld, 1), the
 // generators' per-wave spot partials are column-major and pass (1, rows)
-__global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials_base, int n_rows,
+__global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__restrict__ partials_base, unsigned n_rows,
                                                                size_t row_stride, size_t col_stride, double *__restrict__ out)
 {
     __shared__ double lds[4];
@@ -1150,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
     // remain (the whole-chain generators leave 2^15 rows: 32 round trips per thread became 8, 35 us became ~10); the
     // additions keep the order of the one-trip loop, so the sums are the same bits
     double a[4] = {0.0, 0.0, 0.0, 0.0};
-    int r = threadIdx.x;
+    unsigned r = threadIdx.x;
     for (; r + 15 * BLOCK < n_rows; r += 16 * BLOCK) {
         double t[16];
 #pragma unroll
@@ -1256,7 +1279,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
 static int finish_slice_sums(const char *fn, unsigned block_rows, double *spot_sums, void *workspace, svmc_stream_t stream)
 {
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream),
-                       static_cast<const double *>(workspace), static_cast<int>(block_rows), size_t(1), static_cast<size_t>(block_rows), spot_sums);
+                       static_cast<const double *>(workspace), block_rows, size_t(1), static_cast<size_t>(block_rows), spot_sums);
     return check_launch(fn);
 }
 
@@ -1360,7 +1383,7 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
                            cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
                            (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(cs.total_steps);
     }
@@ -1495,7 +1518,7 @@ int logsv_chain_w_indirect(double *x, double *sigma, double *qvar, size_t n_path
                        reinterpret_cast<const LogsvConsts *>(consts_dev), vol0_dev, ldw, x_snapshots, qvar_snapshots,
                        static_cast<double *>(workspace));
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_slices), dim3(BLOCK), 0, stream,
-                       static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
+                       static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
 }
 
@@ -1543,7 +1566,7 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
     default: launch_chain_w_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, ldw, x_snapshots, qvar_snapshots, workspace); break;
     }
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
-                       static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
+                       wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
 }
 
@@ -1725,7 +1748,7 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
                                as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
                                xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), static_cast<int>(wave_rows(n_path)), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
+                           static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(steps);
     }
@@ -1871,6 +1894,14 @@ int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_pat
     return check_launch("svmc_heston_qe_terminal_w");
 }
 
+int svmc_clock_probe_read(uint64_t *stamps, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(stamps != nullptr, "svmc_clock_probe_read: null output");
+    SVMC_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    SVMC_HIP_TRY(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_clock_probe), 8 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost));
+    return SVMC_OK;
+}
+
 int svmc_payoff_workspace_bytes(size_t *bytes)
 {
     SVMC_REQUIRE(bytes != nullptr, "svmc_payoff_workspace_bytes: null output");
@@ -1896,7 +1927,7 @@ int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_
         return fail(SVMC_ERR_WORKSPACE, "svmc_spot_sums: workspace too small (svmc_payoff_workspace_bytes)");
     double *partials = static_cast<double *>(workspace);
     hipLaunchKernelGGL(spot_sums_kernel, dim3(g), dim3(BLOCK), 0, as_stream(stream), x, n_path, forward, partials);
-    hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream), partials, static_cast<int>(g),
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(2), dim3(BLOCK), 0, as_stream(stream), partials, g,
                        size_t(2), size_t(1), spot_sums);
     return check_launch("svmc_spot_sums");
 }
@@ -1964,7 +1995,7 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
         else
             launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<int>(gx), static_cast<size_t>(3 * cols), size_t(1), sums + 3 * first_strike);
+                           static_cast<unsigned>(gx), static_cast<size_t>(3 * cols), size_t(1), sums + 3 * first_strike);
         first_strike += static_cast<size_t>(cols);
         n_groups = cols = kt = 0;
         has_inv = false;

@@ -9,7 +9,7 @@
 //   log_state(s)    any s >= 0, inf, NaN         -> ln(sigma) at slice starts, constants in scalar registers
 //   sqrt_pos(t)     t in (0, 2^10) normal        -> no scaling, v_rsq_f64 seed + one Goldschmidt/Newton pass
 //   sqrt_pos_1g     same, Goldschmidt step only  -> 2^-47 (Heston's sqrt(v))
-//   normal_icdf32   a raw 32-bit word            -> N(0,1) by a piecewise cubic of the inverse CDF, 512-segment table
+//   normal_icdf32   a raw 32-bit word            -> N(0,1) by a piecewise cubic of the inverse CDF, 1024-segment table
 //   exp_fast(x)     |x| < ~1.4e6                 -> 2-constant Cody-Waite reduction, v_ldexp_f64 saturates
 //   exp_tab(x)      log-volatilities             -> 256-entry table, quadratic tail, one reduction constant
 //   rcp_fast(a)     a normal, away from 0/inf    -> v_rcp_f64 seed + Newton, no div_scale/div_fixup

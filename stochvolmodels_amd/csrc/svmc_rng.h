@@ -19,8 +19,8 @@
 //   exponential branch's uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2, drawn lazily.
 // Resolution: a normal carries 32 random bits (as in version 2, whose Box-Muller pair spent 32 on the radius and 32 on
 // the angle); the lattice is 2^-32 in probability, symmetric about 0, largest |z| = -Phi^-1(2^-33) = 6.34 (truncated
-// mass 2.3e-10 per normal).  The cubic deviates from the exact inverse CDF by at most SVMC_ICDF_MAX_ABS_ERROR (1.1e-8)
-// -- a smooth deterministic distortion four orders below the Monte Carlo error of any chain priced here, pinned against
+// mass 2.3e-10 per normal).  The cubic deviates from the exact inverse CDF by at most SVMC_ICDF_MAX_ABS_ERROR (7.431e-10,
+// svmc_icdf_table.h) -- a smooth deterministic distortion five orders below the Monte Carlo error of any chain priced here, pinned against
 // scipy's Phi^-1 in tests/test_oracle_golden.py.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -173,13 +173,19 @@ def set_default_comm(comm) -> None:
     _default_comm = comm if comm is not None else SingleComm()
 
 
-def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
+def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None, on_phase=None):
     """one process per GPU launched by torch.distributed.run: bind LOCAL_RANK's GPU, create the process
     group over RCCL and make it the default communicator of the chain pricers.
 
     comm = "torch" (default): the collectives go through torch.distributed (backend "nccl" = RCCL);
     comm = "rccl" (or SVMC_DIST_COMM=rccl): they go through libsvmc's own RCCL entry points (RcclComm); the torch
-    process group is then only the bootstrap (a gloo group is enough) that ships rank 0's unique id."""
+    process group is then only the bootstrap (a gloo group is enough) that ships rank 0's unique id.
+
+    on_phase(name): called at "rendezvous" (before init_process_group: waits for every rank to arrive), "collective_init"
+    (before the first all-reduce: RCCL builds its communicator there) and "ready" -- a launcher's watchdog arms its
+    per-phase deadlines from it (bench.py: a rank that never arrives or an RCCL init that never returns ends the run
+    with the rank's traceback instead of hanging)."""
+    phase = on_phase if on_phase is not None else (lambda name: None)
     comm = comm or os.environ.get("SVMC_DIST_COMM") or "torch"
     if comm == "rccl" and backend is None and os.environ.get("SVMC_DIST_BACKEND") is None:
         backend = "gloo"
@@ -209,12 +215,14 @@ def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        phase("rendezvous")
         if backend == "nccl":
             dist.init_process_group(backend=backend, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
         # RCCL builds its communicator (rings over xGMI) lazily at the first collective: do that here, once, not
         # inside the first chain that is priced
+        phase("collective_init")
         warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", device) if backend == "nccl" else "cpu")
         dist.all_reduce(warm)
         if warm.is_cuda:
@@ -233,11 +241,13 @@ def init_from_env(backend: Optional[str] = None, comm: Optional[str] = None):
             raise _lib.SvmcError(f"comm='rccl': {tcomm.world} ranks but {count.value} GPU(s) visible -- RCCL needs one "
                                  f"device per rank")
         _lib.check(_lib.load().svmc_set_device(local_rank % max(count.value, 1)))
+        phase("collective_init")
         box = [RcclComm.unique_id() if tcomm.rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         set_default_comm(RcclComm(tcomm.rank, tcomm.world, box[0]))
     else:
         set_default_comm(tcomm)
+    phase("ready")
     return get_default_comm()
 
 

@@ -3,7 +3,7 @@ ModelParams / ModelPricer: the Monte Carlo part of the reference's pricer interf
 (pricers/model_pricer.py:28-41, :83-265).
 
 Kept: price_chain, price_slice, price_vanilla, compute_chain_prices_with_vols, compute_model_ivols_for_chain, model_mc_price_chain,
-simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols,
+simulate_terminal_values, simulate_vol_paths, compute_mc_chain_implied_vols, get_log_return_mc_pdf,
 calibrate_model_params_to_chain with the reference's signatures.  Out of scope: the
 matplotlib plotting methods and the slice / single-option conveniences built on them.
 """
@@ -92,3 +92,22 @@ class ModelPricer(ABC):
         ivols_up = option_chain.compute_model_ivols_from_chain_data(model_prices=ups)
         ivols_down = option_chain.compute_model_ivols_from_chain_data(model_prices=downs)
         return prices, ups, downs, ivols_mid, ivols_up, ivols_down, stds
+
+    def get_log_return_mc_pdf(self, ttm: float, params: ModelParams, x_grid: np.ndarray, nb_path: int = 100000
+                              ) -> np.ndarray:
+        """Gaussian-kernel density of the simulated terminal log-returns on x_grid, normalised to sum to one
+        (reference :243-265; contract: tests/test_model_calibration_contracts.py:121-139 -- paths that are NaN or
+        beyond +-1e16 are counted, reported on stdout and left out).  simulate_terminal_values of the Monte Carlo
+        pricers returns (x, vol, qvar): the density is that of x."""
+        from scipy.stats import gaussian_kde
+        sample = self.simulate_terminal_values(ttm=ttm, params=params, nb_path=nb_path)
+        if isinstance(sample, (tuple, list)):
+            sample = sample[0]
+        sample = np.asarray(sample, dtype=np.float64).ravel()
+        limit = 1e16
+        is_nan = np.isnan(sample)
+        too_high = ~is_nan & (sample > limit)
+        too_low = ~is_nan & (sample < -limit)
+        print(f"in mc: num -inf = {int(too_low.sum())}, num +inf = {int(too_high.sum())}, num nans = {int(is_nan.sum())}")
+        density = gaussian_kde(sample[~(is_nan | too_high | too_low)])(np.asarray(x_grid, dtype=np.float64))
+        return density / np.nansum(density)

@@ -1,5 +1,5 @@
 """
-The N>1 path on CPU: world_size-1/2/3 gloo groups run the PRODUCT chain drivers (path sharding by global path
+The N>1 path on CPU: world_size-1/2/3/8 gloo groups run the PRODUCT chain drivers (path sharding by global path
 id, per-slice step offsets, the two packed all-reduces, host finalisation) with the engine swapped for the
 oracle-backed test double.  Every world size must reproduce the single-process oracle result for the full
 path set: sharding must not change which randoms a path sees, and the partial sums must add up.
@@ -66,7 +66,7 @@ def _expected(oracle):
     return out
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_sharded_chain_matches_single_process(oracle, tmp_path, world):
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + world), WORLD_SIZE=str(world),

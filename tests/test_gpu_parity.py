@@ -707,7 +707,9 @@ def test_c_abi_chain_drivers_sharded_on_one_gpu(sv, world):
                 np.testing.assert_array_equal(out[r][1], out[0][1])
                 np.testing.assert_allclose(out[r][0], ref_p, rtol=1e-12, atol=1e-14)
                 np.testing.assert_allclose(out[r][1], ref_e, rtol=1e-12, atol=1e-14)
-                worst = max(worst, float(np.max(np.abs(out[r][0] / ref_p - 1.0))))
+                nz = ref_p != 0.0                                                 # deep out-of-the-money strikes price to 0
+                worst = max(worst, float(np.nanmax(np.abs(out[r][0][nz] / ref_p[nz] - 1.0))))
+                assert np.all(out[r][0][~nz] == 0.0)
             print(f"C drivers, {world} shards on one GPU, {model}/{kind}: max relative deviation from the unsharded session {worst:.2e}")
         # detaching gives a single-GPU session again
         _lib.check(L.svmc_session_set_reducer(sessions[0], _lib.ALL_REDUCE_FN(0), None, 0, 1, 0, 0))
@@ -1805,9 +1807,71 @@ def test_bench_line_two_ranks(tmp_path):
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     assert line["n1_share_value"] > 0 and line["c4_full_one_gpu"]["paths"] == 1 << 22
     assert line["stream_ordered_equals_strict_sync"] is True and line["comm"] == "TorchComm" and line["backend"] == "gloo"
-    # two ranks on one device: RCCL's own refusal comes back in the line; with a GPU per rank the leg carries a rate
+    # two ranks on one device: the RCCL leg says why it did not run; with a GPU per rank it carries a rate
     rr = line["rccl_route"]
-    assert ("error" in rr) or (rr["value"] > 0 and line["rccl_ranks_seen"] == 2 and rr["prices_equal_torch_route"] is True)
+    assert ("skipped" in rr) or (rr["value"] > 0 and line["rccl_ranks_seen"] == 2 and rr["prices_equal_torch_route"] is True)
+    _check_self_proving_fields(line, 2)
+
+
+def _check_self_proving_fields(line, world):
+    """what makes an N > 1 line prove itself (bench.py docstring): the sharded job equals the whole job on one device to
+    reduction-order rounding, every rank returned the same bits, the group saw every rank, the kernel time of every rank"""
+    sc = line["self_check"]
+    assert "self_check_failed" not in line, line["self_check_failed"]
+    assert sc["ranks_agree_bitwise"] is True and sc["tolerance"] == 1e-12
+    assert 0.0 <= line["sharded_vs_one_gpu_max_rel_dev"] <= 1e-12 and 0.0 <= sc["sharded_vs_one_gpu_max_rel_dev_stderr"] <= 1e-12
+    assert line["group_ranks_seen"] == world
+    k = line["kernel_ms_over_ranks"]
+    assert len(k["per_rank"]) == world and 0.0 < k["min"] <= k["max"]
+    r = line["roofline"]
+    assert 500.0 < r["clock_mhz_in_kernel"] <= 2500.0 and r["frac"] <= r["frac_at_sustained_clock"] < 1.05
+
+
+def test_bench_line_eight_ranks_share_one_gpu():
+    """the rehearsal of the driver's 8-GPU run on the hardware there is: `python bench.py --gpus 8` starts its own eight
+    ranks (gloo: they share this GPU), 8-way shard_range, eight local ranks -> devices, eight torch.distributed.run
+    children; the line must carry the self-proving fields and the command must return 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVMC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SVMC_BENCH_PREWARM="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--paths-per-gpu", "131072",
+                          "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env,
+                         timeout=900, cwd=root)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["paths_total"] == 8 * 131072 and line["config"]["parallelism"] == "path-sharded x8"
+    assert line["self_launched"] is True and line["backend"] == "gloo" and "skipped" in line["rccl_route"]
+    assert line["n1_share_value"] > 0 and line["c4_full_one_gpu"]["paths"] == 8 * 131072
+    _check_self_proving_fields(line, 8)
+    print("8 ranks on one GPU: sharded vs one-GPU job", line["sharded_vs_one_gpu_max_rel_dev"],
+          "kernel ms over ranks", line["kernel_ms_over_ranks"])
+
+
+def test_bench_fails_fast_when_a_rank_never_arrives():
+    """a rank that hangs before the rendezvous (fault injection) must end the command with a non-zero status and that
+    rank's message on stderr within its deadline -- not hang until the driver's timeout"""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SVMC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SVMC_BENCH_PREWARM="1",
+               SVMC_BENCH_FAULT="hang_init:1", SVMC_BENCH_INIT_TIMEOUT="8", SVMC_BENCH_RENDEZVOUS_TIMEOUT="30")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--paths-per-gpu", "4096", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True, env=env,
+                         timeout=600, cwd=root)
+    took = time.time() - t0
+    assert run.returncode != 0, run.stdout[-1000:]
+    assert "did not finish within" in run.stderr and "rank 1" in run.stderr, run.stderr[-3000:]
+    assert took < 300, took
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -150,6 +150,33 @@ def test_base_class_contract():
             call()
 
 
+def test_mc_pdf_filters_invalid_paths_and_normalises(capsys):
+    """the contract of ModelPricer.get_log_return_mc_pdf (reference tests/test_model_calibration_contracts.py:121-139):
+    NaN and out-of-range paths are counted on stdout and left out, the density is finite, non-negative and sums to one;
+    a pricer whose simulate_terminal_values returns the Monte Carlo triple (x, vol, qvar) is read through x"""
+    class Flat(sv.ModelPricer):
+        def simulate_terminal_values(self, params, **kwargs):
+            return np.array([-0.2, -0.1, 0.0, 0.1, 0.2, np.nan, np.inf, -np.inf])
+
+    class Triple(sv.ModelPricer):
+        def simulate_terminal_values(self, params, **kwargs):
+            x = np.array([-0.2, -0.1, 0.0, 0.1, 0.2, np.nan, np.inf, -np.inf])
+            return x, np.ones(8), np.zeros(8)
+    grid = np.linspace(-0.5, 0.5, 51)
+    dens = []
+    for cls in (Flat, Triple):
+        density = cls().get_log_return_mc_pdf(ttm=0.25, params=None, x_grid=grid, nb_path=8)
+        assert np.all(np.isfinite(density)) and np.all(density >= 0.0)
+        np.testing.assert_allclose(np.sum(density), 1.0, rtol=0.0, atol=1e-14)
+        out = capsys.readouterr().out
+        assert "num -inf = 1" in out and "num +inf = 1" in out and "num nans = 1" in out
+        dens.append(density)
+    np.testing.assert_array_equal(dens[0], dens[1])
+    from scipy.stats import gaussian_kde
+    want = gaussian_kde(np.array([-0.2, -0.1, 0.0, 0.1, 0.2]))(grid)
+    np.testing.assert_allclose(dens[0], want / want.sum(), rtol=1e-14)
+
+
 def test_lazy_exports():
     assert "logsv_mc_chain_pricer_fixed_randoms" in dir(sv)
     with pytest.raises(AttributeError):
@@ -336,6 +363,21 @@ def test_bench_workloads_and_roofline_arithmetic():
     assert abs(r["frac_in_stream_int32_cost"] - r["frac"] * in_stream / cyc) < 1e-12
     assert r["clock_mhz_sensor"] == 2400.0 and r["traffic"] == 59.0e6 and r["stale"] is False
     assert r["insts_per_wave_step_counters"] == 53.2
+    assert r["clock_mhz_in_kernel"] is None and r["frac_at_sustained_clock"] is None        # no stamps handed in
+    # the in-kernel clock: first block 2.0e6 shader cycles in 1e5 ticks of the 100 MHz clock = 2000 MHz, last block 2200 MHz
+    stamps = [10, 1000, 10 + 2_000_000, 1000 + 100_000, 50, 7000, 50 + 1_100_000, 7000 + 50_000]
+    rc = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, None, stamps)["roofline"]
+    assert abs(rc["clock_probe"]["first_block"]["mhz"] - 2000.0) < 1e-9 and abs(rc["clock_probe"]["last_block"]["mhz"] - 2200.0) < 1e-9
+    assert abs(rc["clock_mhz_in_kernel"] - 2100.0) < 1e-9 and abs(rc["clock_probe"]["first_block"]["wave_lifetime_ms"] - 1.0) < 1e-12
+    assert abs(rc["frac_at_sustained_clock"] - rc["frac"] * 2400.0 / 2100.0) < 1e-12
+    assert abs(rc["frac_in_stream_at_sustained_clock"] - rc["frac_in_stream_int32_cost"] * 2400.0 / 2100.0) < 1e-12
+    assert bench.clock_from_stamps([0] * 8) == {}                                               # a launch that never stamped
+    # the N > 1 self-check's deviation measure: relative, zero references only match zeros, NaN patterns must agree
+    assert bench.max_rel_dev([np.array([1.0, 2.0])], [np.array([1.0, 2.0 * (1 + 1e-13)])]) < 1.1e-13
+    assert bench.max_rel_dev([np.array([0.0, 2.0])], [np.array([0.0, 2.0])]) == 0.0
+    assert bench.max_rel_dev([np.array([1e-30, 2.0])], [np.array([0.0, 2.0])]) == float("inf")
+    assert bench.max_rel_dev([np.array([np.nan, 2.0])], [np.array([1.0, 2.0])]) == float("inf")
+    assert bench.max_rel_dev([np.array([1.0])], [np.array([1.0, 2.0])]) == float("inf")
     rr = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, 2400.0)
     assert rr["roofline_hbm"]["algorithmic_bytes"] == 32.0 * 2 ** 20
     # a library that is not the one the histogram describes: stale; counters of another build are not quoted
@@ -352,6 +394,11 @@ def test_bench_workloads_and_roofline_arithmetic():
     live = bench.load_isa(_lib.LIB_PATH)
     assert live["stale"] is False and live["kernels"]["logsv_rng_kernel"]["valu"] > 60
     assert live["kernels"]["logsv_chain_rng_kernel"]["classes"]["quarter"] == 2
+    # ... and the register / scratch / LDS footprint of every kernel of the build: the stepping kernels must not spill
+    import json
+    meta = json.load(open(os.path.join(os.path.dirname(_lib.LIB_PATH), "libsvmc.isa.json")))["metadata"]
+    stepping = [k for k in meta if "rng_kernel" in k]
+    assert len(stepping) >= 6 and all(meta[k]["scratch_bytes"] == 0 for k in stepping), {k: meta[k] for k in stepping}
 
 
 def test_batched_gradient_uses_scipys_difference_points():
