@@ -630,58 +630,155 @@ __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__re
 }
 
 // Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
-template <bool RNG>
-__global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n,
-                                                                int nb_steps, double dt, double v0, double k1theta,
-                                                                double kappa1, double kappa2, double theta, double adj,
-                                                                double half_vartheta2, double vartheta,
-                                                                const double *__restrict__ brownians, size_t ldb,
-                                                                uint64_t seed, uint32_t c3, uint64_t path_offset)
+//
+// Round 4.  The first version stored `*out = s` per lane per step -- one global_store_dwordx2 per wave per step, 512 B -- and
+// ran its 8.6 GB of stores at 3.7 TB/s (0.46 of HBM peak) beside a 48-instruction step.  Now:
+//   * 16-BYTE STORES: a wave stages the sigmas of TWO consecutive steps in a wave-private kilobyte of LDS ([2][64] doubles:
+//     ds_write_b64 per step, conflict-free) and reads them back transposed -- lane l takes the pair (2 (l & 31), + 1) of row
+//     l >> 5 with one conflict-free ds_read_b128 -- so ONE global_store_dwordx4 writes 512 contiguous bytes of row t + 1 (lanes
+//     0-31) and 512 of row t + 2 (lanes 32-63): half the store instructions for the same bytes (8-byte accesses run at 0.54-0.70
+//     of the 16-byte rate, MI355X_MICROARCH.md).  No barrier: the LDS serves a wave's DS instructions in order, and the region
+//     is the wave's own.  Waves that hold the last, partial 64 paths (or an odd leading dimension) keep the 8-byte store.
+//   * the stores are NON-TEMPORAL where that measures faster (SVMC_VOLPATHS_NT): the rows are written once and never re-read.
+//   * a SHORTER step, the generators' form: ln sigma carried in units of ln2/256 so that exp2u_tab's reduction is exact, the
+//     drift regrouped into four FMAs on host-scaled constants (logsv_step_acc's), rcp_1n for the 1/sigma term (it enters L
+//     at 1e-3 of its size): 48 -> 36 VALU instructions per path-step.  Identical in exact arithmetic to :942; rounding differs
+//     at the 1e-16 level per step (tests hold both against the reference's golden paths at 1e-12).
+//   * supplied brownians are loaded a group of four steps ahead (two groups in flight).
+struct VolPathConsts {
+    double c1;      // kappa1 theta dt K          (K = 256 / ln2: L is carried in units of ln2 / 256)
+    double c2;      // (adj - kappa2) dt K
+    double c3;      // (kappa2 theta - kappa1 - vartheta^2 / 2) dt K
+    double cz;      // vartheta K for supplied (already scaled) increments, vartheta sqrt(dt) K for the kernel's own N(0,1)
+    double L0;      // ln(v0) K
+};
+
+#ifndef SVMC_VOLPATHS_NT
+#define SVMC_VOLPATHS_NT 1             // A/B hook: non-temporal stores
+#endif
+#ifndef SVMC_VOLPATHS_WIDE
+#define SVMC_VOLPATHS_WIDE 1           // A/B hook: 16-byte stores through the wave-private LDS transpose
+#endif
+#ifndef SVMC_VOLPATHS_RNG_BLOCK
+#define SVMC_VOLPATHS_RNG_BLOCK 1024   // drawing instantiation: two blocks per CU hold the draw's table + 16 KB of staging each
+#endif
+constexpr int VOLPATHS_RNG_BLOCK = SVMC_VOLPATHS_RNG_BLOCK;
+typedef double vp_double2 __attribute__((ext_vector_type(2)));
+
+template <class T>
+__device__ __forceinline__ void vol_paths_store(T *ptr, T v)
 {
+#if SVMC_VOLPATHS_NT
+    __builtin_nontemporal_store(v, ptr);
+#else
+    *ptr = v;
+#endif
+}
+
+template <bool RNG>
+__global__ __launch_bounds__(RNG ? VOLPATHS_RNG_BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, int nb_steps, double v0, VolPathConsts c,
+                            const double *__restrict__ brownians, size_t ldb, uint64_t seed, uint32_t c3, uint64_t path_offset)
+{
+    constexpr int TB = RNG ? VOLPATHS_RNG_BLOCK : BLOCK;
     __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
+    __shared__ double s_stage[2 * TB];                     // per wave [2][64]: the sigmas of two steps, read back transposed
     const RngTables tab = stage_tables_if(s_tab, s_exp);
-    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    double s = v0, L = log(v0);
-    sigma_t[p] = s;                                                                             // :937
-    const double sdt = sqrt(dt);
-    double *out = sigma_t + ld + p;                        // row t + 1 of this path
-    const auto step = [&](double w) {                      // w: the scaled increment sqrt(dt) N(0,1)               :925
-        const double drift = ((((k1theta * rcp_fast(s)) - kappa1) + kappa2 * (theta - s)) + adj * s) - half_vartheta2;
-        L = (L + drift * dt) + vartheta * w;                                                    // :942
-        s = exp_tab(L, s_exp);                                                                  // :943
-        *out = s;                                                                               // :944
-        out += ld;
+    const size_t p = static_cast<size_t>(blockIdx.x) * TB + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t wave_p0 = p - lane;
+    if (wave_p0 >= n) return;                              // wave-uniform: whole waves past the last path leave
+    const bool active = p < n;
+    // 16-byte stores need the wave's 64 paths in range and every row 16-byte aligned (wave-uniform choice)
+    const bool wide = SVMC_VOLPATHS_WIDE && (wave_p0 + 64 <= n) && ((ld & 1u) == 0u) &&
+                      ((reinterpret_cast<uintptr_t>(sigma_t) & 15u) == 0u);
+    double s = v0, L = c.L0;
+    if (active) vol_paths_store(sigma_t + p, s);                                                // :937
+    double *const stage = s_stage + 128u * (threadIdx.x >> 6);
+    // narrow form: row t + 1 of this path; wide form: this lane's pair of row t + 1 + (lane >> 5)
+    double *out = wide ? sigma_t + ld * (1u + (lane >> 5)) + wave_p0 + 2u * (lane & 31u) : sigma_t + ld + p;
+    const auto step = [&](double w) {                      // w: N(0,1) (RNG) or the scaled increment sqrt(dt) N(0,1)   :925
+        const double y = rcp_1n(s);
+        L = fma(c.c2, s, L);                                                                    // :942, regrouped
+        L = fma(c.c1, y, L);
+        L = L + c.c3;
+        L = fma(c.cz, w, L);
+        s = exp2u_tab(L, s_exp);                                                                // :943
     };
+    // two steps and their stores                                                               :944
+    const auto two_steps = [&](double wa, double wb) {
+        step(wa);
+        const double sa = s;
+        step(wb);
+        if (wide) {
+            stage[lane] = sa;
+            stage[64u + lane] = s;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const vp_double2 v = *reinterpret_cast<const vp_double2 *>(stage + 64u * (lane >> 5) + 2u * (lane & 31u));
+            __builtin_amdgcn_wave_barrier();
+            vol_paths_store(reinterpret_cast<vp_double2 *>(out), v);
+        } else if (active) {
+            vol_paths_store(out, sa);
+            vol_paths_store(out + ld, s);
+        }
+        out += 2 * ld;
+    };
+    const auto last_step = [&](double w) {                 // an odd step count ends with one row: 8-byte stores
+        step(w);
+        double *row = wide ? out - ld * (lane >> 5) - wave_p0 - 2u * (lane & 31u) + p : out;
+        if (active) vol_paths_store(row, s);
+    };
+    int t = 0;
     if (RNG) {
         // one Brownian per step: normal t is the inversion of word t & 3 of call t >> 2 (stream 2) -- a Philox call
         // serves four steps, so the loop runs call by call with no per-step selects
-        const PhiloxLane lane = philox_prepare(seed, c3 | 2u, path_offset + p);
+        const PhiloxLane pl = philox_prepare(seed, c3 | 2u, path_offset + p);
         uint32_t r[4];
         double a0, a1, b0, b1;
-        int t = 0;
         for (; t + 4 <= nb_steps; t += 4) {
-            philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
+            philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
             normals_from_words(r[0], r[1], tab, a0, a1);
             normals_from_words(r[2], r[3], tab, b0, b1);
-            step(sdt * a0);
-            step(sdt * a1);
-            step(sdt * b0);
-            step(sdt * b1);
+            two_steps(a0, a1);
+            two_steps(b0, b1);
         }
         if (t < nb_steps) {                                // the last, partial call (wave-uniform)
-            philox_draw(lane, static_cast<uint32_t>(t >> 2), r);
+            philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
             normals_from_words(r[0], r[1], tab, a0, a1);
-            step(sdt * a0);
-            if (t + 1 < nb_steps) step(sdt * a1);
-            if (t + 2 < nb_steps) {
-                normals_from_words(r[2], r[3], tab, b0, b1);
-                step(sdt * b0);
+            normals_from_words(r[2], r[3], tab, b0, b1);
+            if (t + 2 <= nb_steps) {
+                two_steps(a0, a1);
+                if (t + 3 <= nb_steps) last_step(b0);
+            } else {
+                last_step(a0);
             }
         }
     } else {
-        for (int t = 0; t < nb_steps; ++t) step(brownians[static_cast<size_t>(t) * ldb + p]);
+        const double *w = brownians + (active ? p : wave_p0);
+        double a[4], b[4];
+        if (nb_steps >= 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = w[static_cast<size_t>(u) * ldb];
+            for (; t + 8 <= nb_steps; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = w[static_cast<size_t>(t + 4 + u) * ldb];       // the next group, in flight
+                two_steps(a[0], a[1]);
+                two_steps(a[2], a[3]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = b[u];
+            }
+            two_steps(a[0], a[1]);
+            two_steps(a[2], a[3]);
+            t += 4;
+        }
+        if (t + 2 <= nb_steps) {
+            const double wa = w[static_cast<size_t>(t) * ldb], wb = w[static_cast<size_t>(t + 1) * ldb];
+            two_steps(wa, wb);
+            t += 2;
+        }
+        if (t < nb_steps) last_step(w[static_cast<size_t>(t) * ldb]);
     }
 }
 
@@ -1622,14 +1719,20 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
     if (n_path == 0) return SVMC_OK;
     const double adj = is_spot_measure ? 0.0 : beta;                                            // :930-933
     const double vartheta2 = beta * beta + volvol * volvol;
+    const double K = LOG_UNITS_PER_NAT;
+    VolPathConsts c;
+    c.c1 = kappa1 * theta * dt * K;
+    c.c2 = (adj - kappa2) * dt * K;
+    c.c3 = (kappa2 * theta - kappa1 - 0.5 * vartheta2) * dt * K;
+    c.cz = sqrt(vartheta2) * K * (brownians != nullptr ? 1.0 : sqrt(dt));
+    c.L0 = log(v0) * K;
     if (brownians != nullptr)
         hipLaunchKernelGGL(logsv_vol_paths_kernel<false>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
-                           sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
-                           0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
+                           sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb, seed, make_c3(call_id), path_offset);
     else
-        hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream),
-                           sigma_t, ld, n_path, nb_steps, dt, v0, kappa1 * theta, kappa1, kappa2, theta, adj,
-                           0.5 * vartheta2, sqrt(vartheta2), brownians, ldb, seed, make_c3(call_id), path_offset);
+        hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(static_cast<unsigned>((n_path + VOLPATHS_RNG_BLOCK - 1) / VOLPATHS_RNG_BLOCK)),
+                           dim3(VOLPATHS_RNG_BLOCK), 0, as_stream(stream), sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb,
+                           seed, make_c3(call_id), path_offset);
     return check_launch("svmc_logsv_vol_paths");
 }
 
