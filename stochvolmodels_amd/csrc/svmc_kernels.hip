@@ -629,22 +629,24 @@ __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__re
     }
 }
 
-// Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): HBM-write-bound, 8 B per path-step.
+// Volatility paths on the full grid (pricers/logsv_pricer.py:930-945): 8 B written per path-step.
 //
-// Round 4.  The first version stored `*out = s` per lane per step -- one global_store_dwordx2 per wave per step, 512 B -- and
-// ran its 8.6 GB of stores at 3.7 TB/s (0.46 of HBM peak) beside a 48-instruction step.  Now:
-//   * 16-BYTE STORES: a wave stages the sigmas of TWO consecutive steps in a wave-private kilobyte of LDS ([2][64] doubles:
-//     ds_write_b64 per step, conflict-free) and reads them back transposed -- lane l takes the pair (2 (l & 31), + 1) of row
-//     l >> 5 with one conflict-free ds_read_b128 -- so ONE global_store_dwordx4 writes 512 contiguous bytes of row t + 1 (lanes
-//     0-31) and 512 of row t + 2 (lanes 32-63): half the store instructions for the same bytes (8-byte accesses run at 0.54-0.70
-//     of the 16-byte rate, MI355X_MICROARCH.md).  No barrier: the LDS serves a wave's DS instructions in order, and the region
-//     is the wave's own.  Waves that hold the last, partial 64 paths (or an odd leading dimension) keep the 8-byte store.
-//   * the stores are NON-TEMPORAL where that measures faster (SVMC_VOLPATHS_NT): the rows are written once and never re-read.
-//   * a SHORTER step, the generators' form: ln sigma carried in units of ln2/256 so that exp2u_tab's reduction is exact, the
-//     drift regrouped into four FMAs on host-scaled constants (logsv_step_acc's), rcp_1n for the 1/sigma term (it enters L
-//     at 1e-3 of its size): 48 -> 36 VALU instructions per path-step.  Identical in exact arithmetic to :942; rounding differs
-//     at the 1e-16 level per step (tests hold both against the reference's golden paths at 1e-12).
-//   * supplied brownians are loaded a group of four steps ahead (two groups in flight).
+// Round 4 (profiles/r04_vol_paths.json, tools/r04/write_bw.hip, tools/ubench/ab_vol_paths.py; 2^20 paths x 1024 steps, 8.6 GB):
+//   * what the chip does with this store pattern and NO arithmetic -- a wave owns 64 columns and walks the rows, 512 B per
+//     wave-store -- is 5.7 TB/s (hipMemset: 6.3; 8- and 16-byte stores, plain / nt / sc1 policies all within 3 %, nt the
+//     slowest); a copy in the same pattern (supplied brownians: 8 B read + 8 B written per path-step) runs at 4.84 TB/s of
+//     total traffic, as does hipMemcpy -- the SUPPLIED instantiation sits on that roof (3.5-3.6 ms for 17.2 GB).
+//   * the DRAWING instantiation is POWER-bound, not store-bound: its arithmetic alone (stores disabled) takes 1.27 ms at a
+//     measured 2.0 GHz, its stores alone 1.5 ms -- but with both the shader clock inside the kernel falls to 1.45-1.5 GHz
+//     (clock_probe_stamp: s_memtime against s_memrealtime) and the launch takes 1.95 ms = 4.4 TB/s.  Sixteen-byte stores
+//     through a wave-private LDS transpose (half the store instructions) measured 4-6 % SLOWER -- the extra LDS traffic costs
+//     more power than the store issue it saves -- and were removed again; so were non-temporal and write-through policies.
+//   * what did help is a SHORTER step, the generators' form: ln sigma carried in units of ln2/256 so that exp2u_tab's
+//     reduction is exact, the drift regrouped into four FMAs on host-scaled constants (logsv_step_acc's), rcp_1n for the
+//     1/sigma term (it enters L at 1e-3 of its size): 48 -> 33 VALU instructions per path-step, 2.10 -> 1.95 ms on one box.
+//     Identical in exact arithmetic to :942; rounding differs at the 1e-16 level per step (the tests hold both instantiations
+//     against the reference's golden paths at 1e-12).
+//   * supplied brownians are loaded a group of four steps ahead.
 struct VolPathConsts {
     double c1;      // kappa1 theta dt K          (K = 256 / ln2: L is carried in units of ln2 / 256)
     double c2;      // (adj - kappa2) dt K
@@ -653,23 +655,18 @@ struct VolPathConsts {
     double L0;      // ln(v0) K
 };
 
-#ifndef SVMC_VOLPATHS_NT
-#define SVMC_VOLPATHS_NT 1             // A/B hook: non-temporal stores
-#endif
-#ifndef SVMC_VOLPATHS_WIDE
-#define SVMC_VOLPATHS_WIDE 1           // A/B hook: 16-byte stores through the wave-private LDS transpose
-#endif
 #ifndef SVMC_VOLPATHS_RNG_BLOCK
-#define SVMC_VOLPATHS_RNG_BLOCK 1024   // drawing instantiation: two blocks per CU hold the draw's table + 16 KB of staging each
+#define SVMC_VOLPATHS_RNG_BLOCK 1024   // drawing instantiation: two blocks per CU share one copy each of the draw's table
 #endif
 constexpr int VOLPATHS_RNG_BLOCK = SVMC_VOLPATHS_RNG_BLOCK;
-typedef double vp_double2 __attribute__((ext_vector_type(2)));
+#ifndef SVMC_VOLPATHS_PROBE
+#define SVMC_VOLPATHS_PROBE 0          // measurement builds only (tools/ubench/ab_vol_paths.py): 1 = no stores (the store stays in
+#endif                                 // the code behind a test that never holds), 2 = every store lands on row 1 (L2-resident)
 
-template <class T>
-__device__ __forceinline__ void vol_paths_store(T *ptr, T v)
+__device__ __forceinline__ void vol_paths_store(double *ptr, double v)
 {
-#if SVMC_VOLPATHS_NT
-    __builtin_nontemporal_store(v, ptr);
+#if SVMC_VOLPATHS_PROBE == 1
+    if (v == -1.2345e300) *ptr = v;
 #else
     *ptr = v;
 #endif
@@ -683,103 +680,73 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
     constexpr int TB = RNG ? VOLPATHS_RNG_BLOCK : BLOCK;
     __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
-    __shared__ double s_stage[2 * TB];                     // per wave [2][64]: the sigmas of two steps, read back transposed
     const RngTables tab = stage_tables_if(s_tab, s_exp);
+    clock_probe_stamp(0);
     const size_t p = static_cast<size_t>(blockIdx.x) * TB + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63u;
-    const size_t wave_p0 = p - lane;
-    if (wave_p0 >= n) return;                              // wave-uniform: whole waves past the last path leave
-    const bool active = p < n;
-    // 16-byte stores need the wave's 64 paths in range and every row 16-byte aligned (wave-uniform choice)
-    const bool wide = SVMC_VOLPATHS_WIDE && (wave_p0 + 64 <= n) && ((ld & 1u) == 0u) &&
-                      ((reinterpret_cast<uintptr_t>(sigma_t) & 15u) == 0u);
-    double s = v0, L = c.L0;
-    if (active) vol_paths_store(sigma_t + p, s);                                                // :937
-    double *const stage = s_stage + 128u * (threadIdx.x >> 6);
-    // narrow form: row t + 1 of this path; wide form: this lane's pair of row t + 1 + (lane >> 5)
-    double *out = wide ? sigma_t + ld * (1u + (lane >> 5)) + wave_p0 + 2u * (lane & 31u) : sigma_t + ld + p;
-    const auto step = [&](double w) {                      // w: N(0,1) (RNG) or the scaled increment sqrt(dt) N(0,1)   :925
-        const double y = rcp_1n(s);
-        L = fma(c.c2, s, L);                                                                    // :942, regrouped
-        L = fma(c.c1, y, L);
-        L = L + c.c3;
-        L = fma(c.cz, w, L);
-        s = exp2u_tab(L, s_exp);                                                                // :943
-    };
-    // two steps and their stores                                                               :944
-    const auto two_steps = [&](double wa, double wb) {
-        step(wa);
-        const double sa = s;
-        step(wb);
-        if (wide) {
-            stage[lane] = sa;
-            stage[64u + lane] = s;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const vp_double2 v = *reinterpret_cast<const vp_double2 *>(stage + 64u * (lane >> 5) + 2u * (lane & 31u));
-            __builtin_amdgcn_wave_barrier();
-            vol_paths_store(reinterpret_cast<vp_double2 *>(out), v);
-        } else if (active) {
-            vol_paths_store(out, sa);
-            vol_paths_store(out + ld, s);
-        }
-        out += 2 * ld;
-    };
-    const auto last_step = [&](double w) {                 // an odd step count ends with one row: 8-byte stores
-        step(w);
-        double *row = wide ? out - ld * (lane >> 5) - wave_p0 - 2u * (lane & 31u) + p : out;
-        if (active) vol_paths_store(row, s);
-    };
-    int t = 0;
-    if (RNG) {
-        // one Brownian per step: normal t is the inversion of word t & 3 of call t >> 2 (stream 2) -- a Philox call
-        // serves four steps, so the loop runs call by call with no per-step selects
-        const PhiloxLane pl = philox_prepare(seed, c3 | 2u, path_offset + p);
-        uint32_t r[4];
-        double a0, a1, b0, b1;
-        for (; t + 4 <= nb_steps; t += 4) {
-            philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
-            normals_from_words(r[0], r[1], tab, a0, a1);
-            normals_from_words(r[2], r[3], tab, b0, b1);
-            two_steps(a0, a1);
-            two_steps(b0, b1);
-        }
-        if (t < nb_steps) {                                // the last, partial call (wave-uniform)
-            philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
-            normals_from_words(r[0], r[1], tab, a0, a1);
-            normals_from_words(r[2], r[3], tab, b0, b1);
-            if (t + 2 <= nb_steps) {
-                two_steps(a0, a1);
-                if (t + 3 <= nb_steps) last_step(b0);
-            } else {
-                last_step(a0);
+    if (p < n) {
+        double s = v0, L = c.L0;
+        vol_paths_store(sigma_t + p, s);                                                        // :937
+        double *out = sigma_t + ld + p;                    // row t + 1 of this path
+        const auto step = [&](double w) {                  // w: N(0,1) (RNG) or the scaled increment sqrt(dt) N(0,1)   :925
+            const double y = rcp_1n(s);
+            L = fma(c.c2, s, L);                                                                // :942, regrouped
+            L = fma(c.c1, y, L);
+            L = L + c.c3;
+            L = fma(c.cz, w, L);
+            s = exp2u_tab(L, s_exp);                                                            // :943
+            vol_paths_store(out, s);                                                            // :944
+#if SVMC_VOLPATHS_PROBE != 2
+            out += ld;
+#endif
+        };
+        int t = 0;
+        if (RNG) {
+            // one Brownian per step: normal t is the inversion of word t & 3 of call t >> 2 (stream 2) -- a Philox call
+            // serves four steps, so the loop runs call by call with no per-step selects
+            const PhiloxLane pl = philox_prepare(seed, c3 | 2u, path_offset + p);
+            uint32_t r[4];
+            double a0, a1, b0, b1;
+            for (; t + 4 <= nb_steps; t += 4) {
+                philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
+                normals_from_words(r[0], r[1], tab, a0, a1);
+                normals_from_words(r[2], r[3], tab, b0, b1);
+                step(a0);
+                step(a1);
+                step(b0);
+                step(b1);
             }
-        }
-    } else {
-        const double *w = brownians + (active ? p : wave_p0);
-        double a[4], b[4];
-        if (nb_steps >= 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = w[static_cast<size_t>(u) * ldb];
-            for (; t + 8 <= nb_steps; t += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = w[static_cast<size_t>(t + 4 + u) * ldb];       // the next group, in flight
-                two_steps(a[0], a[1]);
-                two_steps(a[2], a[3]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = b[u];
+            if (t < nb_steps) {                            // the last, partial call (wave-uniform)
+                philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
+                normals_from_words(r[0], r[1], tab, a0, a1);
+                step(a0);
+                if (t + 1 < nb_steps) step(a1);
+                if (t + 2 < nb_steps) {
+                    normals_from_words(r[2], r[3], tab, b0, b1);
+                    step(b0);
+                }
             }
-            two_steps(a[0], a[1]);
-            two_steps(a[2], a[3]);
-            t += 4;
+        } else {
+            const double *w = brownians + p;
+            double a[4], b[4];
+            if (nb_steps >= 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = w[static_cast<size_t>(u) * ldb];
+                for (; t + 8 <= nb_steps; t += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[u] = w[static_cast<size_t>(t + 4 + u) * ldb];   // the next group, in flight
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) step(a[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = b[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) step(a[u]);
+                t += 4;
+            }
+            for (; t < nb_steps; ++t) step(w[static_cast<size_t>(t) * ldb]);
         }
-        if (t + 2 <= nb_steps) {
-            const double wa = w[static_cast<size_t>(t) * ldb], wb = w[static_cast<size_t>(t + 1) * ldb];
-            two_steps(wa, wb);
-            t += 2;
-        }
-        if (t < nb_steps) last_step(w[static_cast<size_t>(t) * ldb]);
     }
+    clock_probe_stamp(1);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,76 @@
+"""Monte Carlo model of the LDS-array cycles of the draw's table reads (ds_read_b128: four service groups of 16 lanes, one
+cycle per group when the 16 lanes' 16-byte pieces sit on 16 distinct bank quads, +1 per extra DISTINCT address on a busy quad;
+identical addresses broadcast -- MI355X_MICROARCH.md, LDS).  Segment of a lane: octave k with probability 2^-(k+1), one of its
+32 equal parts uniformly; byte offset of the piece = 16 * segment.
+
+    python tools/r04/lds_conflict_sim.py
+
+Layouts: the committed one, and partial replication of the hot octaves with the replica picked by a lane's position in its
+service group."""
+import numpy as np
+
+rng = np.random.default_rng(1)
+GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+GROUPS = GROUPS + [[l + 32 for l in g] for g in GROUPS]
+POS = np.zeros(64, dtype=int)
+for g in GROUPS:
+    for k, l in enumerate(g):
+        POS[l] = k
+
+
+def draw_segments(n_waves):
+    u = rng.random((n_waves, 64))
+    octave = np.minimum(np.floor(-np.log2(1.0 - u)).astype(int), 29)       # k = 0: top octave, prob 1/2
+    sub = rng.integers(0, 32, size=(n_waves, 64))
+    return octave, sub
+
+
+def cycles(addr_quads, addrs):
+    """addr_quads, addrs: [n_waves, 64] bank quad (0..15) and unique address id of each lane's piece -> mean cycles per instr"""
+    total = 0
+    n = addrs.shape[0]
+    for g in GROUPS:
+        q = addr_quads[:, g]
+        a = addrs[:, g]
+        worst = np.zeros(n, dtype=int)
+        for quad in range(16):
+            m = q == quad
+            # number of distinct addresses on this quad per wave
+            aa = np.where(m, a, -1)
+            aa.sort(axis=1)
+            distinct = (np.diff(aa, axis=1) != 0).sum(axis=1) + 1 - (aa[:, 0] == -1)   # -1 entries collapse into one "distinct"
+            worst = np.maximum(worst, distinct)
+        total += worst
+    return total.mean()
+
+
+def layout_committed(octave, sub):
+    seg = (29 - octave) * 32 + sub
+    return seg % 16, seg
+
+
+def layout_replicated(octave, sub, hot_octaves, R, skew):
+    """hot octaves: R replicas; replica r = position-in-group mod R; replica r of hot segment h (0 .. 32 hot_octaves - 1) sits at
+    entry index base + h * R + r when skew == 'interleave' (adjacent quads), or in its own copy rotated by r * (16 // R) quads"""
+    seg = (29 - octave) * 32 + sub
+    hot = octave < hot_octaves
+    h = octave * 32 + sub
+    r = POS[None, :] % R
+    if skew == "interleave":
+        idx = 100000 + h * R + r
+        quad = (h * R + r) % 16
+    else:
+        idx = 100000 + r * 4096 + h
+        quad = (h + r * (16 // R)) % 16
+    return np.where(hot, quad, seg % 16), np.where(hot, idx, seg)
+
+
+octave, sub = draw_segments(20000)
+q, a = layout_committed(octave, sub)
+print(f"committed layout: {cycles(q, a):.2f} LDS cycles per ds_read_b128 (conflict-free: 4; measured on the device: 10.7)")
+for hot in (1, 2, 3):
+    for R in (2, 4, 8, 16):
+        for skew in ("interleave", "rotate"):
+            q, a = layout_replicated(octave, sub, hot, R, skew)
+            kb = hot * 32 * R * 32 / 1024
+            print(f"hot octaves {hot}, {R:2d} replicas ({skew:10s}): {cycles(q, a):.2f} cycles, +{kb:.0f} KB of LDS")
