@@ -1105,7 +1105,7 @@ constexpr int PAYOFF_PREFETCH = SVMC_PAYOFF_PREFETCH;     // trips between a pat
 #define SVMC_PAYOFF_BLOCKS 1024
 #endif
 constexpr unsigned PAYOFF_BLOCKS = SVMC_PAYOFF_BLOCKS;    // path blocks per payoff launch, all groups together
-constexpr int PAYOFF_KT = 24;          // strikes per group (the BASELINE chains have 21 per expiry)
+constexpr int PAYOFF_KT = 22;          // strikes per group (the BASELINE chains have 21 per expiry); 23 and 24 spilled 20-44 B per lane at the 256 registers two waves per SIMD leave, so wider expiries split
 
 struct PayoffGroup {
     const double *x, *qvar, *spot_sums;
@@ -1132,10 +1132,14 @@ __device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigne
 }
 
 // waves per SIMD the register allocator must leave room for: the accumulators (4 or 6 registers per strike) set it
-constexpr int payoff_min_waves(int kt, bool has_inv) { return kt <= (has_inv ? 8 : 15) ? 3 : 2; }
+// waves per SIMD of a payoff instantiation, stated EXACTLY (min = max): left a range, the compiler aims for more waves than
+// the accumulators leave registers for and spills (round 3: eleven instantiations carried 20-100 bytes of scratch per lane).
+// The thresholds are the widest groups whose build metadata shows no scratch (libsvmc.isa.json "metadata";
+// tests/test_host_logic.py holds every payoff instantiation to scratch_bytes == 0).
+constexpr int payoff_min_waves(int kt, bool has_inv) { return kt <= (has_inv ? 5 : 12) ? 3 : 2; }
 
 template <int KT, bool HAS_INV, bool NEED_Q>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV), payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld)
 {
     constexpr int NACC = HAS_INV ? 3 : 2;
     __shared__ double lds[4 * block_sum_padded(NACC * KT)];

@@ -339,6 +339,56 @@ def g_analytic():
     save("analytic", **out)
 
 
+# -- C5 on its OWN chain: the reference's analytic prices, the oracle's Monte Carlo leg, the reference's verdict per option ----
+def g_c5_verdict():
+    """Config C5: 5 parameter sets, chain = C4's first four expiries (ttm = k/8, F = 67000 e^{0.05 T},
+    DF = e^{-0.05 T}, 21 strikes at F linspace(0.6, 1.6), puts below the forward), criterion |analytic - MC| <= 4 stderr per
+    option (the reference's own: tests/test_logsv_characterization.py:407).  Analytic side: the UNMODIFIED reference's
+    logsv_chain_pricer.  Monte Carlo side: the C oracle on the counter-based stream, one rank's share of the 2^23 paths
+    (2^20 paths x 4 x 128 steps, seed 20240610) -- the run tests/test_gpu_fullsize.py::test_c5_monte_carlo_leg_rank_share
+    repeats on the GPU.  Stored per set: analytic prices, oracle MC prices / stderrs, z = (MC - analytic) / stderr and the
+    verdict map |z| <= 4 (NaN where no path reaches the strike: stderr 0)."""
+    out = {}
+    ttms = np.arange(1, 5) / 8.0
+    fw = 67000.0 * np.exp(0.05 * ttms)
+    dfs = np.exp(-0.05 * ttms)
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    n, spy, seed = 1 << 20, 1016, 20240610
+    oracle.set_threads(oracle.effective_cores())
+    out.update(ttms=ttms, forwards=fw, discfactors=dfs, strikes=np.stack(strikes), types=np.stack(types),
+               mc=np.array([n, spy, seed]))
+    sets = {
+        "btc": BTC,
+        "readme": LogSvParams(sigma0=0.8327, theta=1.0139, kappa1=4.8609, kappa2=4.794, beta=0.1988, volvol=2.3694),
+        "quick": LogSvParams(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0),
+        "test": TEST,
+        "fig3": LogSvParams(sigma0=1.5, theta=1.0, kappa1=4.0, kappa2=4.0, beta=0.0, volvol=1.5),
+    }
+    for tag, p in sets.items():
+        an = lp.logsv_chain_pricer(params=p, ttms=ttms, forwards=fw, discfactors=dfs, strikes_ttms=strikes,
+                                   optiontypes_ttms=types)
+        an = np.stack([np.asarray(a) for a in an])
+        x, s, q = np.zeros(n), p.sigma0 * np.ones(n), np.zeros(n)
+        mc, sd, t0, step0 = [], [], 0.0, 0
+        for i, ttm in enumerate(ttms):
+            nb, dt, _ = set_time_grid(ttm - t0, spy)
+            x, s, q = oracle.logsv_terminal_rng(x, s, q, nb, dt, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, seed,
+                                                step_offset=step0)
+            a, b = oracle.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]))
+            mc.append(a), sd.append(b)
+            t0, step0 = ttm, step0 + nb
+        mc, sd = np.stack(mc), np.stack(sd)
+        z = (mc - an) / np.where(sd > 0, sd, np.nan)
+        out[f"{tag}_params"] = params_vec(p)
+        out[f"{tag}_analytic"], out[f"{tag}_mc"], out[f"{tag}_stderr"], out[f"{tag}_z"] = an, mc, sd, z
+        out[f"{tag}_pass"] = np.where(np.isnan(z), -1, (np.abs(z) <= 4.0).astype(int)).astype(np.int8)
+        near = np.nanmin(np.abs(np.abs(z) - 4.0))
+        print(f"c5 verdict {tag}: pass {int(np.sum(out[f'{tag}_pass'] == 1))} fail {int(np.sum(out[f'{tag}_pass'] == 0))} "
+              f"unreached {int(np.sum(out[f'{tag}_pass'] == -1))}; closest |z| to the threshold: 4 +- {near:.3f}")
+    save("c5_verdict", **out)
+
+
 # -- a11: the reference's analytic chain with its ODE solver tightened (isolates solver tolerance from algebra) ---
 def g_analytic_tight():
     import stochvolmodels.pricers.logsv.affine_expansion as afe
@@ -696,6 +746,7 @@ if __name__ == "__main__":
     g_payoff()
     g_analytic()
     g_analytic_tight()
+    g_c5_verdict()
     g_analytic_qvar()
     g_heston_qvar()
     g_rough()

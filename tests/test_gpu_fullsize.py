@@ -217,19 +217,40 @@ C5_SETS = {   # LOGSV_BTC_PARAMS, README calibrated, quickstart, t
 
 
 @pytest.mark.parametrize("tag", list(C5_SETS))
-def test_c5_monte_carlo_leg_rank_share(sv, cpu, tag):
+def test_c5_monte_carlo_leg_rank_share(sv, cpu, golden, tag):
     """C5's Monte Carlo leg on ITS workload: each of the five parameter sets on C4's first four expiries, one rank's share
     of the 2^23 paths (2^20 paths x 4 x 128 steps, 4 x 21 strikes), GPU vs the oracle on the same stream -- the stiff
-    kappa2 = 12 set, sigma0 = 1.5 and volvol 2.37 meet the oracle at scale here.  Also printed (no tolerance: the
-    expansion's truncation error is a property of the reference's approximation, tabulated in
-    profiles/r02_c5_bias.json): the z-scores of the Monte Carlo prices against the GPU's analytic chain."""
+    kappa2 = 12 set, sigma0 = 1.5 and volvol 2.37 meet the oracle at scale here.
+
+    And C5's own criterion on C5's own chain, as VERDICT PARITY: per option, does |analytic - MC| <= 4 stderr hold?  The
+    reference's answer is committed (tests/golden/c5_verdict.npz, made by make_golden.py g_c5_verdict: the UNMODIFIED
+    reference's analytic chain against the oracle's Monte Carlo on this very stream); the GPU's answer -- its analytic chain
+    against its Monte Carlo -- must be the same map, option by option.  (Four sets pass on all 84 options; the kappa2 = 12
+    set fails 22 of them at the first expiries, where the standard error of 2^20 paths is far below the truncation error of
+    the reference's second-order expansion -- a property of the reference's approximation, tabulated in
+    profiles/r02_c5_bias.json, that a drop-in must reproduce, not hide.)"""
     p = sv.LOGSV_BTC_PARAMS if C5_SETS[tag] is None else sv.LogSvParams(**C5_SETS[tag])
     ttms, fw, dfs = _c4_chain(4)
     strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
     types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    g = golden("c5_verdict")
+    assert [int(v) for v in g["mc"]] == [1 << 20, 1016, 20240610]              # the golden's Monte Carlo leg is this run
+    np.testing.assert_array_equal(g["strikes"], np.stack(strikes))
+    np.testing.assert_array_equal(g["ttms"], ttms)
     pr, sd = _logsv_chain_gpu_vs_cpu(sv, cpu, f"C5 {tag}", p, 1 << 20, ttms, fw, dfs, strikes, types, 20240610)
     chain = sv.OptionChain(ttms=ttms, forwards=fw, strikes_ttms=strikes, optiontypes_ttms=types, ids=None, discfactors=dfs)
-    an = sv.LogSVPricer().price_chain(chain, p)
-    z = [((a - b) / np.where(c > 0, c, np.nan)) for a, b, c in zip(pr, an, sd)]
+    an = np.stack(sv.LogSVPricer().price_chain(chain, p))
+    pr, sd = np.stack(pr), np.stack(sd)
+    z = (pr - an) / np.where(sd > 0, sd, np.nan)
+    verdict = np.where(np.isnan(z), -1, (np.abs(z) <= 4.0).astype(int))
     print(f"C5 {tag}: (MC - analytic) / stderr per expiry, min .. max over the strikes some path reaches: "
-          + ", ".join(f"[{np.nanmin(row):+.1f} .. {np.nanmax(row):+.1f}]" for row in z))
+          + ", ".join(f"[{np.nanmin(row):+.1f} .. {np.nanmax(row):+.1f}]" for row in z)
+          + f"; verdict: pass {int(np.sum(verdict == 1))}, fail {int(np.sum(verdict == 0))}, unreached {int(np.sum(verdict == -1))}"
+          + f"; closest |z| to the threshold 4 +- {np.nanmin(np.abs(np.abs(z) - 4.0)):.3f}"
+          + f"; max |z_gpu - z_reference| {np.nanmax(np.abs(z - g[f'{tag}_z'])):.2e}")
+    # the GPU's Monte Carlo leg IS the golden's (same stream; _logsv_chain_gpu_vs_cpu held it to the oracle at 1e-12) and its
+    # analytic chain meets the reference's to the reference's own solver tolerance (rtol 1e-3 RK45: 2e-6 of the forward)
+    np.testing.assert_allclose(pr, g[f"{tag}_mc"], rtol=1e-11, atol=1e-11 * float(fw[0]))
+    np.testing.assert_allclose(an, g[f"{tag}_analytic"], rtol=0, atol=2e-6 * float(fw[0]))
+    np.testing.assert_array_equal(verdict, g[f"{tag}_pass"], err_msg=f"C5 {tag}: the GPU's accept / reject map differs from the "
+                                  "reference's")

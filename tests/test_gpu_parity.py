@@ -1072,7 +1072,7 @@ def test_mc_chain_implied_vols(sv):
     assert abs(mid[1][2] - 0.995757) <= 1.5 * (up[1][2] - down[1][2])
 
 
-def test_analytic_qvar(sv, golden):
+def test_analytic_qvar(sv, oracle, golden):
     """analytic calls on quadratic variance (40 000 psi-grid lanes per expiry) vs the reference, and vs the GPU Monte
     Carlo Q_VAR price at the reference's own scale and criterion (40 000 paths, |analytic - MC| <= 4 stderr).  The
     second-order affine expansion is an approximation: for the BTC set's SECOND expiry the Monte Carlo price sits below it
@@ -1104,6 +1104,23 @@ def test_analytic_qvar(sv, golden):
             lower[1] -= 0.065 * np.stack(an)[1]              # the expansion's measured truncation error (docstring)
         print(f"analytic vs MC Q_VAR [{tag}]: z = {np.round(diff / np.stack(sd), 2).tolist()}")
         assert np.all((diff <= band) & (diff >= lower)), (tag, diff / np.stack(sd))
+        # VERDICT PARITY with the bare criterion: per option, |analytic - MC| <= 4 stderr as the GPU answers it (its analytic
+        # chain against its Monte Carlo) and as the reference answers it (its analytic prices -- the golden -- against the
+        # oracle's Monte Carlo on the same stream) must be the same accept / reject map, whatever that map is
+        n, spy, x, s_, q, t0, step0, omc, osd = 40_000, 720, np.zeros(40_000), v[0] * np.ones(40_000), np.zeros(40_000), 0.0, 0, [], []
+        for i, ttm in enumerate(g["ttms"]):
+            nb, dt, _ = sv.set_time_grid(ttm - t0, spy)
+            x, s_, q = oracle.logsv_terminal_rng(x, s_, q, nb, dt, v[1], v[2], v[3], v[4], v[5], 8, step_offset=step0)
+            a, b = oracle.payoff(x, q, float(ttm), float(g["forwards"][i]), kk, np.array(["C"] * 8), float(g["discfactors"][i]), 2)
+            omc.append(a), osd.append(b)
+            t0, step0 = ttm, step0 + nb
+        np.testing.assert_allclose(np.stack(mc), np.stack(omc), rtol=1e-11, atol=1e-15)
+        gpu_map = np.abs(diff) <= band
+        ref_map = np.abs(np.stack(omc) - g[f"{tag}_prices"]) <= 4.0 * np.stack(osd)
+        z_ref = (np.stack(omc) - g[f"{tag}_prices"]) / np.stack(osd)
+        print(f"analytic vs MC Q_VAR [{tag}]: verdict map pass {int(gpu_map.sum())} / fail {int((~gpu_map).sum())}; closest |z| to 4: "
+              f"{np.min(np.abs(np.abs(z_ref) - 4.0)):.3f}")
+        np.testing.assert_array_equal(gpu_map, ref_map, err_msg=f"Q_VAR {tag}: the accept / reject map differs from the reference's")
     with pytest.raises(ValueError):
         chain_p = sv.OptionChain.slice_to_chain(0.25, 1.0, np.array([0.04]), np.array(["P"]))
         sv.LogSVPricer().price_chain(chain_p, sv.LogSvParams(), variable_type=sv.VariableType.Q_VAR)

@@ -398,7 +398,9 @@ def test_bench_workloads_and_roofline_arithmetic():
     import json
     meta = json.load(open(os.path.join(os.path.dirname(_lib.LIB_PATH), "libsvmc.isa.json")))["metadata"]
     stepping = [k for k in meta if "rng_kernel" in k]
-    assert len(stepping) >= 6 and all(meta[k]["scratch_bytes"] == 0 for k in stepping), {k: meta[k] for k in stepping}
+    assert len(stepping) >= 6 and len([k for k in meta if "payoff_group_kernel" in k]) >= 60
+    spilling = {k: v for k, v in meta.items() if v["scratch_bytes"] != 0}
+    assert not spilling, spilling                              # no kernel of the library touches scratch memory
 
 
 def test_batched_gradient_uses_scipys_difference_points():

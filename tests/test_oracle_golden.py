@@ -420,3 +420,29 @@ def test_heston_analytic_qvar(oracle, golden, tag):
     pr = oracle.heston_chain_pricer(v0, theta, kappa, volvol, rho, g["ttms"], g["forwards"], (kk,) * 3, (ty,) * 3,
                                     g["discfactors"], variable_type=2)
     np.testing.assert_allclose(np.stack(pr), g[f"{tag}_prices"], rtol=1e-10, atol=1e-13)
+
+
+def test_c5_verdict_map_is_reproducible_from_the_committed_numbers(oracle, golden):
+    """tests/golden/c5_verdict.npz (C5 on its own chain: the reference's analytic prices, the oracle's Monte Carlo leg, the
+    accept / reject map of |analytic - MC| <= 4 stderr): the map follows from the committed prices, and the Monte Carlo leg
+    of one set is re-run here on the oracle (2^20 paths x 4 x 128 steps on the host cores) and must reproduce the
+    committed numbers -- the GPU suite then requires the product's map to equal this one"""
+    from stochvolmodels_amd.utils.funcs import set_time_grid
+    g = golden("c5_verdict")
+    for tag in ("btc", "readme", "quick", "test", "fig3"):
+        z = (g[f"{tag}_mc"] - g[f"{tag}_analytic"]) / np.where(g[f"{tag}_stderr"] > 0, g[f"{tag}_stderr"], np.nan)
+        want = np.where(np.isnan(z), -1, (np.abs(z) <= 4.0).astype(int))
+        np.testing.assert_array_equal(g[f"{tag}_pass"], want)
+    assert int(np.sum(g["test_pass"] == 0)) == 22 and all(np.all(g[f"{t}_pass"] == 1) for t in ("btc", "readme", "quick", "fig3"))
+    n, spy, seed = (int(v) for v in g["mc"])
+    v = [float(a) for a in g["test_params"]]
+    oracle.set_threads(oracle.effective_cores())
+    x, s, q, t0, step0 = np.zeros(n), v[0] * np.ones(n), np.zeros(n), 0.0, 0
+    for i, ttm in enumerate(g["ttms"]):
+        nb, dt, _ = set_time_grid(ttm - t0, spy)
+        x, s, q = oracle.logsv_terminal_rng(x, s, q, nb, dt, v[1], v[2], v[3], v[4], v[5], seed, step_offset=step0)
+        pr, sd = oracle.payoff(x, q, float(ttm), float(g["forwards"][i]), g["strikes"][i], g["types"][i],
+                               float(g["discfactors"][i]))
+        np.testing.assert_allclose(pr, g["test_mc"][i], rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(sd, g["test_stderr"][i], rtol=1e-12, atol=1e-12)
+        t0, step0 = ttm, step0 + nb
