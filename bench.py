@@ -257,16 +257,24 @@ def load_isa(lib_path: str) -> dict:
 
 
 def load_pmc(lib_sha256: str) -> dict:
-    """the committed counter passes (rocprofv3 --pmc; tools/collect_profiles.sh -> profiles/r03_pmc.json): measured
-    SQ_INSTS_VALU per wave-step (cross-check of the assembly count) and HBM traffic.  They were collected on ONE build;
-    `matches_loaded_library` says whether it is the one running now"""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as fh:
-            pmc = json.load(fh)
-    except (OSError, ValueError):
-        return {}
-    pmc["matches_loaded_library"] = pmc.get("lib_sha256") == lib_sha256
-    return pmc
+    """the committed counter passes (rocprofv3 --pmc; tools/collect_profiles.sh -> profiles/rNN_pmc.json): measured
+    SQ_INSTS_VALU per wave-step (cross-check of the assembly count), the LDS / VALU busy counters and HBM traffic.  Each
+    file was collected on ONE build and names its sha256: the file of the loaded library is taken when there is one
+    (`matches_loaded_library`), else the newest round's -- then only its traffic figures are quoted (they do not depend on
+    the instruction stream), never its instruction counters"""
+    best = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        pmc["file"] = os.path.relpath(path, ROOT)
+        pmc["matches_loaded_library"] = pmc.get("lib_sha256") == lib_sha256
+        if pmc["matches_loaded_library"]:
+            return pmc
+        best = best or pmc
+    return best
 
 
 class ClockPoller:
@@ -378,7 +386,7 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
             "insts_source": f"{isa['source']} (assembly of the loaded library, sha256 {isa['lib_sha256'][:16]})",
             "rates_source": "profiles/r03_valu_rates.txt (tools/ubench/valu_rates.hip)",
             "stale": bool(isa["stale"]),
-            "insts_per_wave_step_counters": measured,      # SQ_INSTS_VALU of profiles/r03_pmc.json, when it is this build's
+            "insts_per_wave_step_counters": measured,      # SQ_INSTS_VALU of profiles/rNN_pmc.json, when it is this build's
             "peak_definition": "1024 SIMDs x 2400 MHz; a wave64 instruction holds its SIMD for the cycles of its class",
             # informational: the SMU's engine-clock reading sampled while the same call repeats for 2 s after the timed region;
             # the sensor averages and lags (boxes of the pool have reported 2100-2395 MHz for the same kernel time), so the
@@ -412,7 +420,7 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
                 "valu_busy_frac": 4.0 * act / N_SIMD / cycles,                  # SQ_ACTIVE_INST_VALU ticks in quad-cycles
                 "lds_busy_frac": lds / 256.0 / cycles,                          # SQ_LDS_IDX_ACTIVE: LDS-array cycles, per CU
                 "lds_bank_conflict_share": (conf / lds) if conf else None,
-                "source": "profiles/r03_pmc.json (rocprofv3 --pmc, same library)"}
+                "source": f"{pmc.get('file')} (rocprofv3 --pmc, same library)"}
     hbm_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
     hbm = {"kernel": kernel, "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes, "ms_per_launch": k_ms, "launches": launches,

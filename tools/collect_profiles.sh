@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: rocprofv3 kernel-trace stats and the PMC passes of the bench
 # command for the C2 and C4 configurations; results land in gpurun_out/ and are summarised locally by
-# tools/rocpd_summary.py (text, committed under profiles/) and tools/make_pmc_json.py (profiles/r03_pmc.json, which
+# tools/rocpd_summary.py (text, committed under profiles/) and tools/make_pmc_json.py (profiles/rNN_pmc.json, which
 # names the sha256 of the library the counters were collected on).
 # Counter passes run with --kernel-trace only (no sys/hip/hsa trace domains).
 set -u

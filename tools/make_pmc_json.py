@@ -60,7 +60,7 @@ def main():
             if "SQ_INSTS_VALU" in c:
                 e["sq_insts_valu_per_dispatch"] = c["SQ_INSTS_VALU"][0]
                 e["valu_insts_per_wave_step"] = c["SQ_INSTS_VALU"][0] / ((paths / 64.0) * steps)
-                e["source"] = "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r03_pmc.json)"
+                e["source"] = "rocprofv3 --pmc SQ_INSTS_VALU"
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 e["fetch_size_kb_raw"], e["write_size_kb_raw"] = c["FETCH_SIZE"][0], c["WRITE_SIZE"][0]
                 e["hbm_bytes"] = 2.0 * c["FETCH_SIZE"][0] * 1024.0 + c["WRITE_SIZE"][0] * 1024.0
