@@ -178,8 +178,9 @@ SVMC_API int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int
 /* ---- Black-76 implied vols of one slice, HOST arrays in and out (no device work): the price -> vol step between a
  * pricer and the calibration objective, OptionChain.compute_model_ivols_from_chain_data data/option_chain.py:327-346
  * (which delegates to the third-party vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices; parity with it
- * is unpinned).  optiontypes: SVMC_CALL / SVMC_PUT only (else SVMC_ERR_UNSUPPORTED_VARIABLE).  A quote whose price is
- * not strictly inside (price(vol_lo), price(vol_hi)) -- or is NaN -- gets NaN. */
+ * is unpinned).  optiontypes: SVMC_CALL / SVMC_PUT, and SVMC_INV_CALL / SVMC_INV_PUT as the vanilla inversion of price x
+ * forward (the Black-76 value of (S - K)^+ / S is the vanilla value over the forward); another code gives
+ * SVMC_ERR_UNKNOWN_PAYOFF.  A quote whose price is not strictly inside (price(vol_lo), price(vol_hi)) -- or is NaN -- gets NaN. */
 SVMC_API int svmc_black_implied_vols(const double *prices, const double *strikes, const int8_t *optiontypes,
                                      size_t n_strikes, double forward, double ttm, double discfactor, double vol_lo,
                                      double vol_hi, double *ivols);
@@ -336,8 +337,8 @@ SVMC_API int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *
                                           const int *nb_steps_host, const double *dts_host, size_t ldw,
                                           double *prices_host, double *stderrs_host);
 /* the same call with the price -> implied-vol step of a calibration objective (data/option_chain.py:327-346) done where
- * the prices are: ivols_host [sum K_i] receives the Black-76 implied vols of the 'C' / 'P' quotes of a LOG_RETURN chain
- * on the bracket [1e-6, 10] (NaN outside it, for inverse quotes and for Q_VAR chains) -- on the graph route one more
+ * the prices are: ivols_host [sum K_i] receives the Black-76 implied vols of the quotes of a LOG_RETURN chain ('IC' / 'IP':
+ * of price x forward) on the bracket [1e-6, 10] (NaN outside it and for Q_VAR chains) -- on the graph route one more
  * kernel node and one more copy-back in the captured graph (svmc_black.h: the solver of svmc_black_implied_vols), on
  * the others the host routine after the prices.  ivols_host may be NULL (= svmc_logsv_chain_price_fixed). */
 SVMC_API int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_host, const double *forwards_host,

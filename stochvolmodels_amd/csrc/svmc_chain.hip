@@ -355,11 +355,13 @@ static void implied_vols_on_host(const ChainView &c, int variable_type, const do
 {
     for (int i = 0; i < c.m; ++i)
         for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k) {
-            // quotes on the log-return only: options on the realised variance have no Black vol on the forward
-            const bool vanilla = variable_type == SVMC_LOG_RETURN && (c.types[k] == SVMC_CALL || c.types[k] == SVMC_PUT);
-            ivols[k] = vanilla ? black_implied_vol(prices[k], c.strikes[k], c.types[k] == SVMC_CALL, c.forwards[i], c.ttms[i],
-                                                   c.discfactors[i], IV_VOL_LO, IV_VOL_HI)
-                               : std::numeric_limits<double>::quiet_NaN();
+            // quotes on the log-return only: options on the realised variance have no Black vol on the forward; inverse
+            // options (IC / IP) as in chain_implied_vols_kernel: the vanilla inversion of price x forward
+            const bool call = c.types[k] == SVMC_CALL || c.types[k] == SVMC_INV_CALL;
+            const double px = c.types[k] >= SVMC_INV_CALL ? prices[k] * c.forwards[i] : prices[k];
+            ivols[k] = variable_type == SVMC_LOG_RETURN
+                           ? black_implied_vol(px, c.strikes[k], call, c.forwards[i], c.ttms[i], c.discfactors[i], IV_VOL_LO, IV_VOL_HI)
+                           : std::numeric_limits<double>::quiet_NaN();
         }
 }
 

@@ -1652,9 +1652,9 @@ __global__ __launch_bounds__(64) void chain_implied_vols_kernel(const double *__
     double price, se;
     payoff_finalize_one(sums[3 * k], sums[3 * k + 1], sums[3 * k + 2], qd[2], qd[5], n_path_total, &price, &se);
     const int code = static_cast<int>(qd[1]);
-    const bool vanilla = code == SVMC_CALL || code == SVMC_PUT;
-    ivols[k] = vanilla ? black_implied_vol(price, qd[0], code == SVMC_CALL, qd[3], qd[4], qd[5], vol_lo, vol_hi)
-                       : bits_to_double(0u, 0x7ff80000u);                  // inverse quotes: not provided (NaN)
+    // inverse quotes (IC / IP): the Black-76 value of (S - K)^+ / S is the vanilla value over the forward
+    const bool call = code == SVMC_CALL || code == SVMC_INV_CALL;
+    ivols[k] = black_implied_vol(code >= SVMC_INV_CALL ? price * qd[3] : price, qd[0], call, qd[3], qd[4], qd[5], vol_lo, vol_hi);
 }
 
 int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,

@@ -194,11 +194,15 @@ int svmc_black_implied_vols(const double *prices, const double *strikes, const i
     SVMC_REQUIRE(forward > 0.0 && ttm > 0.0 && discfactor > 0.0, "svmc_black_implied_vols: forward, ttm, discfactor > 0");
     SVMC_REQUIRE(0.0 < vol_lo && vol_lo < vol_hi, "svmc_black_implied_vols: need 0 < vol_lo < vol_hi");
     for (size_t k = 0; k < n_strikes; ++k)
-        if (optiontypes[k] != SVMC_CALL && optiontypes[k] != SVMC_PUT)
-            return svmc::fail(SVMC_ERR_UNSUPPORTED_VARIABLE,
-                              "svmc_black_implied_vols: implied vols are provided for 'C' and 'P' quotes");
-    for (size_t k = 0; k < n_strikes; ++k)
-        ivols[k] = svmc::black_implied_vol(prices[k], strikes[k], optiontypes[k] == SVMC_CALL, forward, ttm, discfactor, vol_lo,
-                                           vol_hi);
+        if (optiontypes[k] < SVMC_CALL || optiontypes[k] > SVMC_INV_PUT)
+            return svmc::fail(SVMC_ERR_UNKNOWN_PAYOFF, "unknown option payoff code");
+    for (size_t k = 0; k < n_strikes; ++k) {
+        // an inverse option pays (S - K)^+ / S: in units of the underlying its Black-76 value is the vanilla value over the
+        // forward -- DF (N(d1) - K/F N(d2)) -- so its implied vol is that of price x forward
+        const bool inverse = optiontypes[k] >= SVMC_INV_CALL;
+        const bool call = optiontypes[k] == SVMC_CALL || optiontypes[k] == SVMC_INV_CALL;
+        ivols[k] = svmc::black_implied_vol(inverse ? prices[k] * forward : prices[k], strikes[k], call, forward, ttm, discfactor,
+                                           vol_lo, vol_hi);
+    }
     return SVMC_OK;
 }

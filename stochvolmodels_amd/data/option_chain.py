@@ -194,8 +194,9 @@ class OptionChain:
         """model prices -> Black implied vols, slice by slice (reference data/option_chain.py:327-346).
 
         The reference delegates to the third-party `vanilla_option_pricers.infer_bsm_ivols_from_model_chain_prices`,
-        which is not available here: this is a textbook Black-76 inversion for 'C' and 'P' done by libsvmc's host
-        routine svmc_black_implied_vols (safeguarded Newton; the MC calibration loop gets the same inversion from the
+        which is not available here: this is a textbook Black-76 inversion -- 'C' / 'P', and 'IC' / 'IP' as the vanilla
+        inversion of price x forward (an inverse option's Black value is the vanilla value over the forward) -- done by
+        libsvmc's host routine svmc_black_implied_vols (safeguarded Newton; the MC calibration loop gets the same inversion from the
         last kernel of its replayed graph instead, logsv_mc_chain_pricer_fixed_randoms(return_ivols=True)).  Parity with the third-party routine is UNPINNED; prices outside the band
         attainable for vols in [1e-6, 10] give NaN."""
         forwards = self.forwards if forwards is None else forwards
@@ -210,12 +211,10 @@ def black_ivols_native(prices: np.ndarray, ttm: float, forward: float, strikes: 
     the independent check)"""
     import ctypes as C
     from .. import _lib
-    types = np.asarray(optiontypes).astype(str)
-    if not np.all(np.isin(types, ("C", "P"))):
-        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
+    from ..engine import option_type_codes
+    codes = option_type_codes(np.asarray(optiontypes).astype(str))       # C, P, IC, IP -> 0..3; ValueError otherwise
     prices = np.ascontiguousarray(prices, dtype=np.float64)
     strikes = np.ascontiguousarray(strikes, dtype=np.float64)
-    codes = np.ascontiguousarray(types != "C", dtype=np.int8)            # SVMC_CALL = 0, SVMC_PUT = 1
     out = np.empty(strikes.shape, dtype=np.float64)
     dp = C.POINTER(C.c_double)
     _lib.check(_lib.load().svmc_black_implied_vols(prices.ctypes.data_as(dp), strikes.ctypes.data_as(dp),
@@ -246,9 +245,10 @@ def infer_black_ivols(prices: np.ndarray, ttm: float, forward: float, strikes: n
                       discfactor: float = 1.0, lo: float = 1e-6, hi: float = 10.0) -> np.ndarray:
     """Black-76 implied vols by bisection on [lo, hi] (monotone in vol; 60 halvings reach 1e-17 of the bracket)"""
     types = np.asarray(optiontypes).astype(str)
-    if not np.all(np.isin(types, ("C", "P"))):
-        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
-    is_call = types == "C"
+    if not np.all(np.isin(types, ("C", "P", "IC", "IP"))):
+        raise ValueError("unknown option payoff code")
+    is_call = (types == "C") | (types == "IC")
+    prices = np.where((types == "IC") | (types == "IP"), np.asarray(prices, dtype=float) * forward, prices)   # inverse: x forward
     a = np.full(strikes.shape, lo)
     b = np.full(strikes.shape, hi)
     ok = (prices > black_price(forward, strikes, ttm, a, is_call, discfactor)) & \

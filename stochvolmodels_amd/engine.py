@@ -635,12 +635,14 @@ def payoff_finalize_chain(sums: np.ndarray, shifts: np.ndarray, discfactors: np.
     return prices, stderrs
 
 
-# Engines are cached per (device id, n_path, path_offset) so that buffers stay resident across calls.  The cache is
-# process-global and guarded by a lock; the engines themselves are NOT thread-safe (one stream, one set of state
-# buffers): concurrent callers must use distinct (n_path, path_offset) keys or their own HipEngine objects.
-# Eviction (more than MAX_CACHED_ENGINES resident) only ever closes an engine nobody else references -- a caller that
-# kept the object returned by get_engine() keeps its HBM -- and an engine that was closed raises SvmcError (null
-# pointer) on its next launch instead of touching freed memory.
+# Engines are cached per (device id, n_path, path_offset, THREAD) so that buffers stay resident across calls and two threads
+# that price chains of the same size concurrently never share state buffers, reduction scratch or the pinned download
+# buffer: each gets its own engine (the launches of all of them are serialised by the HIP runtime on the stream they
+# were given -- the default stream unless the caller built its own HipEngine with another).  The cache is process-global and
+# guarded by a lock.  Eviction (more than MAX_CACHED_ENGINES resident) only ever closes an engine nobody else references
+# -- a caller that kept the object returned by get_engine() keeps its HBM; the engines of threads that ended are the
+# first to go -- and an engine that was closed raises SvmcError (null pointer) on its next launch instead of touching
+# freed memory.
 MAX_CACHED_ENGINES = 4
 _ENGINES = {}
 _ENGINES_LOCK = threading.Lock()
@@ -654,14 +656,15 @@ def _current_device() -> int:
 
 def get_engine(n_path: int, path_offset: int = 0, device: Optional[int] = None) -> HipEngine:
     dev = _current_device() if device is None else int(device)     # None = the CURRENT HIP device, resolved now
-    key = (dev, int(n_path), int(path_offset))
+    key = (dev, int(n_path), int(path_offset), threading.get_ident())
     with _ENGINES_LOCK:
         eng = _ENGINES.get(key)
         if eng is not None and not eng.closed:
             _ENGINES[key] = _ENGINES.pop(key)          # most recently used last
             return eng
-        if len(_ENGINES) >= MAX_CACHED_ENGINES:        # bound resident HBM: drop the least recently used FREE engine
-            for k in list(_ENGINES):
+        if len(_ENGINES) >= MAX_CACHED_ENGINES:        # bound resident HBM: drop FREE engines, dead threads' first, then LRU
+            alive = {t.ident for t in threading.enumerate()}
+            for k in sorted(_ENGINES, key=lambda k_: k_[3] in alive):      # stable: keeps the LRU order within each class
                 # references: the dict, the loop variable below, getrefcount's argument
                 cand = _ENGINES[k]
                 if sys.getrefcount(cand) <= 3:

@@ -550,8 +550,6 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
         # single GPU, randoms resident: the whole chain in one call of the fused C++ driver
         strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
         codes = [option_type_codes(t) for t in optiontypes_ttms]
-        if return_ivols and any(np.any(c > 1) for c in codes):           # as the host inversion (data/option_chain.py)
-            raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
         out = resident.price_logsv_chain(ttms, forwards, discfactors, [k.ravel() for k in strikes],
                                          [c.ravel() for c in codes], v0, theta, kappa1, kappa2, beta, volvol,
                                          vol_backbone_etas, is_spot_measure, variable_type_code(variable_type),
@@ -600,8 +598,6 @@ def logsv_mc_chain_pricer_fixed_randoms_batch(params_list: Sequence[LogSvParams]
     if not isinstance(W0s, DeviceRandoms):
         raise TypeError("the batched pricer works on resident randoms (upload_fixed_randoms / draw_fixed_randoms_on_device)")
     codes = [option_type_codes(t) for t in optiontypes_ttms]
-    if return_ivols and any(np.any(c > 1) for c in codes):
-        raise NotImplementedError("implied vols are provided for 'C' and 'P' quotes")
     if comm.world == 1 and FUSED_FIXED_RANDOMS_DRIVER and len(W0s) == len(ttms):
         strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
         rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol] + list(p.get_vol_backbone_etas(ttms=ttms))

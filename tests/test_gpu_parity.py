@@ -1017,7 +1017,7 @@ def test_implied_vols_from_the_graph(sv, oracle):
     """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
     (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
     libm against the host's), identical with the graph off (host route), the same NaN pattern for unattainable prices,
-    prices untouched by asking for them; inverse quotes raise as on the host"""
+    prices untouched by asking for them; inverse quotes are inverted as price x forward, as on the host"""
     from stochvolmodels_amd.data.option_chain import black_ivols_native
     ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
     k = np.linspace(0.55, 1.6, 13)
@@ -1048,9 +1048,15 @@ def test_implied_vols_from_the_graph(sv, oracle):
     np.testing.assert_allclose(np.concatenate(on[2]), np.concatenate(off[2]), rtol=1e-12)
     _, _, iv_host = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=W[0], W1s=W[1], dts=W[2], return_ivols=True, **common, **p)
     np.testing.assert_allclose(np.concatenate(iv_host), np.concatenate(on[2]), rtol=1e-12)
-    with pytest.raises(NotImplementedError):
-        sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True,
-                                               **dict(common, optiontypes_ttms=(np.where(k >= 1.0, "IC", "P"),) * 4), **p)
+    # inverse quotes: the vanilla inversion of price x forward, from the graph's last kernel and from the host routine alike
+    inv_types = (np.where(k >= 1.0, "IC", "IP"),) * 4
+    pr_i, _, iv_i = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, return_ivols=True,
+                                                           **dict(common, optiontypes_ttms=inv_types), **p)
+    chain_i = sv.OptionChain(ttms=ttms, forwards=common["forwards"], strikes_ttms=(k,) * 4, optiontypes_ttms=inv_types, ids=None,
+                             discfactors=common["discfactors"])
+    host_i = chain_i.compute_model_ivols_from_chain_data(pr_i)
+    np.testing.assert_allclose(np.concatenate(iv_i), np.concatenate(host_i), rtol=1e-10, equal_nan=True)
+    assert np.isfinite(np.concatenate(iv_i)).sum() >= 30
     res.free()
 
 
@@ -1578,6 +1584,40 @@ def test_logsv_slice_w_equals_terminal_w_plus_reductions(sv):
         assert np.array_equal(x, y)
     assert np.array_equal(a.download(a.snapshot_ptr(0), 2 * n), b.download(b.snapshot_ptr(0), 2 * n))
     np.testing.assert_allclose(a.download(sa, 2), b.download(sb, 2), rtol=1e-14)      # different reduction trees
+
+
+def test_threads_price_concurrently(sv):
+    """the Python host from several threads at once: every thread gets its own engine from the cache (state buffers,
+    reduction scratch, pinned download buffer), so four threads pricing chains of the SAME size with different seeds, 12
+    calls each, return exactly what the same calls return one after the other"""
+    import threading
+    p = sv.LOGSV_BTC_PARAMS
+    ttms = np.array([0.1, 0.25, 0.5])
+    kk = np.linspace(0.7, 1.3, 7)
+    kw = dict(ttms=ttms, forwards=np.array([1.0, 1.01, 1.02]), discfactors=np.array([0.99, 0.98, 0.97]), strikes_ttms=(kk,) * 3,
+              optiontypes_ttms=(np.where(kk >= 1.0, "C", "IP"),) * 3, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+              kappa2=p.kappa2, beta=p.beta, volvol=p.volvol, vol_backbone_etas=np.ones(3), nb_path=30_011,
+              nb_steps_per_year=200)
+    serial = {(t, i): sv.logsv_mc_chain_pricer(seed=1000 * t + i, **kw) for t in range(4) for i in range(12)}
+    got, errs = {}, []
+
+    def work(t):
+        try:
+            for i in range(12):
+                got[(t, i)] = sv.logsv_mc_chain_pricer(seed=1000 * t + i, **kw)
+        except Exception as exc:                             # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errs, errs
+    assert len(got) == 48
+    for key, (pr, sd) in serial.items():
+        for a, b in zip(pr + sd, got[key][0] + got[key][1]):
+            np.testing.assert_array_equal(a, b, err_msg=str(key))
 
 
 def test_two_engines_on_their_own_streams(sv):

@@ -195,8 +195,13 @@ def test_black_implied_vol_round_trip():
     chain = sv.OptionChain.slice_to_chain(0.5, 1.02, k, types, discfactor=0.97)
     np.testing.assert_allclose(chain.compute_model_ivols_from_chain_data([pr])[0], vols, rtol=1e-12)
     assert np.isnan(infer_black_ivols(np.array([2.0]), 0.5, 1.0, np.array([1.0]), np.array(["C"]))[0])
-    with pytest.raises(NotImplementedError):
-        infer_black_ivols(pr[:1], 0.5, 1.0, k[:1], np.array(["IC"]))
+    # inverse quotes: the Black-76 value of (S - K)^+ / S is the vanilla value over the forward -> same vols from price / F
+    inv = np.where(types == "C", "IC", "IP")
+    np.testing.assert_allclose(infer_black_ivols(pr / 1.02, 0.5, 1.02, k, inv, 0.97), vols, rtol=1e-12)
+    chain_inv = sv.OptionChain.slice_to_chain(0.5, 1.02, k, inv, discfactor=0.97)
+    np.testing.assert_allclose(chain_inv.compute_model_ivols_from_chain_data([pr / 1.02])[0], vols, rtol=1e-12)
+    with pytest.raises(ValueError):
+        infer_black_ivols(pr[:1], 0.5, 1.0, k[:1], np.array(["X"]))
 
 
 def test_validate_optimization_result():
@@ -281,11 +286,15 @@ def test_native_black_implied_vols_vs_bisection():
     # far tail: prices down to 1e-300 are still inverted on the log scale
     a = black_ivols_native(np.array([1.3377398071023282e-297 * 50.0]), 1.0, 50.0, np.array([50.0 * np.exp(1.1555)]), ["C"])
     assert np.isfinite(a[0]) and 0.02 < a[0] < 0.05
-    # contract: NaN outside the attainable band / for NaN prices; error for inverse payoffs
+    # contract: NaN outside the attainable band / for NaN prices
     out = black_ivols_native(np.array([0.0, np.nan, 2.0, 0.05]), 1.0, 1.0, np.array([1.0, 1.0, 1.0, 1.0]), ["C"] * 4)
     assert np.isnan(out[:3]).all() and abs(out[3] - 0.12538) < 1e-4
-    with pytest.raises(NotImplementedError):
-        black_ivols_native(np.array([0.1]), 1.0, 1.0, np.array([1.0]), ["IC"])
+    # inverse quotes: the vanilla inversion of price x forward; unknown codes raise like the payoffs do
+    F, kk, vv = 40.0, np.array([30.0, 40.0, 55.0]), np.array([0.6, 0.5, 0.7])
+    pr = black_price(F, kk, 0.75, vv, np.array([False, True, True]), 0.95) / F
+    np.testing.assert_allclose(black_ivols_native(pr, 0.75, F, kk, ["IP", "IC", "IC"], 0.95), vv, rtol=1e-9)
+    with pytest.raises(ValueError):
+        black_ivols_native(np.array([0.1]), 1.0, 1.0, np.array([1.0]), ["XX"])
 
 
 def test_build_keeps_basic_blocks_aligned():
