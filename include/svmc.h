@@ -208,6 +208,19 @@ SVMC_API int svmc_rough_logsv_slice(double *log_s, double *vol, double *qvar, si
                                     uint32_t call_id, uint64_t path_offset, uint32_t step_offset, int from_origin,
                                     double forward, double *x_snapshot, double *qvar_snapshot, double *spot_sums,
                                     void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+/* ALL expiries of rough_logsv_mc_chain_pricer_fixed_randoms (pricers/logsv_pricer.py:1206-1230) in ONE stepping launch: the
+ * reference re-simulates every expiry from time 0 with its own step, so the expiries are independent simulations and run
+ * side by side (grid.y = expiry).  Expiry i takes nb_steps_host[i] steps of hs_host[i] on rows 0 .. nb_steps_host[i] - 1 of
+ * Z0 / Z1 (both NULL: drawn on device, stream 3, steps 0 ..); x_snapshots [n_expiries][n_path], qvar_snapshots the same or
+ * NULL, spot_sums [2 n_expiries]; the state arrays receive the last expiry's terminal state.  Same bits per expiry as
+ * svmc_rough_logsv_slice(from_origin = 1).  n_expiries <= 16. */
+SVMC_API int svmc_rough_logsv_chain(double *log_s, double *vol, double *qvar, size_t n_path, int n_expiries,
+                                    const int *nb_steps_host, const double *hs_host, const double *forwards_host,
+                                    int n_factors, const double *nodes_host, const double *weights_host,
+                                    const double *v0_host, double theta, double kappa1, double kappa2, double rho,
+                                    double volvol, const double *Z0, const double *Z1, size_t ldw, uint64_t seed,
+                                    uint32_t call_id, uint64_t path_offset, double *x_snapshots, double *qvar_snapshots,
+                                    double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream);
 
 /* ---- Heston generator: simulate_heston_x_vol_terminal, pricers/heston_pricer.py:334-381 ----------
  * `var` is the variance (the reference returns variance, not vol).  scheme = SVMC_HESTON_EULER_FLOOR

@@ -72,6 +72,8 @@ def _declare(L: C.CDLL) -> None:
                                 sz, vp], i32),
         "svmc_rough_logsv_slice": ([vp, vp, vp, sz, i32, f64, i32, pf64, pf64, pf64, f64, f64, f64, f64, f64, vp, vp, sz,
                                     u64, u32, u64, u32, i32, f64, vp, vp, vp, vp, sz, vp], i32),
+        "svmc_rough_logsv_chain": ([vp, vp, vp, sz, i32, C.POINTER(i32), pf64, pf64, i32, pf64, pf64, pf64, f64, f64, f64, f64, f64,
+                                    vp, vp, sz, u64, u32, u64, vp, vp, vp, vp, sz, vp], i32),
         "svmc_rough_logsv_terminal": ([vp, vp, vp, sz, i32, f64, i32, pf64, pf64, pf64, f64, f64, f64, f64, f64, vp, vp, sz,
                                        u64, u32, u64, u32, i32, vp], i32),
         "svmc_heston_terminal_rng": ([vp, vp, vp, sz, i32, f64, f64, f64, f64, f64, i32, u64, u32, u64, u32, vp], i32),

@@ -346,6 +346,28 @@ class HipEngine:
             *args, float(forward), self.snapshot_ptr(snap_row), None if qvar_row is None else self.snapshot_ptr(qvar_row),
             spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
 
+    def rough_logsv_chain(self, nb_steps: Sequence[int], hs: Sequence[float], forwards: Sequence[float], nodes, weights, v0,
+                          theta, kappa1, kappa2, rho, volvol, need_qvar: bool, spot_ptr: int, z0_ptr=None, z1_ptr=None,
+                          ldw=None, seed=0, call_id=0) -> None:
+        """every expiry of a rough-LogSV chain in one stepping launch (svmc_rough_logsv_chain): each expiry simulated from
+        time 0 on its own step, side by side; snapshot rows 0..m-1 get the terminal x, rows m..2m-1 the quadratic
+        variance (need_qvar), spot_ptr the 2m spot sums"""
+        nodes, weights, v0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (nodes, weights, v0))
+        if not (nodes.ndim == 1 and nodes.shape == weights.shape == v0.shape):
+            raise ValueError("nodes, weights and v0 must be 1-d arrays of one length")
+        if self._factors is None:
+            self._factors = DeviceBuffer(3 * self.n_path)
+        m = len(nb_steps)
+        dp = C.POINTER(C.c_double)
+        nbs = (C.c_int * m)(*[int(v) for v in nb_steps])
+        h, f = (np.ascontiguousarray(a, dtype=np.float64) for a in (hs, forwards))
+        self._timed("rough_logsv_expiries_kernel", lambda: _lib.check(self.lib.svmc_rough_logsv_chain(
+            self.x.ptr, self._factors.ptr, self.qvar.ptr, self.n_path, m, nbs, h.ctypes.data_as(dp), f.ctypes.data_as(dp),
+            int(nodes.size), nodes.ctypes.data_as(dp), weights.ctypes.data_as(dp), v0.ctypes.data_as(dp), float(theta),
+            float(kappa1), float(kappa2), float(rho), float(volvol), z0_ptr, z1_ptr, self.n_path if ldw is None else int(ldw),
+            int(seed), int(call_id), self.path_offset, self.snapshot_ptr(0), self.snapshot_ptr(m) if need_qvar else None,
+            spot_ptr, self.ws.ptr, self.ws_bytes, self.stream)))
+
     def get_factors(self, n_factors: int) -> np.ndarray:
         return self.download(self._factors.ptr, n_factors * self.n_path).reshape(n_factors, self.n_path)
 

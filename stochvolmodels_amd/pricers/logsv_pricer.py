@@ -115,6 +115,8 @@ def _calibration_constraints(parse, constraints_type: ConstraintsType):
 WHOLE_CHAIN_STEPPING = True
 # single-GPU chains on resident randoms go through svmc_logsv_chain_price_fixed (one C++ call per chain) when True
 FUSED_FIXED_RANDOMS_DRIVER = True
+# rough LogSV chains: every expiry in one stepping launch (svmc_rough_logsv_chain); False = one launch per expiry (A/B, tests)
+ROUGH_CHAIN_ONE_LAUNCH = True
 
 LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
 
@@ -710,8 +712,15 @@ def rough_logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.nda
             print(f"Number of paths with negative vol: {np.sum(vw < 0.0)}, nan vol: {np.count_nonzero(np.isnan(vw))}")
             print(f"Mean spot Strand: {np.mean(np.exp(x))}, nan spots: {np.count_nonzero(np.isnan(x))}")
 
+    def advance_chain(need_q: bool, spot_ptr: int) -> None:
+        # the expiries are independent simulations from time 0 (:1206-1216): all of them in one launch, side by side
+        eng.rough_logsv_chain(nbs, [float(g[1] - g[0]) for g in timegrids], forwards, nodes, weights, v0, theta, kappa1, kappa2,
+                              rho, volvol, need_q, spot_ptr, z0_ptr=z0, z1_ptr=z1)
+
+    one_launch = ROUGH_CHAIN_ONE_LAUNCH and not debug and len(nbs) <= 16 and hasattr(eng, "rough_logsv_chain")
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
-                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr))
+                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr),
+                                 advance_chain=advance_chain if one_launch else None)
 
 
 def rough_logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
@@ -737,5 +746,11 @@ def rough_logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfact
         eng.rough_logsv(nb, h, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, seed=rng_seed, call_id=call_id,
                         slice_out=(forward, snap_row, qvar_row, spot_ptr))
 
+    def advance_chain(need_q: bool, spot_ptr: int) -> None:
+        eng.rough_logsv_chain([g[0] for g in grids], [g[1] for g in grids], forwards, nodes, weights, v0, theta, kappa1, kappa2,
+                              rho, volvol, need_q, spot_ptr, seed=rng_seed, call_id=call_id)
+
+    one_launch = ROUGH_CHAIN_ONE_LAUNCH and len(grids) <= 16 and hasattr(eng, "rough_logsv_chain")
     return price_chain_on_engine(eng, comm, nb_path, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
-                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr))
+                                 variable_type, advance, finalize=_rough_finalize(normalize_stderr),
+                                 advance_chain=advance_chain if one_launch else None)

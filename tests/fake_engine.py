@@ -139,6 +139,13 @@ class FakeEngine:
         if slice_out is not None:
             self.finish_slice(*slice_out)
 
+    def rough_logsv_chain(self, nb_steps, hs, forwards, nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, need_qvar,
+                          spot_ptr, z0_ptr=None, z1_ptr=None, ldw=None, seed=0, call_id=0):
+        m = len(nb_steps)
+        for i in range(m):                                   # every expiry from time 0 on its own step
+            self.rough_logsv(nb_steps[i], float(hs[i]), nodes, weights, v0, theta, kappa1, kappa2, rho, volvol, z0_ptr, z1_ptr,
+                             ldw, seed, call_id, 0, True, (float(forwards[i]), i, (m + i) if need_qvar else None, spot_ptr + 16 * i))
+
     def logsv_slice_w(self, nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0, w1, forward,
                       snap_row, qvar_row, spot_ptr, ldw=None):
         self.logsv_w(nb_steps, dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure, w0, w1, ldw)

@@ -1526,6 +1526,37 @@ def test_calibration_errors(sv, golden):
         sv.LogSVPricer().calibrate_model_params_to_chain(option_chain=bare, params0=p0, disp=False)
 
 
+def test_rough_chain_one_launch_equals_expiry_by_expiry(sv):
+    """svmc_rough_logsv_chain: all expiries of a rough chain side by side in one launch must return the bits of the
+    expiry-by-expiry launches -- supplied randoms and device draw, 1-3 factors, LOG_RETURN and Q_VAR, odd path count"""
+    from stochvolmodels_amd.pricers import logsv_pricer as lp
+    ttms = np.array([0.05, 0.1, 0.25, 0.4])
+    kk = np.linspace(0.8, 1.25, 6)
+    n, spy = 5003, 120
+    chain = dict(ttms=ttms, forwards=np.array([1.0, 1.005, 1.01, 1.02]), discfactors=np.array([0.999, 0.995, 0.99, 0.98]),
+                 strikes_ttms=(kk,) * 4, optiontypes_ttms=(np.where(kk >= 1.0, "C", "P"),) * 4)
+    Z0, Z1, grids = sv.get_randoms_for_rough_vol_chain_valuation(ttms, nb_path=n, nb_steps_per_year=spy, seed=4)
+    for H in (0.1, 0.45, 0.5):
+        p = sv.LogSvParams(sigma0=0.8, theta=1.0, kappa1=3.0, kappa2=3.0, beta=0.15, volvol=1.8, H=H)
+        p.approximate_kernel(T=float(ttms[-1]))
+        pars = dict(sigma0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, orthog_vol=p.volvol,
+                    weights=p.weights, nodes=p.nodes)
+        for vt, strikes in ((sv.VariableType.LOG_RETURN, chain["strikes_ttms"]), (sv.VariableType.Q_VAR, (0.6 * kk,) * 4)):
+            kw = dict(chain, strikes_ttms=strikes, variable_type=vt, **pars)
+            out = {}
+            for flag in (True, False):
+                lp.ROUGH_CHAIN_ONE_LAUNCH = flag
+                try:
+                    out[flag] = (sv.rough_logsv_mc_chain_pricer_fixed_randoms(Z0=Z0, Z1=Z1, timegrids=grids, **kw),
+                                 sv.rough_logsv_mc_chain_pricer(nb_path=n, nb_steps_per_year=spy, seed=11, **kw))
+                finally:
+                    lp.ROUGH_CHAIN_ONE_LAUNCH = True
+            for a, b in zip(out[True], out[False]):
+                for x, y in zip(a[0] + a[1], b[0] + b[1]):
+                    np.testing.assert_array_equal(x, y, err_msg=f"H = {H}, {vt}")
+            assert np.all(np.isfinite(np.concatenate(out[True][0][0])))
+
+
 def test_rough_cabi_continuation_and_errors(sv, oracle, golden):
     """svmc_rough_logsv_terminal called directly: two half-range calls continuing from the resident state equal one
     full-range call bit for bit (device RNG: the step offset carries the counter), and argument errors map to

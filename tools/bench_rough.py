@@ -40,5 +40,45 @@ def main():
                                   mean_qvar=float(y.mean()))))
 
 
+def chain():
+    """a whole rough chain through the pricer (the rough calibration engine's objective evaluation): 4 expiries, resident
+    randoms, every expiry re-simulated from time 0 -- all expiries in one launch (svmc_rough_logsv_chain) against one
+    launch per expiry"""
+    import time
+
+    import stochvolmodels_amd as sv
+    from stochvolmodels_amd.pricers import logsv_pricer as lp
+    ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
+    k = np.linspace(0.7, 1.3, 13)
+    chain_kw = dict(ttms=ttms, forwards=np.ones(4), discfactors=np.ones(4), strikes_ttms=(k,) * 4,
+                    optiontypes_ttms=(np.where(k >= 1.0, "C", "P"),) * 4)
+    p = sv.LogSvParams(sigma0=0.8, theta=1.0, kappa1=3.0, kappa2=3.0, beta=0.15, volvol=1.8, H=0.1)
+    p.approximate_kernel(T=1.0)
+    pars = dict(sigma0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, orthog_vol=p.volvol,
+                weights=p.weights, nodes=p.nodes)
+    for n in (4000, 100_000):
+        Z0, Z1, grids = sv.get_randoms_for_rough_vol_chain_valuation(ttms, nb_path=n, nb_steps_per_year=360, seed=10)
+        res = sv.upload_rough_randoms(Z0, Z1)
+        out = {}
+        for flag in (False, True, False, True):
+            lp.ROUGH_CHAIN_ONE_LAUNCH = flag
+            f = lambda: sv.rough_logsv_mc_chain_pricer_fixed_randoms(Z0=res, Z1=None, timegrids=grids, **chain_kw, **pars)   # noqa: E731
+            for _ in range(5):
+                f()
+            ts = []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                f()
+                ts.append(time.perf_counter() - t0)
+            out.setdefault(flag, []).append(1e3 * float(np.median(ts)))
+        lp.ROUGH_CHAIN_ONE_LAUNCH = True
+        print(json.dumps(dict(config="rough LogSV chain, 4 expiries x 13 strikes, 3 factors, resident randoms", paths=n,
+                              steps=[int(g.size) - 1 for g in grids], one_launch_ms=out[True], launch_per_expiry_ms=out[False])))
+        res.free()
+
+
 if __name__ == "__main__":
-    main()
+    if "--chain" in sys.argv:
+        chain()
+    else:
+        main()
