@@ -844,57 +844,16 @@ __device__ __forceinline__ void rough_step(const RoughConsts &c, double (&v)[N],
     for (int i = 0; i < N; ++i) v[i] = vh[i];
 }
 
-// RNG = false: Z0/Z1 supplied (the reference's only interface for this model); true: counter-based draw
-template <int N, bool RNG>
-__global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_kernel(double *__restrict__ log_s, double *__restrict__ vol,
-                                                            double *__restrict__ yq, size_t n, int nb_steps,
-                                                            RoughConsts c, const double *__restrict__ Z0,
-                                                            const double *__restrict__ Z1, size_t ldw, uint64_t seed,
-                                                            uint32_t c3, uint64_t path_offset, uint32_t step_offset,
-                                                            int from_origin, SliceOut so)
-{
-    __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
-    __shared__ double s_exp[256];
-    const RngTables tab = stage_tables_if(s_tab, s_exp);
-    const auto exp_of = [&](double a) { return exp_tab(a, s_exp); };
-    const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool active = p < n;
-    double ls = 0.0, y = 0.0;
-    if (active) {
-        double v[N];
-        if (from_origin) {                   // (log_s, v, y) = (0, v0, 0): the chain pricer restarts every expiry here
-#pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = c.v0[i];
-        } else {
-            ls = log_s[p];
-            y = yq[p];
-#pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = vol[static_cast<size_t>(i) * n + p];
-        }
-        if (RNG) {
-            const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
-            rng_time_loop(lane, step_offset, nb_steps, tab,
-                          [&](double z0, double z1) { rough_step<N>(c, v, ls, y, z0, z1, exp_of); });
-        } else {
-            const double *const w[2] = {Z0 + p, Z1 + p};
-            streamed_time_loop<2, SVMC_ROUGH_STREAM_U>(w, ldw, nb_steps,
-                                                       [&](const double(&z)[2]) { rough_step<N>(c, v, ls, y, z[0], z[1], exp_of); });
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) vol[static_cast<size_t>(i) * n + p] = v[i];
-        log_s[p] = ls;
-        yq[p] = y;
-    }
-    slice_epilogue(so, p, active, ls, y);
-}
-
 // ALL expiries of a rough-LogSV chain in ONE launch: the reference re-simulates every expiry from time 0 on its own step
 // (pricers/logsv_pricer.py:1206-1216), so the expiries are INDEPENDENT simulations -- blockIdx.y picks one.  A calibration-
 // sized path set (4 000-10 000 paths: 63-157 waves) fills a sixteenth of the chip, and m such launches one after the other
 // each pay their own latency-bound time loop; side by side they cost the longest one.  Per expiry the arithmetic is
-// rough_logsv_kernel's with from_origin = 1 on the same constants (the step-dependent ones travel per expiry): same bits.
-// Snapshot row i / m + i and partial column pair i belong to expiry i; the state arrays receive the LAST expiry's terminal
-// state, as the expiry-by-expiry loop leaves them.
+// the same on the same constants (the step-dependent ones travel per expiry).  Snapshot row i / m + i and partial column pair i
+// belong to expiry i; the state arrays receive the LAST expiry's terminal state, as the expiry-by-expiry loop leaves them.
+// This is the ONLY rough kernel: a single expiry is grid.y = 1, and a continuation from the resident state (from_origin = 0,
+// the draw's steps starting at step_offset) is the same launch reading the state first -- so one launch per expiry, all
+// expiries in one launch and a run cut into continued halves execute the same code and agree to the bit by construction.
+// RNG = false: Z0/Z1 supplied (the reference's only interface for this model); true: counter-based draw.
 struct RoughExpiries {
     double h[MAX_CHAIN_SLICES], inv_h[MAX_CHAIN_SLICES], sqrt_h[MAX_CHAIN_SLICES], ito[MAX_CHAIN_SLICES],
         volvol_w_sqrt_h[MAX_CHAIN_SLICES], forward[MAX_CHAIN_SLICES];
@@ -906,7 +865,7 @@ template <int N, bool RNG>
 __global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_expiries_kernel(
     double *__restrict__ log_s, double *__restrict__ vol, double *__restrict__ yq, size_t n, RoughConsts c, RoughExpiries e,
     const double *__restrict__ Z0, const double *__restrict__ Z1, size_t ldw, uint64_t seed, uint32_t c3, uint64_t path_offset,
-    double *__restrict__ x_snap, double *__restrict__ q_snap, double *__restrict__ partials)
+    uint32_t step_offset, int from_origin, double *__restrict__ x_snap, double *__restrict__ q_snap, double *__restrict__ partials)
 {
     __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
@@ -924,11 +883,18 @@ __global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_expiries_
     double ls = 0.0, y = 0.0;
     if (active) {
         double v[N];
+        if (from_origin) {                                 // (log_s, v, y) = (0, v0, 0)                   :1206-1208
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] = c.v0[k];        // (log_s, v, y) = (0, v0, 0)                   :1206-1208
+            for (int k = 0; k < N; ++k) v[k] = c.v0[k];
+        } else {                                           // continue from the resident state (single-expiry launches)
+            ls = log_s[p];
+            y = yq[p];
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = vol[static_cast<size_t>(k) * n + p];
+        }
         if (RNG) {
             const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
-            rng_time_loop(lane, 0u, nb_steps, tab, [&](double z0, double z1) { rough_step<N>(c, v, ls, y, z0, z1, exp_of); });
+            rng_time_loop(lane, step_offset, nb_steps, tab, [&](double z0, double z1) { rough_step<N>(c, v, ls, y, z0, z1, exp_of); });
         } else {
             const double *const w[2] = {Z0 + p, Z1 + p};
             streamed_time_loop<2, SVMC_ROUGH_STREAM_U>(w, ldw, nb_steps,
@@ -1913,6 +1879,69 @@ int svmc_heston_chain_rng_from(double x0, double var0, double qvar0, double *x, 
                                  x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes, stream);
 }
 
+// launch of rough_logsv_expiries_kernel: n_expiries simulations from time 0 side by side (grid.y).  EVERY from-origin launch of
+// the rough model goes through this kernel -- the chain (svmc_rough_logsv_chain) and a single expiry (svmc_rough_logsv_slice /
+// _terminal with from_origin != 0: grid.y = 1) -- so that one launch per expiry and all expiries in one launch are the same
+// code on the same constants: identical bits by construction, not by how two kernels happen to be contracted.
+static void launch_rough_expiries(const RoughConsts &c_in, int n_factors, int n_expiries, const int *nb_steps_host,
+                                  const double *hs_host, const double *forwards_host, double *log_s, double *vol, double *qvar,
+                                  size_t n_path, const double *Z0, const double *Z1, size_t ldw, uint64_t seed, uint32_t call_id,
+                                  uint64_t path_offset, uint32_t step_offset, int from_origin, double *x_snapshots,
+                                  double *qvar_snapshots, double *partials, hipStream_t st)
+{
+    RoughConsts c = c_in;
+    RoughExpiries e{};
+    e.m = n_expiries;
+    for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+        const int j = i < n_expiries ? i : 0;
+        const double h = hs_host[j];
+        e.h[i] = h;
+        e.inv_h[i] = 1.0 / h;
+        e.sqrt_h[i] = sqrt(h);
+        e.ito[i] = -0.5 * c.volvol_w * c.volvol_w * h;
+        e.volvol_w_sqrt_h[i] = c.volvol_w * e.sqrt_h[i];
+        e.forward[i] = forwards_host ? forwards_host[j] : 0.0;
+        e.nb_steps[i] = nb_steps_host[j];
+    }
+    const bool draw = Z0 == nullptr;                        // the drawing kernels run the generators' block size
+    const dim3 g(draw ? rng_grid(n_path) : grid_for(n_path), static_cast<unsigned>(n_expiries)), b(draw ? rng_block() : BLOCK);
+    const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals
+#define SVMC_ROUGH_CHAIN_LAUNCH(NF)                                                                                          \
+    do {                                                                                                                     \
+        if (!draw)                                                                                                           \
+            hipLaunchKernelGGL((rough_logsv_expiries_kernel<NF, false>), g, b, 0, st, log_s, vol, qvar, n_path, c, e, Z0, Z1, \
+                               ldw, seed, c3, path_offset, step_offset, from_origin, x_snapshots, qvar_snapshots, partials); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((rough_logsv_expiries_kernel<NF, true>), g, b, 0, st, log_s, vol, qvar, n_path, c, e, Z0, Z1,  \
+                               ldw, seed, c3, path_offset, step_offset, from_origin, x_snapshots, qvar_snapshots, partials); \
+    } while (0)
+    if (n_factors == 1) SVMC_ROUGH_CHAIN_LAUNCH(1);
+    else if (n_factors == 2) SVMC_ROUGH_CHAIN_LAUNCH(2);
+    else SVMC_ROUGH_CHAIN_LAUNCH(3);
+#undef SVMC_ROUGH_CHAIN_LAUNCH
+}
+
+// the step-independent constants of the rough model
+static RoughConsts make_rough_consts(int n_factors, const double *nodes_host, const double *weights_host, const double *v0_host,
+                                     double theta, double kappa1, double kappa2, double rho, double volvol)
+{
+    RoughConsts c{};
+    c.wsum = 0.0;
+    c.w_lam_v0 = 0.0;
+    for (int i = 0; i < n_factors; ++i) {
+        c.nodes[i] = nodes_host[i];
+        c.w[i] = weights_host[i];
+        c.v0[i] = v0_host[i];
+        c.wlam[i] = weights_host[i] * nodes_host[i];
+        c.wsum += weights_host[i];
+        c.w_lam_v0 += c.wlam[i] * v0_host[i];
+    }
+    c.theta = theta; c.kappa1 = kappa1; c.kappa2 = kappa2; c.rho = rho; c.rho_comp = sqrt(1.0 - rho * rho);
+    c.volvol = volvol; c.inv_volvol = 1.0 / volvol; c.w_inv = 1.0 / c.wsum;
+    c.volvol_w = volvol * c.wsum;
+    return c;
+}
+
 static int rough_logsv_launch(const char *name, double *log_s, double *vol, double *qvar, size_t n_path, int nb_steps,
                               double h, int n_factors, const double *nodes_host, const double *weights_host,
                               const double *v0_host, double theta, double kappa1, double kappa2, double rho,
@@ -1929,40 +1958,9 @@ static int rough_logsv_launch(const char *name, double *log_s, double *vol, doub
     SVMC_REQUIRE(call_id < (1u << 24), fn + ": call_id must fit 24 bits");
     SVMC_REQUIRE(volvol > 0.0 && rho * rho <= 1.0, fn + ": volvol > 0 and |rho| <= 1");
     if (n_path == 0 || (nb_steps == 0 && !from_origin && so.partials == nullptr)) return SVMC_OK;
-    RoughConsts c{};
-    c.wsum = 0.0;
-    c.w_lam_v0 = 0.0;
-    for (int i = 0; i < n_factors; ++i) {
-        c.nodes[i] = nodes_host[i];
-        c.w[i] = weights_host[i];
-        c.v0[i] = v0_host[i];
-        c.wlam[i] = weights_host[i] * nodes_host[i];
-        c.wsum += weights_host[i];
-        c.w_lam_v0 += c.wlam[i] * v0_host[i];
-    }
-    c.theta = theta; c.kappa1 = kappa1; c.kappa2 = kappa2; c.rho = rho; c.rho_comp = sqrt(1.0 - rho * rho);
-    c.volvol = volvol; c.inv_volvol = 1.0 / volvol; c.h = h; c.sqrt_h = sqrt(h); c.w_inv = 1.0 / c.wsum;
-    c.volvol_w = volvol * c.wsum;
-    c.inv_h = 1.0 / h;
-    c.ito = -0.5 * c.volvol_w * c.volvol_w * h;
-    c.volvol_w_sqrt_h = c.volvol_w * c.sqrt_h;
-    const bool draw = Z0 == nullptr;                        // the drawing kernels run the generators' block size
-    const dim3 g(draw ? rng_grid(n_path) : grid_for(n_path)), b(draw ? rng_block() : BLOCK);
-    const hipStream_t st = as_stream(stream);
-    const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals
-#define SVMC_ROUGH_LAUNCH(NF)                                                                                          \
-    do {                                                                                                               \
-        if (Z0 != nullptr)                                                                                             \
-            hipLaunchKernelGGL((rough_logsv_kernel<NF, false>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0, \
-                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin, so);                          \
-        else                                                                                                           \
-            hipLaunchKernelGGL((rough_logsv_kernel<NF, true>), g, b, 0, st, log_s, vol, qvar, n_path, nb_steps, c, Z0,  \
-                               Z1, ldw, seed, c3, path_offset, step_offset, from_origin, so);                          \
-    } while (0)
-    if (n_factors == 1) SVMC_ROUGH_LAUNCH(1);
-    else if (n_factors == 2) SVMC_ROUGH_LAUNCH(2);
-    else SVMC_ROUGH_LAUNCH(3);
-#undef SVMC_ROUGH_LAUNCH
+    const RoughConsts c = make_rough_consts(n_factors, nodes_host, weights_host, v0_host, theta, kappa1, kappa2, rho, volvol);
+    launch_rough_expiries(c, n_factors, 1, &nb_steps, &h, &so.forward, log_s, vol, qvar, n_path, Z0, Z1, ldw, seed, call_id,
+                          path_offset, step_offset, from_origin, so.x_snap, so.q_snap, so.partials, as_stream(stream));
     return check_launch(name);
 }
 
@@ -2018,52 +2016,12 @@ int svmc_rough_logsv_chain(double *log_s, double *vol, double *qvar, size_t n_pa
     SVMC_REQUIRE(n_path > 0, fn + ": n_path must be positive");
     if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * n_expiries * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, fn + ": workspace too small (svmc_slice_workspace_bytes)");
-    RoughConsts c{};
-    c.wsum = 0.0;
-    c.w_lam_v0 = 0.0;
-    for (int i = 0; i < n_factors; ++i) {
-        c.nodes[i] = nodes_host[i];
-        c.w[i] = weights_host[i];
-        c.v0[i] = v0_host[i];
-        c.wlam[i] = weights_host[i] * nodes_host[i];
-        c.wsum += weights_host[i];
-        c.w_lam_v0 += c.wlam[i] * v0_host[i];
-    }
-    c.theta = theta; c.kappa1 = kappa1; c.kappa2 = kappa2; c.rho = rho; c.rho_comp = sqrt(1.0 - rho * rho);
-    c.volvol = volvol; c.inv_volvol = 1.0 / volvol; c.w_inv = 1.0 / c.wsum;
-    c.volvol_w = volvol * c.wsum;
-    RoughExpiries e{};
-    e.m = n_expiries;
-    for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
-        const int j = i < n_expiries ? i : 0;
-        const double h = hs_host[j];
-        SVMC_REQUIRE(h > 0.0 && nb_steps_host[j] > 0, fn + ": steps and step counts must be positive");
-        e.h[i] = h;                                         // the step-dependent constants exactly as rough_logsv_launch forms them
-        e.inv_h[i] = 1.0 / h;
-        e.sqrt_h[i] = sqrt(h);
-        e.ito[i] = -0.5 * c.volvol_w * c.volvol_w * h;
-        e.volvol_w_sqrt_h[i] = c.volvol_w * e.sqrt_h[i];
-        e.forward[i] = forwards_host[j];
-        e.nb_steps[i] = nb_steps_host[j];
-    }
-    const bool draw = Z0 == nullptr;
-    const dim3 g(draw ? rng_grid(n_path) : grid_for(n_path), static_cast<unsigned>(n_expiries)), b(draw ? rng_block() : BLOCK);
+    for (int i = 0; i < n_expiries; ++i)
+        SVMC_REQUIRE(hs_host[i] > 0.0 && nb_steps_host[i] > 0, fn + ": steps and step counts must be positive");
+    const RoughConsts c = make_rough_consts(n_factors, nodes_host, weights_host, v0_host, theta, kappa1, kappa2, rho, volvol);
     const hipStream_t st = as_stream(stream);
-    const uint32_t c3 = make_c3(call_id) | 3u;              // stream tag 3: the rough model's normals
-    double *parts = static_cast<double *>(workspace);
-#define SVMC_ROUGH_CHAIN_LAUNCH(NF)                                                                                          \
-    do {                                                                                                                     \
-        if (!draw)                                                                                                           \
-            hipLaunchKernelGGL((rough_logsv_expiries_kernel<NF, false>), g, b, 0, st, log_s, vol, qvar, n_path, c, e, Z0, Z1, \
-                               ldw, seed, c3, path_offset, x_snapshots, qvar_snapshots, parts);                              \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((rough_logsv_expiries_kernel<NF, true>), g, b, 0, st, log_s, vol, qvar, n_path, c, e, Z0, Z1,  \
-                               ldw, seed, c3, path_offset, x_snapshots, qvar_snapshots, parts);                              \
-    } while (0)
-    if (n_factors == 1) SVMC_ROUGH_CHAIN_LAUNCH(1);
-    else if (n_factors == 2) SVMC_ROUGH_CHAIN_LAUNCH(2);
-    else SVMC_ROUGH_CHAIN_LAUNCH(3);
-#undef SVMC_ROUGH_CHAIN_LAUNCH
+    launch_rough_expiries(c, n_factors, n_expiries, nb_steps_host, hs_host, forwards_host, log_s, vol, qvar, n_path, Z0, Z1, ldw,
+                          seed, call_id, path_offset, 0u, 1, x_snapshots, qvar_snapshots, static_cast<double *>(workspace), st);
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * n_expiries), dim3(BLOCK), 0, st, static_cast<const double *>(workspace),
                        wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch("svmc_rough_logsv_chain");
