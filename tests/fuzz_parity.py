@@ -7,7 +7,7 @@ counts, all payoff codes, both measures, both payoff variables, vol backbones, o
   (c) the CPU oracle on the same counter-based randoms,
 requiring (a) == (b) bit for bit and (a) ~ (c) at 1e-9.
 
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tests/fuzz_parity.py [n_cases] [seed]
 """
 import os
 import sys

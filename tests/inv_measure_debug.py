@@ -1,5 +1,8 @@
+"""Checker script (run by hand on a GPU box): the C4 rank share in the inverse measure, GPU vs the CPU oracle, per expiry -- the
+round-3 investigation of the additive recentring under the BTC set.  Lives under tests/ because it drives
+the oracle (test infrastructure)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import stochvolmodels_amd as sv
 from stochvolmodels_amd.engine import get_engine

@@ -1,5 +1,8 @@
+"""Overflow / collapse regimes (checker script, run by hand on a GPU box: python tests/stress_extremes.py): LogSV with volvol 6-8
+over 6-8 years, terminal-state classes (finite / +inf / -inf / NaN) of the GPU generator against the CPU oracle on the same
+stream.  Lives under tests/ because it drives the oracle (test infrastructure)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle
 from stochvolmodels_amd.engine import get_engine

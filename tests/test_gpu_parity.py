@@ -1852,14 +1852,14 @@ def test_reference_quickstart_known_answers(sv):
 
 
 def test_randomised_chain_sweep(sv, oracle):
-    """tools/fuzz_parity.py inside the suite: 40 random chains -- ragged strike counts (1..11 per expiry, 1..6
+    """tests/fuzz_parity.py inside the suite: 40 random chains -- ragged strike counts (1..11 per expiry, 1..6
     expiries), all payoff codes, both measures, both payoff variables, vol backbones, odd path counts, LogSV / Heston
     Euler / QE -- priced by the whole-chain kernels, slice by slice (bit-identical) and by the CPU oracle on the same
     counter-based randoms (1e-8 relative, identical NaN / inf pattern)"""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tests", "fuzz_parity.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(n_cases=40, seed=20240927) < 1e-8
