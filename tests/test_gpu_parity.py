@@ -1285,7 +1285,7 @@ def test_payoff_randomised_against_numpy_semantics(sv, oracle):
 
 @pytest.mark.parametrize("vt", [1, 2])
 def test_payoff_every_group_width(sv, oracle, vt):
-    """one payoff kernel per group width (1..24 strikes of plain chains, 1..16 with inverse options) and payoff variable:
+    """one payoff kernel per group width (1..22 strikes of plain chains, 1..16 with inverse options) and payoff variable:
     every instantiation once, and the widths that spill into a second group, against the NumPy restatement -- with NaN and
     -inf log-returns in the sample, which take the saturated branches of the in-kernel exp"""
     import warnings
