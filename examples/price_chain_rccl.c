@@ -46,6 +46,10 @@ int main(int argc, char **argv)
     const uint64_t n_total = (argc > 4) ? strtoull(argv[4], NULL, 10) : 65536;
     const uint64_t seed = (argc > 5) ? strtoull(argv[5], NULL, 10) : 20240601ull;
 
+    /* fail fast: a rank that dies before ncclCommInitRank leaves the others waiting inside it for ever -- SIGALRM's default
+     * action ends this process (non-zero status) when the whole program has not finished within its deadline */
+    alarm(getenv("SVMC_EXAMPLE_DEADLINE") ? (unsigned)atoi(getenv("SVMC_EXAMPLE_DEADLINE")) : 300u);
+
     int n_dev = 0;
     CHECK(svmc_device_count(&n_dev));
     CHECK(svmc_set_device(rank % n_dev));

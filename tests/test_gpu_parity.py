@@ -807,6 +807,34 @@ def test_vol_paths(sv, oracle, golden):
 
 
 # ---- analytic side (row a11): libsvmc's Fourier kernels ------------------------------------------------------------
+def test_vol_paths_ragged_sizes(sv, oracle):
+    """simulate_vol_paths on every tail of its loops: 1..9 and 18 steps (the drawing loop runs call by call, four steps each;
+    the supplied-brownians loop prefetches groups of four) x path counts around the wave size, both measures, device draw
+    and supplied increments, against the CPU twin"""
+    t = dict(v0=0.3, theta=0.25, kappa1=2.0, kappa2=3.0, beta=-0.4, volvol=0.9)
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for n in (1, 63, 64, 65, 1000):
+        for nb in (1, 2, 3, 4, 5, 6, 7, 8, 9, 18):
+            spy, ttm = nb - 1 if nb > 1 else 1, 1.0 if nb > 1 else 0.5           # int(ttm * spy) + 1 = nb
+            nb_, dt, _ = sv.set_time_grid(ttm, spy)
+            assert nb_ == nb
+            for spot in (True, False):
+                sig, grid = sv.simulate_vol_paths(ttm=ttm, nb_path=n, nb_steps_per_year=spy, is_spot_measure=spot, seed=3 + nb, **t)
+                ref = oracle.logsv_vol_paths(nb, dt, t["v0"], t["theta"], t["kappa1"], t["kappa2"], t["beta"], t["volvol"], n,
+                                             is_spot_measure=spot, seed=3 + nb)
+                assert sig.shape == (nb + 1, n) and grid.shape == (nb + 1,)
+                np.testing.assert_allclose(sig, ref, rtol=1e-12)
+                worst = max(worst, float(np.max(np.abs(sig / ref - 1.0))))
+                w = np.sqrt(dt) * rng.standard_normal((nb, n))
+                sig, _ = sv.simulate_vol_paths(ttm=ttm, nb_path=n, nb_steps_per_year=spy, is_spot_measure=spot, brownians=w, **t)
+                ref = oracle.logsv_vol_paths(nb, dt, t["v0"], t["theta"], t["kappa1"], t["kappa2"], t["beta"], t["volvol"], n,
+                                             is_spot_measure=spot, brownians=w)
+                np.testing.assert_allclose(sig, ref, rtol=1e-12)
+                worst = max(worst, float(np.max(np.abs(sig / ref - 1.0))))
+    print(f"vol paths, ragged sizes: largest relative deviation from the CPU twin {worst:.2e}")
+
+
 def test_analytic_logsv_chain(sv, oracle, golden):
     """GPU analytic LogSV chain vs the reference with its ODE solver tightened (1e-9), vs the reference as shipped
     (2e-6 = its RK45 default error), the quickstart goldens, and the CPU twin"""
