@@ -65,6 +65,13 @@ def layout_replicated(octave, sub, hot_octaves, R, skew):
     return np.where(hot, quad, seg % 16), np.where(hot, idx, seg)
 
 
+# calibration against the counters of round 3 (SQ_LDS_IDX_ACTIVE per ds_read_b128, A/B builds of three table sizes, DESIGN.md
+# section 5): 8.1 / 9.5 / 10.7 cycles at 256 / 512 / 1024 segments
+for parts, measured in ((8, 8.1), (16, 9.5), (32, 10.7)):
+    u = rng.random((20000, 64))
+    oc = np.minimum(np.floor(-np.log2(1.0 - u)).astype(int), 29)
+    seg = (29 - oc) * parts + rng.integers(0, parts, size=(20000, 64))
+    print(f"{32 * parts:5d} segments, committed layout: modelled {cycles(seg % 16, seg):.2f} LDS cycles per ds_read_b128, measured {measured}")
 octave, sub = draw_segments(20000)
 q, a = layout_committed(octave, sub)
 print(f"committed layout: {cycles(q, a):.2f} LDS cycles per ds_read_b128 (conflict-free: 4; measured on the device: 10.7)")
