@@ -804,7 +804,7 @@ def main():
                         leg, err = None, f"{type(exc).__name__}: {exc}"[:300]
                     extra["c_abi_route"] = leg if all_ranks_ok(leg is not None) else {"error": err or "failed on another rank"}
             rc.close()
-    if backend == "nccl" and extra["rccl_ranks_seen"] != world:
+    if (backend == "nccl" or isinstance(comm, svdist.RcclComm)) and extra["rccl_ranks_seen"] != world:
         failures.append(f"rccl_ranks_seen {extra['rccl_ranks_seen']} != --gpus {world} on the RCCL backend")
 
     if world > 1 and not args.no_self_check:
