@@ -15,6 +15,10 @@ from .engine import DeviceBuffer
 
 # Dormand-Prince tolerances of the coefficient ODEs.  The reference uses SciPy's RK45 defaults (1e-3 / 1e-6),
 # i.e. prices good to ~1e-6..1e-4; these reproduce the reference with its solver tightened to 1e-13 in price.
+# The chain pricers take `ode_rtol=` / `ode_atol=` to trade that margin for time (tools/r04/analytic_tolerance_probe.py, a
+# 4 x 21 chain, five parameter sets: 1e-10 / 1e-12 -> 0.92-1.22 ms; 1e-8 / 1e-10 -> 0.52-0.84 ms, prices within 7e-11 of the
+# default's; 1e-6 / 1e-8 -> 0.39-0.69 ms, within 4e-9; all of them stay 6.8e-7 from the reference as shipped -- its own
+# solver's error).
 ODE_RTOL, ODE_ATOL = 1e-10, 1e-12
 
 
@@ -64,11 +68,12 @@ class AnalyticGrid:
         return self._down(self.log_mgf, (self.n,))
 
     def logsv_advance(self, ttm, sigma0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, expansion_order,
-                      vol_backbone_eta) -> None:
+                      vol_backbone_eta, rtol: Optional[float] = None, atol: Optional[float] = None) -> None:
         _lib.check(self.lib.svmc_logsv_mgf_grid(self.phi.ptr, self.psi.ptr, self.n, float(ttm), float(sigma0),
                                                 float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
                                                 int(bool(is_spot_measure)), int(expansion_order), float(vol_backbone_eta),
-                                                self.a.ptr, self.log_mgf.ptr, ODE_RTOL, ODE_ATOL, None))
+                                                self.a.ptr, self.log_mgf.ptr, ODE_RTOL if rtol is None else float(rtol),
+                                                ODE_ATOL if atol is None else float(atol), None))
 
     def heston_advance(self, ttm, v0, theta, kappa, volvol, rho, have_t0: bool) -> None:
         _lib.check(self.lib.svmc_heston_mgf_grid(self.phi.ptr, self.psi.ptr, self.n, float(ttm), float(v0), float(theta),
@@ -128,14 +133,16 @@ class AnalyticGridBatch:
         _lib.check(self.lib.svmc_memset(self.a.ptr, 0, self.a.nbytes, None))
         self._capped: Optional[DeviceBuffer] = None
 
-    def logsv_advance(self, ttm: float, params_rows: np.ndarray, is_spot_measure: bool, expansion_order: int) -> None:
+    def logsv_advance(self, ttm: float, params_rows: np.ndarray, is_spot_measure: bool, expansion_order: int,
+                      rtol: Optional[float] = None, atol: Optional[float] = None) -> None:
         """params_rows [n_sets][8] = (sigma0, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, 0)"""
         rows = np.ascontiguousarray(params_rows, dtype=np.float64)
         assert rows.shape == (self.n_sets, 8)
         _lib.check(self.lib.svmc_logsv_mgf_grid_batch(self.phi.ptr, self.psi.ptr, self.n, self.n_sets, float(ttm),
                                                       rows.ctypes.data_as(C.POINTER(C.c_double)), int(bool(is_spot_measure)),
-                                                      int(expansion_order), self.a.ptr, self.log_mgf.ptr, ODE_RTOL,
-                                                      ODE_ATOL, None))
+                                                      int(expansion_order), self.a.ptr, self.log_mgf.ptr,
+                                                      ODE_RTOL if rtol is None else float(rtol),
+                                                      ODE_ATOL if atol is None else float(atol), None))
 
     def capped_sums(self, forward: float, strikes: np.ndarray) -> np.ndarray:
         """-> [n_sets][n_strikes]"""

@@ -124,7 +124,7 @@ LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa
 def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,
                              discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
                              optiontypes_ttms: Sequence[np.ndarray], is_spot_measure: bool = True,
-                             expansion_order: ExpansionOrder = ExpansionOrder.SECOND, vol_scaler: float = None
+                             expansion_order: ExpansionOrder = ExpansionOrder.SECOND, vol_scaler: float = None, **kwargs
                              ) -> List[List[np.ndarray]]:
     """logsv_chain_pricer (LOG_RETURN, numerical ODE route) for SEVERAL parameter sets on one chain, all sets advanced
     by one launch per expiry and inverted by one launch per expiry: [set][expiry] -> prices.  Each set keeps its own
@@ -142,7 +142,8 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
         for ttm, forward, strikes, types, discfactor in zip(ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors):
             rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, p.get_vol_backbone_eta(tau=ttm), 0.0]
                              for p in params_list])
-            batch.logsv_advance(ttm - ttm0, rows, is_spot_measure, order)
+            batch.logsv_advance(ttm - ttm0, rows, is_spot_measure, order, rtol=kwargs.get("ode_rtol"),
+                                atol=kwargs.get("ode_atol"))
             capped = batch.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
             for s in range(len(params_list)):
                 out[s].append(vanilla_prices_from_capped(capped[s], float(forward), strikes, types, float(discfactor),
@@ -242,15 +243,19 @@ class LogSVPricer(ModelPricer):
         resident = None
         model_vols_batch = None
         if calibration_engine == CalibrationEngine.ANALYTIC:
+            # ode_rtol= / ode_atol=: the tolerances of the coefficient ODEs for this fit (default: the pricers' 1e-10 / 1e-12;
+            # 1e-8 / 1e-10 prices within 7e-11 of that in 0.65 of the time: stochvolmodels_amd/analytic.py)
+            tol = {k: kwargs[k] for k in ("ode_rtol", "ode_atol") if k in kwargs}
+
             def model_vols(pars):
                 return self.compute_model_ivols_for_chain(option_chain=option_chain, params=parse(pars),
-                                                          vol_scaler=vol_scaler)
+                                                          vol_scaler=vol_scaler, **tol)
 
             def model_vols_batch(pars_list):
                 # the n bumped vectors of SLSQP's forward-difference gradient through ONE batch of launches per expiry
                 # (logsv_chain_pricer_batch: the sets advance together; bit-identical to one call per set)
                 prices = self.price_chain_batch(option_chain=option_chain, params_list=[parse(p) for p in pars_list],
-                                                vol_scaler=vol_scaler)
+                                                vol_scaler=vol_scaler, **tol)
                 return [option_chain.compute_model_ivols_from_chain_data(model_prices=pr) for pr in prices]
             if not kwargs.get("batched_gradient", True):
                 model_vols_batch = None
@@ -373,7 +378,8 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
         for ttm, forward, strikes, types, discfactor in zip(ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors):
             eta = params.get_vol_backbone_eta(tau=ttm)
             grid.logsv_advance(ttm - ttm0, params.sigma0, params.theta, params.kappa1, params.kappa2, params.beta,
-                               params.volvol, is_spot_measure, order, eta)
+                               params.volvol, is_spot_measure, order, eta, rtol=kwargs.get("ode_rtol"),
+                               atol=kwargs.get("ode_atol"))
             if vt == 1:
                 capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
                 prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor),

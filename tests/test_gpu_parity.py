@@ -906,6 +906,28 @@ def test_analytic_heston_and_c5_sweep(sv, golden):
         np.testing.assert_array_equal(np.stack(a), np.stack(one_by_one))
 
 
+def test_analytic_chain_ode_tolerance_knob(sv, golden):
+    """ode_rtol= / ode_atol= of the analytic chain pricers: looser tolerances of the coefficient ODEs stay where
+    stochvolmodels_amd/analytic.py says they do (1e-8 / 1e-10 within 1e-9 of the default's prices, 1e-6 / 1e-8 within
+    5e-8), single chain and batch alike, and the batch still equals the chains one by one to the bit"""
+    g = golden("analytic")
+    kk, types, ttms = g["strikes"], g["types"], g["ttms"]
+    chain = sv.OptionChain(ttms=ttms, forwards=np.ones(4), strikes_ttms=(kk,) * 4, optiontypes_ttms=(types,) * 4, ids=None)
+    pricer = sv.LogSVPricer()
+    sets = []
+    for tag in ("btc", "test"):
+        v = [float(a) for a in g[f"logsv_{tag}_params"]]
+        sets.append(sv.LogSvParams(sigma0=v[0], theta=v[1], kappa1=v[2], kappa2=v[3], beta=v[4], volvol=v[5]))
+    base = [np.stack(pricer.price_chain(chain, p)) for p in sets]
+    for (rt, at), bound in (((1e-8, 1e-10), 1e-9), ((1e-6, 1e-8), 5e-8)):
+        loose = [np.stack(pricer.price_chain(chain, p, ode_rtol=rt, ode_atol=at)) for p in sets]
+        for a, b in zip(loose, base):
+            assert 0.0 < float(np.max(np.abs(a - b))) <= bound, (rt, float(np.max(np.abs(a - b))))
+        batch = pricer.price_chain_batch(chain, sets, ode_rtol=rt, ode_atol=at)
+        for a, b in zip(batch, loose):
+            np.testing.assert_array_equal(np.stack(a), b)
+
+
 def test_c5_reference_criterion_at_reference_scale(sv, golden):
     """Config C5's acceptance criterion, verbatim and at the reference's own scale: the reference accepts its analytic
     LogSV prices against Monte Carlo when |analytic - MC| <= 4 stderr on a 3-month slice (strikes 0.9 / 1.0 / 1.1,
