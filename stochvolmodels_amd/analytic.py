@@ -92,6 +92,33 @@ class AnalyticGrid:
         _lib.check(self.lib.svmc_stream_synchronize(None))
         return out
 
+    # -- the same two reductions QUEUED into slices of one result buffer, downloaded once per chain: a chain's expiries are
+    #    then launched back to back (advance, invert, advance, invert, ...) with no host round trip between them -- the wait
+    #    for each expiry's sums cost a wake-up, the interpreter and a launch latency per expiry with the GPU idle (~50 us each)
+    def reserve_results(self, n_doubles: int) -> None:
+        if self._capped is None or self._capped.n < n_doubles:
+            if self._capped is not None:
+                self._capped.free()
+            self._capped = DeviceBuffer(max(int(n_doubles), 32))
+
+    def queue_capped_sums(self, forward: float, strikes: np.ndarray, offset: int) -> None:
+        strikes = np.ascontiguousarray(strikes, dtype=np.float64)      # copied by the call (kernel arguments / pinned staging)
+        _lib.check(self.lib.svmc_mgf_vanilla_slice(self.phi.ptr, self.log_mgf.ptr, self.n, float(forward),
+                                                   strikes.ctypes.data_as(C.POINTER(C.c_double)), strikes.size,
+                                                   self._capped.offset(offset), None))
+
+    def queue_qvar_sums(self, ttm: float, strikes: np.ndarray, offset: int) -> None:
+        strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+        _lib.check(self.lib.svmc_mgf_qvar_slice(self.psi.ptr, self.log_mgf.ptr, self.n, float(ttm),
+                                                strikes.ctypes.data_as(C.POINTER(C.c_double)), strikes.size,
+                                                self._capped.offset(offset), None))
+
+    def download_results(self, n_doubles: int) -> np.ndarray:
+        out = np.empty(int(n_doubles))
+        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, 8 * int(n_doubles), None))
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        return out
+
     def qvar_sums(self, ttm: float, strikes: np.ndarray) -> np.ndarray:
         strikes = np.ascontiguousarray(strikes, dtype=np.float64)
         k = strikes.size
@@ -155,6 +182,25 @@ class AnalyticGridBatch:
                                                          None))
         out = np.empty((self.n_sets, k))
         _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, out.nbytes, None))
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        return out
+
+    def reserve_results(self, n_doubles: int) -> None:
+        if self._capped is None or self._capped.n < n_doubles:
+            if self._capped is not None:
+                self._capped.free()
+            self._capped = DeviceBuffer(max(int(n_doubles), 32))
+
+    def queue_capped_sums(self, forward: float, strikes: np.ndarray, offset: int) -> None:
+        """the [n_sets][n_strikes] sums of one expiry, queued into the result buffer at `offset` (AnalyticGrid.queue_capped_sums)"""
+        strikes = np.ascontiguousarray(strikes, dtype=np.float64)
+        _lib.check(self.lib.svmc_mgf_vanilla_slice_batch(self.phi.ptr, self.log_mgf.ptr, self.n, self.n_sets, float(forward),
+                                                         strikes.ctypes.data_as(C.POINTER(C.c_double)), strikes.size,
+                                                         self._capped.offset(offset), None))
+
+    def download_results(self, n_doubles: int) -> np.ndarray:
+        out = np.empty(int(n_doubles))
+        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, 8 * int(n_doubles), None))
         _lib.check(self.lib.svmc_stream_synchronize(None))
         return out
 

@@ -145,16 +145,27 @@ def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rh
     phi_grid, psi_grid, _ = mgfp.get_transform_var_grid(variable_type=variable_type, vol_scaler=vol_scaler)
     grid = AnalyticGrid(phi_grid, psi_grid, 1)
     try:
-        prices, ttm0 = [], 0.0
-        for ttm, forward, discfactor, strikes, types in zip(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms):
+        # the chain's launches queued back to back, one download of every expiry's sums at the end (AnalyticGrid.queue_*)
+        ks = [int(np.asarray(k).size) for k in strikes_ttms]
+        offs = np.concatenate([[0], np.cumsum(ks)]).astype(int)
+        grid.reserve_results(int(offs[-1]))
+        ttm0 = 0.0
+        for i, (ttm, forward, strikes) in enumerate(zip(ttms, forwards, strikes_ttms)):
             grid.heston_advance(ttm - ttm0, v0, theta, kappa, volvol, rho, True)     # zero a, b == the None branch
             if vt == 1:
-                capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
-                prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor), True))
+                grid.queue_capped_sums(float(forward), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             else:
-                sums = grid.qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64))
-                prices.append(qvar_prices_from_sums(sums, float(ttm), types, float(discfactor)))
+                grid.queue_qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             ttm0 = ttm
+        sums = grid.download_results(int(offs[-1]))
+        prices = []
+        for i, (ttm, forward, discfactor, strikes, types) in enumerate(zip(ttms, forwards, discfactors, strikes_ttms,
+                                                                           optiontypes_ttms)):
+            if vt == 1:
+                prices.append(vanilla_prices_from_capped(sums[offs[i]:offs[i + 1]], float(forward), strikes, types,
+                                                         float(discfactor), True))
+            else:
+                prices.append(qvar_prices_from_sums(sums[offs[i]:offs[i + 1]], float(ttm), types, float(discfactor)))
         return prices
     finally:
         grid.close()

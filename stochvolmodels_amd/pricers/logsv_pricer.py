@@ -138,17 +138,27 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
                                                      if vol_scaler is None else vol_scaler)) for p in params_list]
     batch = AnalyticGridBatch([g[0] for g in grids], [g[1] for g in grids], 5 if order == 2 else 3)
     try:
-        out, ttm0 = [[] for _ in params_list], 0.0
-        for ttm, forward, strikes, types, discfactor in zip(ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors):
+        # every expiry's launches are queued back to back (advance, invert, advance, invert, ...) and the sums come back in ONE
+        # download at the end of the chain: no host round trip between expiries
+        ks = [int(np.asarray(k).size) for k in strikes_ttms]
+        n_sets = len(params_list)
+        offs = np.concatenate([[0], np.cumsum([n_sets * k for k in ks])]).astype(int)
+        batch.reserve_results(int(offs[-1]))
+        ttm0 = 0.0
+        for i, (ttm, forward, strikes) in enumerate(zip(ttms, forwards, strikes_ttms)):
             rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, p.get_vol_backbone_eta(tau=ttm), 0.0]
                              for p in params_list])
             batch.logsv_advance(ttm - ttm0, rows, is_spot_measure, order, rtol=kwargs.get("ode_rtol"),
                                 atol=kwargs.get("ode_atol"))
-            capped = batch.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
-            for s in range(len(params_list)):
+            batch.queue_capped_sums(float(forward), np.asarray(strikes, dtype=np.float64), int(offs[i]))
+            ttm0 = ttm
+        sums = batch.download_results(int(offs[-1]))
+        out = [[] for _ in params_list]
+        for i, (forward, strikes, types, discfactor) in enumerate(zip(forwards, strikes_ttms, optiontypes_ttms, discfactors)):
+            capped = sums[offs[i]:offs[i + 1]].reshape(n_sets, ks[i])
+            for s in range(n_sets):
                 out[s].append(vanilla_prices_from_capped(capped[s], float(forward), strikes, types, float(discfactor),
                                                          is_spot_measure))
-            ttm0 = ttm
         return out
     finally:
         batch.close()
@@ -374,20 +384,30 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
                                                         vol_scaler=vol_scaler)
     grid = AnalyticGrid(phi_grid, psi_grid, 5 if order == 2 else 3)
     try:
-        prices, ttm0 = [], 0.0
-        for ttm, forward, strikes, types, discfactor in zip(ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors):
+        # the chain's launches queued back to back, one download of every expiry's sums at the end (AnalyticGrid.queue_*)
+        ks = [int(np.asarray(k).size) for k in strikes_ttms]
+        offs = np.concatenate([[0], np.cumsum(ks)]).astype(int)
+        grid.reserve_results(int(offs[-1]))
+        ttm0 = 0.0
+        for i, (ttm, forward, strikes) in enumerate(zip(ttms, forwards, strikes_ttms)):
             eta = params.get_vol_backbone_eta(tau=ttm)
             grid.logsv_advance(ttm - ttm0, params.sigma0, params.theta, params.kappa1, params.kappa2, params.beta,
                                params.volvol, is_spot_measure, order, eta, rtol=kwargs.get("ode_rtol"),
                                atol=kwargs.get("ode_atol"))
             if vt == 1:
-                capped = grid.capped_sums(float(forward), np.asarray(strikes, dtype=np.float64))
-                prices.append(vanilla_prices_from_capped(capped, float(forward), strikes, types, float(discfactor),
-                                                         is_spot_measure))
+                grid.queue_capped_sums(float(forward), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             else:
-                sums = grid.qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64))
-                prices.append(qvar_prices_from_sums(sums, float(ttm), types, float(discfactor)))
+                grid.queue_qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             ttm0 = ttm
+        sums = grid.download_results(int(offs[-1]))
+        prices = []
+        for i, (ttm, forward, strikes, types, discfactor) in enumerate(zip(ttms, forwards, strikes_ttms, optiontypes_ttms,
+                                                                           discfactors)):
+            if vt == 1:
+                prices.append(vanilla_prices_from_capped(sums[offs[i]:offs[i + 1]], float(forward), strikes, types,
+                                                         float(discfactor), is_spot_measure))
+            else:
+                prices.append(qvar_prices_from_sums(sums[offs[i]:offs[i + 1]], float(ttm), types, float(discfactor)))
         return prices
     finally:
         grid.close()
