@@ -6,6 +6,7 @@ Complex arrays travel as numpy.complex128 <-> interleaved doubles.  GPU only, li
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -22,8 +23,56 @@ from .engine import DeviceBuffer
 ODE_RTOL, ODE_ATOL = 1e-10, 1e-12
 
 
-class AnalyticGrid:
+# Grids are pooled per (thread, class, sizes): a chain pricing took a grid's five allocations, two uploads (each with its own
+# wait) and five frees -- 58 us per chain (tools/r04/analytic_grid_probe.py) of an 0.9-1.2 ms pricing, and the whole of it
+# again at every objective evaluation of an analytic calibration, whose transform grid never changes.  acquire() hands back
+# the pooled object with its ODE state zeroed (queued memsets) and re-uploads phi / psi only when their bytes changed;
+# release() returns it.  One pooled grid per key: a second acquire() before the release() builds a private one.
+_POOL = {}
+_POOL_LOCK = threading.Lock()
+
+
+class _Pooled:
+    @classmethod
+    def acquire(cls, *args):
+        key = (threading.get_ident(), cls.__name__) + cls._pool_key(*args)
+        with _POOL_LOCK:
+            obj = _POOL.pop(key, None)
+        if obj is None:
+            obj = cls(*args)
+        else:
+            obj._reset(*args)
+        obj._pool_slot = key
+        return obj
+
+    def release(self) -> None:
+        key = getattr(self, "_pool_slot", None)
+        with _POOL_LOCK:
+            if key is not None and key not in _POOL:
+                _POOL[key] = self
+                return
+        self.close()
+
+
+class AnalyticGrid(_Pooled):
     """transform grid phi (and psi) resident on the device, with the per-grid-point ODE state carried slice to slice"""
+
+    @staticmethod
+    def _pool_key(phi, psi, n_coef):
+        return (int(np.asarray(phi).size), int(n_coef))
+
+    def _reset(self, phi, psi, n_coef) -> None:
+        phi = np.ascontiguousarray(phi, dtype=np.complex128)
+        psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        if not np.array_equal(phi, self.phi_host):
+            _lib.check(self.lib.svmc_memcpy_h2d(self.phi.ptr, phi.ctypes.data, phi.nbytes, None))
+            self.phi_host = phi
+        if not np.array_equal(psi, self.psi_host):
+            _lib.check(self.lib.svmc_memcpy_h2d(self.psi.ptr, psi.ctypes.data, psi.nbytes, None))
+            self.psi_host = psi
+        _lib.check(self.lib.svmc_stream_synchronize(None))     # pageable sources: the copies must not outlive the arrays
+        _lib.check(self.lib.svmc_memset(self.a.ptr, 0, self.a.nbytes, None))
+        _lib.check(self.lib.svmc_memset(self.b.ptr, 0, self.b.nbytes, None))
 
     def __init__(self, phi: np.ndarray, psi: np.ndarray, n_coef: int):
         self.lib = _lib.load()
@@ -35,7 +84,8 @@ class AnalyticGrid:
         self.n_coef = int(n_coef)
         self.phi_host = np.ascontiguousarray(phi, dtype=np.complex128)
         self.phi = self._up(self.phi_host)
-        self.psi = self._up(np.ascontiguousarray(psi, dtype=np.complex128))
+        self.psi_host = np.ascontiguousarray(psi, dtype=np.complex128)
+        self.psi = self._up(self.psi_host)
         self.a = DeviceBuffer(2 * self.n * self.n_coef)
         self.b = DeviceBuffer(2 * self.n)
         self.log_mgf = DeviceBuffer(2 * self.n)
@@ -137,11 +187,25 @@ class AnalyticGrid:
                 b.free()
 
 
-class AnalyticGridBatch:
+class AnalyticGridBatch(_Pooled):
     """the transform grids of SEVERAL LogSV parameter sets resident on the device, advanced expiry by expiry in one
     launch per expiry (svmc_logsv_mgf_grid_batch) and inverted in one launch per expiry (svmc_mgf_vanilla_slice_batch):
     config C5's five sets, or the bumped parameter vectors of a finite-difference gradient, side by side.  Bit-identical
     to one AnalyticGrid per set."""
+
+    @staticmethod
+    def _pool_key(phis, psis, n_coef):
+        return (len(phis), int(np.asarray(phis[0]).size), int(n_coef))
+
+    def _reset(self, phis, psis, n_coef) -> None:
+        phi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in phis]))
+        psi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in psis]))
+        for buf, z, name in ((self.phi, phi, "phi_host"), (self.psi, psi, "psi_host")):
+            if not np.array_equal(z, getattr(self, name)):
+                _lib.check(self.lib.svmc_memcpy_h2d(buf.ptr, z.ctypes.data, z.nbytes, None))
+                setattr(self, name, z)
+        _lib.check(self.lib.svmc_stream_synchronize(None))
+        _lib.check(self.lib.svmc_memset(self.a.ptr, 0, self.a.nbytes, None))
 
     def __init__(self, phis: Sequence[np.ndarray], psis: Sequence[np.ndarray], n_coef: int):
         self.lib = _lib.load()
@@ -151,6 +215,7 @@ class AnalyticGridBatch:
         phi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in phis]))
         psi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in psis]))
         assert phi.shape == psi.shape == (self.n_sets, self.n)
+        self.phi_host, self.psi_host = phi, psi
         self.phi, self.psi = DeviceBuffer(2 * phi.size), DeviceBuffer(2 * psi.size)
         for buf, z in ((self.phi, phi), (self.psi, psi)):
             _lib.check(self.lib.svmc_memcpy_h2d(buf.ptr, z.ctypes.data, z.nbytes, None))

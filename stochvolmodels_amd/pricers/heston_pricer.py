@@ -143,7 +143,7 @@ def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rh
     if vol_scaler is None:
         vol_scaler = np.minimum(0.3, np.sqrt(v0 * ttms[0]))
     phi_grid, psi_grid, _ = mgfp.get_transform_var_grid(variable_type=variable_type, vol_scaler=vol_scaler)
-    grid = AnalyticGrid(phi_grid, psi_grid, 1)
+    grid = AnalyticGrid.acquire(phi_grid, psi_grid, 1)
     try:
         # the chain's launches queued back to back, one download of every expiry's sums at the end (AnalyticGrid.queue_*)
         ks = [int(np.asarray(k).size) for k in strikes_ttms]
@@ -168,7 +168,7 @@ def heston_chain_pricer(v0: float, theta: float, kappa: float, volvol: float, rh
                 prices.append(qvar_prices_from_sums(sums[offs[i]:offs[i + 1]], float(ttm), types, float(discfactor)))
         return prices
     finally:
-        grid.close()
+        grid.release()
 
 
 def simulate_heston_x_vol_terminal(ttm: float, x0: np.ndarray, var0: np.ndarray, qvar0: np.ndarray, theta: float,

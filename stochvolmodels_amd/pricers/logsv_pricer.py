@@ -136,7 +136,7 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
     grids = [mgfp.get_transform_var_grid(variable_type=VariableType.LOG_RETURN, is_spot_measure=is_spot_measure,
                                          vol_scaler=(set_vol_scaler(sigma0=p.sigma0, ttm=np.min(ttms))
                                                      if vol_scaler is None else vol_scaler)) for p in params_list]
-    batch = AnalyticGridBatch([g[0] for g in grids], [g[1] for g in grids], 5 if order == 2 else 3)
+    batch = AnalyticGridBatch.acquire([g[0] for g in grids], [g[1] for g in grids], 5 if order == 2 else 3)
     try:
         # every expiry's launches are queued back to back (advance, invert, advance, invert, ...) and the sums come back in ONE
         # download at the end of the chain: no host round trip between expiries
@@ -161,7 +161,7 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
                                                          is_spot_measure))
         return out
     finally:
-        batch.close()
+        batch.release()
 
 
 class LogSVPricer(ModelPricer):
@@ -382,7 +382,7 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
         vol_scaler = set_vol_scaler(sigma0=params.sigma0, ttm=np.min(ttms))
     phi_grid, psi_grid, _ = mgfp.get_transform_var_grid(variable_type=variable_type, is_spot_measure=is_spot_measure,
                                                         vol_scaler=vol_scaler)
-    grid = AnalyticGrid(phi_grid, psi_grid, 5 if order == 2 else 3)
+    grid = AnalyticGrid.acquire(phi_grid, psi_grid, 5 if order == 2 else 3)
     try:
         # the chain's launches queued back to back, one download of every expiry's sums at the end (AnalyticGrid.queue_*)
         ks = [int(np.asarray(k).size) for k in strikes_ttms]
@@ -410,7 +410,7 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
                 prices.append(qvar_prices_from_sums(sums[offs[i]:offs[i + 1]], float(ttm), types, float(discfactor)))
         return prices
     finally:
-        grid.close()
+        grid.release()
 
 
 def _broadcast_state(x0, vol0, qvar0, nb_path):
