@@ -438,7 +438,7 @@ SVMC_API int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn
  *                          per grid point integrate A' = A^T M A + L A + H (:67-205) over ttm from a[] (in: A at the
  *                          previous expiry, out: A at this one; [n_grid][5] for expansion_order 2, [n_grid][3] for 1)
  *                          and return log_mgf = sum_k A_k (sigma0 - theta)^k.  The reference calls SciPy RK45 at its
- *                          default rtol 1e-3 / atol 1e-6; here the embedded Dormand-Prince pair takes rtol/atol.
+ *                          default rtol 1e-3 / atol 1e-6; here the Dormand-Prince 8(5,3) pair (DOP853) takes rtol/atol.
  *   svmc_heston_mgf_grid   compute_heston_mgf_grid, pricers/heston_pricer.py:183-214 (closed form; a, b carried).
  *   svmc_mgf_vanilla_slice the strike sums of vanilla_slice_pricer_with_mgf_grid, utils/mgf_pricer.py:174-221, for
  *                          grids with |Re phi| = 1/2: capped[k] = nansum_j Re[ w_j/(pi (p_j^2+1/4))

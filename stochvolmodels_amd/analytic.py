@@ -17,9 +17,9 @@ from .engine import DeviceBuffer
 # Dormand-Prince tolerances of the coefficient ODEs.  The reference uses SciPy's RK45 defaults (1e-3 / 1e-6),
 # i.e. prices good to ~1e-6..1e-4; these reproduce the reference with its solver tightened to 1e-13 in price.
 # The chain pricers take `ode_rtol=` / `ode_atol=` to trade that margin for time (tools/r04/analytic_tolerance_probe.py, a
-# 4 x 21 chain, five parameter sets: 1e-10 / 1e-12 -> 0.92-1.22 ms; 1e-8 / 1e-10 -> 0.52-0.84 ms, prices within 7e-11 of the
-# default's; 1e-6 / 1e-8 -> 0.39-0.69 ms, within 4e-9; all of them stay 6.8e-7 from the reference as shipped -- its own
-# solver's error).
+# 4 x 21 chain, five parameter sets, DOP853: 1e-10 / 1e-12 -> 0.40-0.79 ms; 1e-8 / 1e-10 -> 0.31-0.71 ms, prices within
+# 1.1e-11 of the default's; 1e-6 / 1e-8 -> 0.28-0.67 ms, within 4.5e-9; all of them stay 6.8e-7 from the reference as shipped
+# -- its own solver's error.  With the 5(4) pair of rounds 1-3 the same settings took 0.92-1.22 / 0.52-0.84 / 0.39-0.69 ms).
 ODE_RTOL, ODE_ATOL = 1e-10, 1e-12
 
 

@@ -3,7 +3,7 @@ Affine expansion of the LogSV MGF on the GPU (mirror of the numerical path of th
 pricers/logsv/affine_expansion.py: ExpansionOrder :43-55, get_expansion_n :58-65, compute_logsv_a_mgf_grid :570-685).
 
 The coefficient ODEs A' = A^T M A + L A + H (Eq. 4.14; matrices of Eqs. 4.17 / 4.25) are integrated by
-libsvmc's logsv_mgf_grid_kernel, one 16-lane row per transform-grid point, with an embedded Dormand-Prince pair at
+libsvmc's logsv_mgf_grid_kernel, one 16-lane row per transform-grid point, with the Dormand-Prince 8(5,3) pair (DOP853) at
 rtol 1e-10 (the reference: a Python loop of scipy.solve_ivp RK45 calls at rtol 1e-3).  The semi-analytic
 fixed-point path (`is_analytic=True`) and the BDF switch are not reproduced: `is_stiff_solver` is accepted and
 ignored (the adaptive explicit pair simply takes more steps), `is_analytic=True` raises.

@@ -254,7 +254,7 @@ class LogSVPricer(ModelPricer):
         model_vols_batch = None
         if calibration_engine == CalibrationEngine.ANALYTIC:
             # ode_rtol= / ode_atol=: the tolerances of the coefficient ODEs for this fit (default: the pricers' 1e-10 / 1e-12;
-            # 1e-8 / 1e-10 prices within 7e-11 of that in 0.65 of the time: stochvolmodels_amd/analytic.py)
+            # looser settings buy little since the 8th-order pair: stochvolmodels_amd/analytic.py)
             tol = {k: kwargs[k] for k in ("ode_rtol", "ode_atol") if k in kwargs}
 
             def model_vols(pars):
