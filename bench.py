@@ -529,28 +529,36 @@ class CAbiChain:
 
 
 def c_abi_route_leg(make_chain, python_step, calls: int, n_paths_job: int, nb: int, barrier, max_over_ranks) -> dict:
-    """`calls` chains through CAbiChain.price, each timed on the host clock; the Python route's prices on the last seed
-    beside it.  The timed region runs with the garbage collector frozen (main() did that before its own timed region)."""
+    """`calls` chains through CAbiChain.price, each timed on the host clock and INTERLEAVED call by call with the Python route on
+    the same seed (the chip's clock drifts over a run: two routes timed in separate windows differ by the drift, not by the
+    route -- tools/ubench/fused_driver_overhead.py), prices compared on every call.  Runs with the garbage collector frozen
+    (main() did that before its own timed region)."""
     chain = make_chain()
     try:
         for i in range(3):
             chain.price(7 + i)
         barrier()
-        ts = []
+        t_c, t_py, equal, worst = [], [], True, 0.0
         for i in range(calls):
             t0 = time.perf_counter()
+            p_py, e_py = python_step(i)
+            t1 = time.perf_counter()
             p_c, e_c = chain.price(20240602 + i)
-            ts.append(time.perf_counter() - t0)
+            t2 = time.perf_counter()
+            t_py.append(t1 - t0)
+            t_c.append(t2 - t1)
+            equal = equal and all(np.array_equal(a, b) for a, b in zip(p_c, p_py)) and \
+                all(np.array_equal(a, b) for a, b in zip(e_c, e_py))
+            worst = max(worst, max_rel_dev(p_c, p_py))
         barrier()
-        p_py, e_py = python_step(calls - 1)
-        ts = np.array(ts)
-        med = max_over_ranks(float(np.median(ts)))
+        t_c, t_py = np.array(t_c), np.array(t_py)
+        med = max_over_ranks(float(np.median(t_c)))
+        med_py = max_over_ranks(float(np.median(t_py)))
         return {"entry_point": "svmc_logsv_chain_price (one C-ABI call per chain, svmc_session_t)", "calls": calls,
-                "ms_per_step": 1e3 * med, "ms_per_step_max": 1e3 * max_over_ranks(float(ts.max())),
-                "ms_per_step_mean": 1e3 * max_over_ranks(float(ts.mean())), "value": n_paths_job * nb / med,
-                "prices_equal_python_route": bool(all(np.array_equal(a, b) for a, b in zip(p_c, p_py))
-                                                  and all(np.array_equal(a, b) for a, b in zip(e_c, e_py))),
-                "max_rel_dev_vs_python_route": max_rel_dev(p_c, p_py)}
+                "ms_per_step": 1e3 * med, "ms_per_step_max": 1e3 * max_over_ranks(float(t_c.max())),
+                "ms_per_step_mean": 1e3 * max_over_ranks(float(t_c.mean())), "value": n_paths_job * nb / med,
+                "python_route_ms_per_step_interleaved": 1e3 * med_py, "c_over_python_interleaved": med / med_py,
+                "prices_equal_python_route": bool(equal), "max_rel_dev_vs_python_route": worst}
     finally:
         chain.close()
 
