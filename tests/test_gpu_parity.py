@@ -1965,6 +1965,31 @@ def _check_self_proving_fields(line, world):
     assert 500.0 < r["clock_mhz_in_kernel"] <= 2500.0 and r["frac"] <= r["frac_at_sustained_clock"] < 1.05
 
 
+def test_bench_line_one_gpu():
+    """the default single-GPU line (C2) at a few steps: the fused C driver's leg (bit-equal prices, interleaved with the Python
+    route), the clock measured inside the kernel and the fraction against it, the counters only when they are this library's"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SVMC_DIST_BACKEND")}
+    env["SVMC_BENCH_PREWARM"] = "3"
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-sample-paths",
+                          "4096", "--no-streamed", "--no-extra-legs"], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["workload"].startswith("C2") and line["config"]["paths_total"] == 1 << 20
+    c = line["c_abi_route"]
+    assert c["prices_equal_python_route"] is True and c["max_rel_dev_vs_python_route"] == 0.0 and c["calls"] >= 3
+    assert 0.85 < c["c_over_python_interleaved"] < 1.1 and c["value"] > 1e11
+    r = line["roofline"]
+    assert r["kernel"] == "logsv_rng_kernel" and r["stale"] is False and 500.0 < r["clock_mhz_in_kernel"] <= 2500.0
+    assert r["frac"] <= r["frac_at_sustained_clock"] < 1.0 and r["frac_at_sustained_clock"] <= r["frac_in_stream_at_sustained_clock"] < 1.1
+    assert ("counters" in r) == (r["insts_per_wave_step_counters"] is not None)
+    assert line["cpu_baseline"]["kind"] == "port" and "self_check_failed" not in line
+
+
 def test_bench_line_eight_ranks_share_one_gpu():
     """the rehearsal of the driver's 8-GPU run on the hardware there is: `python bench.py --gpus 8` starts its own eight
     ranks (gloo: they share this GPU), 8-way shard_range, eight local ranks -> devices, eight torch.distributed.run
