@@ -38,6 +38,10 @@ class _Pooled:
         key = (threading.get_ident(), cls.__name__) + cls._pool_key(*args)
         with _POOL_LOCK:
             obj = _POOL.pop(key, None)
+            if len(_POOL) > 8:                                  # grids of threads that ended: free their HBM
+                alive = {t.ident for t in threading.enumerate()}
+                for k in [k for k in _POOL if k[0] not in alive]:
+                    _POOL.pop(k).close()
         if obj is None:
             obj = cls(*args)
         else:
