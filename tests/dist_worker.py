@@ -18,7 +18,8 @@ def main(out_path):
     from stochvolmodels_amd.pricers import heston_pricer, logsv_pricer
     from stochvolmodels_amd.utils.config import VariableType
 
-    comm = svdist.init_from_env(backend="gloo")
+    phases = []
+    comm = svdist.init_from_env(backend="gloo", on_phase=phases.append)
     engines = {}
 
     def fake_get_engine(n_path, path_offset=0, device=None):
@@ -63,6 +64,7 @@ def main(out_path):
     res["rng_state"] = np.array(funcs.get_rng_state(), dtype=np.uint64)
     pr, sd = logsv_pricer.logsv_mc_chain_pricer(**{**short, "seed": None})
     res["unseeded_prices"] = np.stack(pr)
+    res["phases"] = np.array(phases)
     res["rank_paths"] = np.array([e.n_path for e in engines.values()])
     res["rank_offsets"] = np.array([e.path_offset for e in engines.values()])
     np.savez(out_path + f".rank{comm.rank}.npz", **res)

@@ -87,6 +87,8 @@ def test_sharded_chain_matches_single_process(oracle, tmp_path, world):
         assert np.array_equal(got["unseeded_prices"], rank0["unseeded_prices"])
         for key, ref in exp.items():                       # every rank returns the global result
             np.testing.assert_allclose(got[key], ref, rtol=1e-11, atol=1e-14, err_msg=f"{key} rank {r}/{world}")
+        # the phases a launcher's watchdog arms its deadlines from (bench.py): none for a lone process without a group
+        assert list(got["phases"]) == ([] if world == 1 else ["rendezvous", "collective_init", "ready"])
         assert set(got["rank_paths"]) == {(1001 * (r + 1)) // world - (1001 * r) // world}
         offsets.append(int(got["rank_offsets"][0]))
     assert offsets == [(1001 * r) // world for r in range(world)]

@@ -455,3 +455,27 @@ def test_batched_gradient_uses_scipys_difference_points():
         obj.model_vols_batch = lambda pts: [fun(p) for p in pts]
         obj._last = (x0.tobytes(), f0)
         np.testing.assert_array_equal(obj.gradient(x0), g_scipy)
+
+
+def test_bench_watchdog_ends_a_stuck_phase():
+    """bench.py's Watchdog (no GPU involved): a phase that overruns its deadline ends the process with status 1 and the
+    phase's name and a traceback on stderr -- even while the main thread sits in a call that never returns; a phase that
+    finishes in time and disarms leaves the process alone"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib.util, sys, time\n"
+            f"spec = importlib.util.spec_from_file_location('bench', r'{os.path.join(root, 'bench.py')}')\n"
+            "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+            "wd = bench.Watchdog(7)\n"
+            "wd.arm(30.0, 'a phase that ends in time'); wd.disarm()\n"
+            "wd.arm(2.0, 'a collective that never returns')\n"
+            "if sys.argv[1] == 'hang': time.sleep(60)\n"
+            "wd.disarm(); print('finished')\n")
+    ok = subprocess.run([sys.executable, "-c", code, "fine"], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and "finished" in ok.stdout
+    stuck = subprocess.run([sys.executable, "-c", code, "hang"], capture_output=True, text=True, timeout=120)
+    assert stuck.returncode == 1 and "finished" not in stuck.stdout
+    assert "rank 7" in stuck.stderr and "a collective that never returns" in stuck.stderr and "did not finish within 2 s" in stuck.stderr
+    assert "time.sleep" in stuck.stderr or "Timeout" in stuck.stderr or "line" in stuck.stderr          # the traceback
