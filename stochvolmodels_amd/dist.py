@@ -92,6 +92,11 @@ class TorchComm:
             self._torch.cuda.synchronize(handle.device)   # reduced values visible to the next svmc kernels
 
     def to_host(self, engine, ptr, handle, n: int):
+        if handle.is_cuda and self._stream_ordered(engine, handle) and hasattr(engine, "download"):
+            # the reduced sums sit in device memory behind `ptr` and the collective is ordered on the engine's stream: take them
+            # through the engine's page-locked landing buffer like the single-GPU route does (a torch .cpu() of 4 KB goes through
+            # the runtime's pageable staging path: ~16 us more per chain, tools/ubench/sync_latency.py)
+            return engine.download(ptr, n)
         engine.synchronize()
         return handle[:n].detach().cpu().numpy().copy()
 
