@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .engine import DeviceBuffer
+from .engine import DeviceBuffer, _current_device
 
 # Dormand-Prince tolerances of the coefficient ODEs.  The reference uses SciPy's RK45 defaults (1e-3 / 1e-6),
 # i.e. prices good to ~1e-6..1e-4; these reproduce the reference with its solver tightened to 1e-13 in price.
@@ -23,7 +23,7 @@ from .engine import DeviceBuffer
 ODE_RTOL, ODE_ATOL = 1e-10, 1e-12
 
 
-# Grids are pooled per (thread, class, sizes): a chain pricing took a grid's five allocations, two uploads (each with its own
+# Grids are pooled per (thread, device, class, sizes): a chain pricing took a grid's five allocations, two uploads (each with its own
 # wait) and five frees -- 58 us per chain (tools/r04/analytic_grid_probe.py) of an 0.9-1.2 ms pricing, and the whole of it
 # again at every objective evaluation of an analytic calibration, whose transform grid never changes.  acquire() hands back
 # the pooled object with its ODE state zeroed (queued memsets) and re-uploads phi / psi only when their bytes changed;
@@ -35,7 +35,7 @@ _POOL_LOCK = threading.Lock()
 class _Pooled:
     @classmethod
     def acquire(cls, *args):
-        key = (threading.get_ident(), cls.__name__) + cls._pool_key(*args)
+        key = (threading.get_ident(), _current_device(), cls.__name__) + cls._pool_key(*args)
         with _POOL_LOCK:
             obj = _POOL.pop(key, None)
             if len(_POOL) > 8:                                  # grids of threads that ended: free their HBM
