@@ -86,6 +86,23 @@ __device__ __forceinline__ void ode_rhs(const OdeConsts &c, cd phi, cd psi, cons
     }
 }
 
+// A step controller that keeps rejecting -- a coefficient system that blows up before the expiry for a parameter vector a
+// calibrator wandered into -- shrinks h by 0.2 a try; below this fraction of the interval (SciPy gives up at 10 ulp of t with
+// "required step size is less than spacing between numbers" and hands back the state it reached) the grid point is given up
+// and its state set to NaN -- the inversion drops a NaN term, as the reference's np.nansum does (utils/mgf_pricer.py:205) --
+// instead of the kernel grinding through a 10^6-try cap (seconds) and inverting whatever half-integrated state it reached.
+// The clip of the LAST step to the expiry comes after this test: a legitimately tiny final remainder never trips it.
+constexpr double ODE_STEP_FLOOR = 0x1.0p-46;               // 1.4e-14 of the interval: 20 rejections in a row from ttm / 8
+// ... and a system that is merely STIFF beyond reason (vol-of-vol of 2000 %: the explicit pair's stability bound, not its
+// accuracy, sets the step) would take its ~10^5-10^6 steps at ~4.5 us each -- 4.5 s a launch at the old 10^6 cap, after which
+// the state reached so far was inverted into finite garbage (tools/r04/analytic_blowup_probe.py).  The coefficient systems of
+// every parameter set of the test suite take under 128 tries (the suite passes with the cap there: -DSVMC_ODE_MAX_TRIES=128);
+// at 2^15 the point is given up the same way.
+#ifndef SVMC_ODE_MAX_TRIES
+#define SVMC_ODE_MAX_TRIES (1 << 15)
+#endif
+constexpr int ODE_MAX_TRIES = SVMC_ODE_MAX_TRIES;
+
 // Dormand-Prince 5(4), FSAL, mixed error scale, RMS norm -- the CPU twin's dopri5() (same tableau, same controller; the
 // error norm and the step factor are evaluated as noted below)
 __device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5], double rtol, double atol)
@@ -100,8 +117,9 @@ __device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
     double t = 0.0, h = ttm / 32.0;
     int tries = 0;
     ode_rhs(c, phi, psi, y, k1);
-    while (t < ttm && tries < 1000000) {
+    while (t < ttm && tries < ODE_MAX_TRIES) {
         ++tries;
+        if (!(h >= ODE_STEP_FLOOR * ttm)) break;          // the controller's step collapsed (or went NaN): given up below
         if (t + h > ttm) h = ttm - t;
 #pragma unroll
         for (int i = 0; i < 5; ++i) yt[i] = y[i] + h * (a21 * k1[i]);
@@ -143,8 +161,13 @@ __device__ void dopri5(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
                 k1[i] = k7[i];
             }
         }
-        const double fac = (err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0;
+        // a non-finite estimate (an overflowed trial state) is a rejection that SHRINKS the step, not the 5 x of err = 0
+        const double fac = !(err_sq < 0x1.0p+1000) ? 0.2 : ((err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0);
         h *= fmin(5.0, fmax(0.2, fac));
+    }
+    if (!(t >= ttm)) {                                      // given up (ODE_STEP_FLOOR / ODE_MAX_TRIES): no state is better than a wrong one
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y[i] = cd{__builtin_nan(""), __builtin_nan("")};
     }
 }
 
@@ -173,8 +196,9 @@ __device__ void dop853(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
         yt[i] = y[i] + h * (SVMC_D853_STAGE_##S);                                                                            \
     }                                                                                                                        \
     ode_rhs(c, phi, psi, yt, KS)
-    while (t < ttm && tries < 1000000) {
+    while (t < ttm && tries < ODE_MAX_TRIES) {
         ++tries;
+        if (!(h >= ODE_STEP_FLOOR * ttm)) break;          // the controller's step collapsed (or went NaN): given up below
         if (t + h > ttm) h = ttm - t;
         SVMC_D853_LANE_STAGE(2, K2);
         SVMC_D853_LANE_STAGE(3, K3);
@@ -224,6 +248,10 @@ __device__ void dop853(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
         h *= fac;
     }
 #undef SVMC_D853_LANE_STAGE
+    if (!(t >= ttm)) {                                      // given up (ODE_STEP_FLOOR / ODE_MAX_TRIES): no state is better than a wrong one
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y[i] = cd{__builtin_nan(""), __builtin_nan("")};
+    }
 }
 
 
@@ -274,8 +302,9 @@ __device__ void dopri5_row(const OdeLane &k, bool second, double ttm, cd &y, dou
     double t = 0.0, h = ttm / 32.0;
     int tries = 0;
     cd k1 = ode_rhs_row(k, y, second);
-    while (t < ttm && tries < 1000000) {
+    while (t < ttm && tries < ODE_MAX_TRIES) {
         ++tries;
+        if (!(h >= ODE_STEP_FLOOR * ttm)) break;          // row-uniform (h is): given up below
         if (t + h > ttm) h = ttm - t;
         const cd k2 = ode_rhs_row(k, y + h * (a21 * k1), second);
         const cd k3 = ode_rhs_row(k, y + h * (a31 * k1 + a32 * k2), second);
@@ -298,9 +327,11 @@ __device__ void dopri5_row(const OdeLane &k, bool second, double ttm, cd &y, dou
             y = yn;
             k1 = k7;
         }
-        const double fac = (err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0;
+        // a non-finite estimate (an overflowed trial state) is a rejection that SHRINKS the step, not the 5 x of err = 0
+        const double fac = !(err_sq < 0x1.0p+1000) ? 0.2 : ((err_sq > 0.0) ? 0.9 * exp_fast(0.1 * neg_log(err_sq)) : 5.0);
         h *= fmin(5.0, fmax(0.2, fac));
     }
+    if (!(t >= ttm)) y = cd{__builtin_nan(""), __builtin_nan("")};      // given up (ODE_STEP_FLOOR / ODE_MAX_TRIES); row-uniform
 }
 
 // DOP853 with one component per lane (dop853 above, the row form of dopri5_row): twelve stage derivatives, the trial states and
@@ -312,8 +343,9 @@ __device__ void dop853_row(const OdeLane &k, bool second, double ttm, cd &y, dou
     int tries = 0;
     bool rejected = false;
     cd k1 = ode_rhs_row(k, y, second);
-    while (t < ttm && tries < 1000000) {
+    while (t < ttm && tries < ODE_MAX_TRIES) {
         ++tries;
+        if (!(h >= ODE_STEP_FLOOR * ttm)) break;          // row-uniform (h is): given up below
         if (t + h > ttm) h = ttm - t;
         const cd k2 = ode_rhs_row(k, y + h * (SVMC_D853_STAGE_2), second);
         const cd k3 = ode_rhs_row(k, y + h * (SVMC_D853_STAGE_3), second);
@@ -352,6 +384,7 @@ __device__ void dop853_row(const OdeLane &k, bool second, double ttm, cd &y, dou
         }
         h *= fac;
     }
+    if (!(t >= ttm)) y = cd{__builtin_nan(""), __builtin_nan("")};      // given up (ODE_STEP_FLOOR / ODE_MAX_TRIES); row-uniform
 }
 
 

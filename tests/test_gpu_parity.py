@@ -928,6 +928,33 @@ def test_analytic_chain_ode_tolerance_knob(sv, golden):
             np.testing.assert_array_equal(np.stack(a), b)
 
 
+def test_analytic_gives_up_on_unreasonably_stiff_coefficients(sv):
+    """A parameter vector whose coefficient ODEs are stiff beyond reason (vol-of-vol of 5000 %: ~10^6 steps of the explicit
+    pair) or blow up before the expiry is GIVEN UP within a fraction of a second -- step floor / try cap of
+    csrc/svmc_analytic.hip: the grid point's log-MGF is NaN and the inversion drops it, as the reference's np.nansum does
+    (utils/mgf_pricer.py:205) -- so every price stays inside [0, max(forward, strike)]; before, the launch ran 4.5-12 s into a
+    10^6-try cap and the half-integrated state was inverted into prices of -6e4.  A sane set priced in the same launch, or
+    right after, is untouched by the episode."""
+    import time
+    kk = np.linspace(0.6, 1.4, 21)
+    ty = np.where(kk >= 1.0, "C", "P")
+    chain = sv.OptionChain(ttms=np.array([1.25, 5.0]), forwards=np.ones(2), strikes_ttms=(kk,) * 2, optiontypes_ttms=(ty,) * 2,
+                           ids=None)
+    pricer = sv.LogSVPricer()
+    sane = np.stack(pricer.price_chain(chain, sv.LOGSV_BTC_PARAMS))
+    assert np.all(np.isfinite(sane)) and np.all(sane > 0.0)
+    wild = sv.LogSvParams(sigma0=1.0, theta=1.0, kappa1=0.1, kappa2=0.1, beta=50.0, volvol=50.0)
+    t0 = time.perf_counter()
+    out = np.stack(pricer.price_chain(chain, wild))
+    seconds = time.perf_counter() - t0
+    assert seconds < 1.5, seconds
+    assert np.all((out >= 0.0) & (out <= np.maximum(1.0, kk)[None, :])), out[-1][:3]
+    batch = pricer.price_chain_batch(chain, [sv.LOGSV_BTC_PARAMS, wild])
+    np.testing.assert_array_equal(np.stack(batch[0]), sane)          # a set's neighbours in the launch do not feel it
+    np.testing.assert_array_equal(np.stack(batch[1]), out)
+    np.testing.assert_array_equal(np.stack(pricer.price_chain(chain, sv.LOGSV_BTC_PARAMS)), sane)
+
+
 def test_c5_reference_criterion_at_reference_scale(sv, golden):
     """Config C5's acceptance criterion, verbatim and at the reference's own scale: the reference accepts its analytic
     LogSV prices against Monte Carlo when |analytic - MC| <= 4 stderr on a 3-month slice (strikes 0.9 / 1.0 / 1.1,
