@@ -432,6 +432,55 @@ typedef int (*svmc_all_reduce_fn)(void *user, double *device_buf, size_t n, svmc
 SVMC_API int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn fn, void *user, int rank, int world,
                                       uint64_t n_path_total, uint64_t path_offset);
 
+/* ---- single-process multi-device sessions ----------------------------------------------------------------------
+ * The same sharding WITHOUT a process per GPU: logsv_mc_chain_pricer / heston_mc_chain_pricer (pricers/logsv_pricer.py:
+ * 806-867, pricers/heston_pricer.py:285-331 -- one single-process NumPy loop in the reference) for a caller that owns
+ * several devices from one process.  A multi-session is n_shards sessions of one job of n_path_total paths -- shard r
+ * holds the global path ids [N r / R, N (r + 1) / R) on device devices_host[r] (NULL: r mod the visible devices), each
+ * driven by its own host thread of the library -- and one svmc_multi_*_chain_price call prices the chain on all of them
+ * concurrently and returns the job's prices (every shard finalises the same all-reduced sums; svmc_multi_info's
+ * shards_agree says whether they came out bit-identical, as they must).  Arguments are those of svmc_logsv_chain_price /
+ * svmc_heston_chain_price with the multi-session in place of the session.
+ * reduce_mode picks the transport of the two sum all-reduces (utils/mc_payoffs.py:61-63, :85-86):
+ *   SVMC_MULTI_REDUCE_RCCL  ncclCommInitAll, one communicator per device, the collectives issued on each shard's stream
+ *                           (error if RCCL does not resolve or two shards share a device);
+ *   SVMC_MULTI_REDUCE_HOST  a sum through page-locked host memory in rank order, one meeting point of the shard threads
+ *                           per all-reduce -- no dependency beyond the HIP runtime, works with several shards on ONE
+ *                           device (tests/test_gpu_multi.py prices C4's 8 x 2^21 shards that way on a one-GPU box);
+ *   SVMC_MULTI_REDUCE_AUTO  RCCL where it can be had, else HOST; svmc_multi_info reports which one is in use.
+ * Results equal one session of n_path_total paths up to the order of the final additions (the randoms are indexed by the
+ * global path id) and do not depend on the transport.  A failing shard releases the others from the host meeting point
+ * and the call returns its status and message; inside an RCCL collective a lost peer cannot be recovered from (RCCL's own
+ * semantics).  Calls on one multi-session must not overlap; distinct multi-sessions are independent. */
+typedef void *svmc_multi_t;
+#define SVMC_MULTI_REDUCE_AUTO 0
+#define SVMC_MULTI_REDUCE_HOST 1
+#define SVMC_MULTI_REDUCE_RCCL 2
+SVMC_API int svmc_multi_create(svmc_multi_t *multi, int n_shards, const int *devices_host, uint64_t n_path_total,
+                               int max_expiries, size_t max_strikes_total, int reduce_mode);
+SVMC_API int svmc_multi_destroy(svmc_multi_t multi);
+/* any output may be NULL: shard count, transport in use (SVMC_MULTI_REDUCE_HOST / _RCCL), the ranks RCCL's warm-up
+ * all-reduce counted (0 in host mode), and whether all shards returned identical bits in the last pricing call */
+SVMC_API int svmc_multi_info(svmc_multi_t multi, int *n_shards, int *reduce_mode, int *rccl_ranks_seen, int *shards_agree);
+/* shard r: its device, path range and the host wall time of its part of the last call (a slow device shows here) */
+SVMC_API int svmc_multi_shard_info(svmc_multi_t multi, int shard, int *device, uint64_t *path_offset, uint64_t *n_path,
+                                   double *last_call_ms);
+SVMC_API int svmc_multi_logsv_chain_price(svmc_multi_t multi, const double *ttms_host, const double *forwards_host,
+                                          const double *discfactors_host, const double *vol_backbone_etas_host,
+                                          int n_expiries, const double *strikes_host, const int8_t *types_host,
+                                          const size_t *strike_offsets_host, double v0, double theta, double kappa1,
+                                          double kappa2, double beta, double volvol, int is_spot_measure,
+                                          int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
+                                          double *prices_host, double *stderrs_host);
+SVMC_API int svmc_multi_heston_chain_price(svmc_multi_t multi, const double *ttms_host, const double *forwards_host,
+                                           const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                           const int8_t *types_host, const size_t *strike_offsets_host, double v0,
+                                           double theta, double kappa, double rho, double volvol, int scheme,
+                                           int nb_steps_per_year, int variable_type, uint64_t seed, uint32_t call_id,
+                                           double *prices_host, double *stderrs_host);
+/* the terminal state of the whole job, shard by shard into [n_path_total] host arrays (any pointer may be NULL) */
+SVMC_API int svmc_multi_state(svmc_multi_t multi, double *x_host, double *vol_host, double *qvar_host);
+
 /* ---- analytic side: affine-expansion MGF + Fourier inversion ------------------
  * Complex arrays are interleaved (re, im) doubles, i.e. numpy.complex128 / C99 double complex, on the device.
  *   svmc_logsv_mgf_grid    compute_logsv_a_mgf_grid, pricers/logsv/affine_expansion.py:570-685 (numerical path):

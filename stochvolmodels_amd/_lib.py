@@ -128,10 +128,19 @@ def _declare(L: C.CDLL) -> None:
         "svmc_rccl_all_reduce_sum": ([vp, vp, sz, vp], i32),
         "svmc_session_set_comm": ([vp, vp, i32, i32, u64, u64], i32),
         "svmc_session_set_reducer": ([vp, ALL_REDUCE_FN, vp, i32, i32, u64, u64], i32),
+        "svmc_multi_create": ([pvp, i32, pi32, u64, i32, sz, i32], i32),
+        "svmc_multi_destroy": ([vp], i32),
+        "svmc_multi_info": ([vp, pi32, pi32, pi32, pi32], i32),
+        "svmc_multi_shard_info": ([vp, i32, pi32, C.POINTER(u64), C.POINTER(u64), pf64], i32),
+        "svmc_multi_logsv_chain_price": ([vp, pf64, pf64, pf64, pf64, i32, pf64, pi8, psz, f64, f64, f64, f64, f64, f64, i32,
+                                          i32, i32, u64, u32, pf64, pf64], i32),
+        "svmc_multi_heston_chain_price": ([vp, pf64, pf64, pf64, i32, pf64, pi8, psz, f64, f64, f64, f64, f64, i32, i32, i32,
+                                           u64, u32, pf64, pf64], i32),
+        "svmc_multi_state": ([vp, pf64, pf64, pf64], i32),
     }
     for name, (argtypes, restype) in sig.items():
-        if os.environ.get("SVMC_LIB") and not hasattr(L, name):
-            continue                   # an A/B build of an OLDER ABI (tools/ubench): its newer entry points are simply absent
+        if os.environ.get("SVMC_ALLOW_OLD_ABI") == "1" and not hasattr(L, name):
+            continue                   # an A/B build of an OLDER ABI (tools/ubench sets this): its newer entry points are absent
         fn = getattr(L, name)          # AttributeError here = the .so does not match include/svmc.h
         fn.argtypes = argtypes
         fn.restype = restype

@@ -25,7 +25,7 @@ LIB = os.path.join(PKG, "libsvmc.so")
 # line stale when the library it loaded is not the one the histogram describes
 ISA_JSON = os.path.join(PKG, "libsvmc.isa.json")
 ISA_KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "heston_rng_kernelILi0", "heston_rng_kernelILi1")
-SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip", "svmc_comm.hip")
+SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip", "svmc_comm.hip", "svmc_multi.hip")
 HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h", "svmc_log_table.h", "svmc_icdf_table.h", "svmc_black.h", "svmc_ode.h", "svmc_dop853.h")
 ARCH = "gfx950"
 

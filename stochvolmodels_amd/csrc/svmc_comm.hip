@@ -40,6 +40,7 @@ struct RcclApi {
     const char *(*error_string)(ncclResult_t) = nullptr;
     ncclResult_t (*comm_count)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*comm_user_rank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*comm_init_all)(ncclComm_t *, int, const int *) = nullptr;      // optional: single-process multi-device
     std::string origin, error;
     bool ok = false;
 };
@@ -75,6 +76,7 @@ static RcclApi &rccl()
         api.error_string = reinterpret_cast<decltype(api.error_string)>(sym("ncclGetErrorString"));
         api.comm_count = reinterpret_cast<decltype(api.comm_count)>(sym("ncclCommCount"));
         api.comm_user_rank = reinterpret_cast<decltype(api.comm_user_rank)>(sym("ncclCommUserRank"));
+        api.comm_init_all = reinterpret_cast<decltype(api.comm_init_all)>(sym("ncclCommInitAll"));
         api.ok = api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_reduce && api.error_string;
         if (!api.ok) api.error = "RCCL (" + api.origin + ") lacks a required symbol";
     });
@@ -84,6 +86,18 @@ static RcclApi &rccl()
 static int rccl_fail(const char *what, ncclResult_t r)
 {
     return fail(SVMC_ERR_RCCL, std::string(what) + ": " + (rccl().error_string ? rccl().error_string(r) : "RCCL error"));
+}
+
+// one communicator per device of ONE process (ncclCommInitAll): the transport of a multi-session (svmc_multi.hip) whose
+// shards sit on distinct devices; each communicator is then driven by its shard's own host thread
+int rccl_comm_init_all(int n, const int *devices, void **comms_out)
+{
+    if (!rccl().ok) return fail(SVMC_ERR_RCCL, rccl().error);
+    if (rccl().comm_init_all == nullptr) return fail(SVMC_ERR_RCCL, "RCCL (" + rccl().origin + ") lacks ncclCommInitAll");
+    static_assert(sizeof(ncclComm_t) == sizeof(void *), "ncclComm_t is a pointer");
+    const ncclResult_t r = rccl().comm_init_all(reinterpret_cast<ncclComm_t *>(comms_out), n, devices);
+    if (r != ncclSuccess) return rccl_fail("ncclCommInitAll", r);
+    return SVMC_OK;
 }
 
 }  // namespace svmc

@@ -50,6 +50,8 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
 constexpr int IV_QUOTE_DOUBLES_HOST = 6;   // = IV_QUOTE_DOUBLES of svmc_kernels.hip: {strike, code, shift, forward, ttm, df}
 int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,
                        double vol_hi, double *ivols_dev, hipStream_t stream);
+// svmc_comm.hip: ncclCommInitAll -- comms_out[n] communicators for the devices[n] of this process (svmc_multi.hip)
+int rccl_comm_init_all(int n, const int *devices, void **comms_out);
 void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
                              int is_spot_measure, double *out);
 

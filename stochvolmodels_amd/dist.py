@@ -50,7 +50,6 @@ class TorchComm:
         self._torch, self._dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._bufs = {}
 
     def _device(self, engine):
         kind = getattr(engine, "torch_device", None)
@@ -61,13 +60,17 @@ class TorchComm:
     def alloc(self, engine, n_doubles: int, tag: str):
         # one persistent tensor per (engine, tag), zero-initialised; the HANDLE is the live prefix t[:n_doubles], so
         # the collective reduces exactly the doubles this chain wrote -- every rank calls with the same n_doubles
-        # (it is a function of the chain alone), whatever chains each rank priced before
-        key = (id(engine), tag)
+        # (it is a function of the chain alone), whatever chains each rank priced before.  The tensors live ON the engine
+        # object (not in a table keyed by id(engine): a closed engine's id can come back as a new engine on another device,
+        # and the cached tensor would then sit on the wrong GPU), keyed by this communicator, the tag and the device
+        device = self._device(engine)
+        bufs = engine.__dict__.setdefault("_comm_bufs", {})
+        key = (id(self), tag, str(device))
         n = max(int(n_doubles), 1)
-        t = self._bufs.get(key)
+        t = bufs.get(key)
         if t is None or t.numel() < n:
-            t = self._torch.zeros(n, dtype=self._torch.float64, device=self._device(engine))
-            self._bufs[key] = t
+            t = self._torch.zeros(n, dtype=self._torch.float64, device=device)
+            bufs[key] = t
         return t.data_ptr(), t.narrow(0, 0, n)
 
     def _stream_ordered(self, engine, handle) -> bool:

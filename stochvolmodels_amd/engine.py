@@ -455,6 +455,7 @@ class HipEngine:
         """free every HBM buffer of the engine; any later launch through it fails in the C ABI's null-pointer
         checks (SvmcError), it never touches freed memory"""
         self.closed = True
+        self.__dict__.pop("_comm_bufs", None)       # a communicator's reduction tensors that lived on this engine (dist.TorchComm)
         for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values()):
             if b is not None:
                 b.free()

@@ -72,7 +72,8 @@ class HestonPricer(ModelPricer):
                                       optiontypes_ttms=option_chain.optiontypes_ttms, nb_path=nb_path,
                                       variable_type=variable_type, scheme=kwargs.get("scheme", "euler"),
                                       nb_steps_per_year=kwargs.get("nb_steps_per_year", 360),
-                                      seed=kwargs.get("seed"), comm=kwargs.get("comm"))
+                                      seed=kwargs.get("seed"), comm=kwargs.get("comm"), devices=kwargs.get("devices"),
+                                      reduce=kwargs.get("reduce"))
 
     @timer
     def calibrate_model_params_to_chain(self, option_chain: OptionChain, params0: HestonParams = None,
@@ -201,11 +202,21 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
                            strikes_ttms: Sequence[np.ndarray], optiontypes_ttms: Sequence[np.ndarray], v0: float,
                            theta: float, kappa: float, rho: float, volvol: float, nb_path: int = 100000,
                            variable_type: VariableType = VariableType.LOG_RETURN, scheme="euler",
-                           nb_steps_per_year: int = 360, seed: Optional[int] = None, comm=None
-                           ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-    """chain MC (reference :285-331): state carried slice to slice, 360 steps/yr unless overridden."""
-    variable_type_code(variable_type)
+                           nb_steps_per_year: int = 360, seed: Optional[int] = None, comm=None, devices=None,
+                           reduce: Optional[str] = None) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """chain MC (reference :285-331): state carried slice to slice, 360 steps/yr unless overridden.
+    devices=N | [ids]: the paths sharded over that many GPUs of this process (stochvolmodels_amd.multi), as for
+    logsv_mc_chain_pricer."""
+    vt_code = variable_type_code(variable_type)
     code = _scheme_code(scheme)
+    if devices is not None:
+        if comm is not None:
+            raise ValueError("devices= (one process, several GPUs) and comm= (one process per GPU) are exclusive")
+        from ..multi import get_multi_session
+        rng_seed, call_id = next_rng_call(seed)
+        ms = get_multi_session(devices, nb_path, len(ttms), sum(int(np.asarray(k).size) for k in strikes_ttms), reduce=reduce)
+        return ms.price_heston_chain(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, v0, theta, kappa, rho, volvol,
+                                     code, nb_steps_per_year, vt_code, rng_seed, call_id)
     comm = comm or svdist.get_default_comm()
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)

@@ -215,7 +215,8 @@ class LogSVPricer(ModelPricer):
                                      optiontypes_ttms=option_chain.optiontypes_ttms, is_spot_measure=is_spot_measure,
                                      variable_type=variable_type, nb_path=nb_path,
                                      nb_steps_per_year=nb_steps or int(360 * np.max(option_chain.ttms)) + 1,
-                                     seed=kwargs.get("seed"), comm=kwargs.get("comm"))
+                                     seed=kwargs.get("seed"), comm=kwargs.get("comm"), devices=kwargs.get("devices"),
+                                     reduce=kwargs.get("reduce"))
 
     def set_vol_scaler(self, option_chain: OptionChain) -> float:
         """transform-grid scaler from the chain's first ATM vol, held fixed over a calibration (reference :429-438)"""
@@ -483,9 +484,22 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
                           theta: float, kappa1: float, kappa2: float, beta: float, volvol: float,
                           vol_backbone_etas: np.ndarray, is_spot_measure: bool = True, nb_path: int = 100000,
                           nb_steps_per_year: int = 360, variable_type: VariableType = VariableType.LOG_RETURN,
-                          seed: Optional[int] = None, comm=None) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-    """chain MC with on-device randoms (reference :806-867): per slice nb_steps_i = int((T_i - T_{i-1})*spy) + 1."""
-    variable_type_code(variable_type)
+                          seed: Optional[int] = None, comm=None, devices=None, reduce: Optional[str] = None
+                          ) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """chain MC with on-device randoms (reference :806-867): per slice nb_steps_i = int((T_i - T_{i-1})*spy) + 1.
+    devices=N | [ids]: shard the paths over that many GPUs of THIS process (stochvolmodels_amd.multi: one session and one
+    host thread per device inside libsvmc; reduce='auto' | 'host' | 'rccl' picks the all-reduce transport) -- the same
+    numbers as one device up to the order of the final additions."""
+    vt_code = variable_type_code(variable_type)
+    if devices is not None:
+        if comm is not None:
+            raise ValueError("devices= (one process, several GPUs) and comm= (one process per GPU) are exclusive")
+        from ..multi import get_multi_session
+        rng_seed, call_id = next_rng_call(seed)
+        ms = get_multi_session(devices, nb_path, len(ttms), sum(int(np.asarray(k).size) for k in strikes_ttms), reduce=reduce)
+        return ms.price_logsv_chain(ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms, v0, theta, kappa1, kappa2,
+                                    beta, volvol, vol_backbone_etas, is_spot_measure, nb_steps_per_year, vt_code, rng_seed,
+                                    call_id)
     comm = comm or svdist.get_default_comm()
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)

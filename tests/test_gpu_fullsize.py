@@ -125,29 +125,40 @@ def _c4_chain(m=8):
 
 
 def _logsv_chain_gpu_vs_cpu(sv, cpu, tag, p, n, ttms, fw, dfs, strikes, types, seed, spy=1016, is_spot_measure=True,
-                            variable_type=None, etas=None, price_floor=None):
-    """one LogSV chain on the GPU (product entry point) and slice by slice on the oracle, same stream"""
+                            variable_type=None, etas=None, price_floor=None, rank=0, world=1):
+    """one LogSV chain on the GPU (product entry point) and slice by slice on the oracle, same stream.  world > 1: the n
+    paths are RANK `rank`'s share of a job of n x world paths -- global path ids rank n .. (rank + 1) n - 1 -- priced through
+    the product's sharded route with the cross-rank sums left out (a communicator that reduces nothing), so the prices are
+    that share's own: what rank `rank` contributes, checked path by path and sum by sum against the oracle at that offset"""
+    from stochvolmodels_amd import dist as svdist
     from stochvolmodels_amd.engine import get_engine
     m = len(ttms)
     etas = np.ones(m) if etas is None else etas
     vt = sv.VariableType.LOG_RETURN if variable_type is None else variable_type
+    comm = None
+    if world > 1:
+        comm = svdist.SingleComm()
+        comm.rank, comm.world = rank, world
+        assert svdist.shard_range(n * world, rank, world) == (rank * n, n)
     pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=dfs, strikes_ttms=strikes,
                                       optiontypes_ttms=types, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
                                       kappa2=p.kappa2, beta=p.beta, volvol=p.volvol, vol_backbone_etas=etas,
-                                      is_spot_measure=is_spot_measure, nb_path=n, nb_steps_per_year=spy, seed=seed,
-                                      variable_type=vt)
+                                      is_spot_measure=is_spot_measure, nb_path=n * world, nb_steps_per_year=spy, seed=seed,
+                                      variable_type=vt, comm=comm)
+    sd = [e * np.sqrt(world) for e in sd]          # the job's standard error divides by sqrt(n world); the share's own by sqrt(n)
     x, s, q = np.zeros(n), p.sigma0 * np.ones(n), np.zeros(n)
     opr, osd, t0, step0 = [], [], 0.0, 0
     for i, ttm in enumerate(ttms):
         nb, dt, _ = sv.set_time_grid(ttm - t0, spy)
         assert nb == 128
         x, s, q = cpu.logsv_terminal_rng(x, s, q, nb, dt, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, seed,
-                                         eta=float(etas[i]), is_spot_measure=is_spot_measure, step_offset=step0)
+                                         eta=float(etas[i]), is_spot_measure=is_spot_measure, step_offset=step0,
+                                         path_offset=rank * n)
         a, b = cpu.payoff(x, q, float(ttm), float(fw[i]), strikes[i], types[i], float(dfs[i]), variable_type=int(vt.value))
         opr.append(a), osd.append(b)
         t0, step0 = ttm, step0 + nb
     floor = price_floor if price_floor is not None else 1e-3 * float(fw[0])
-    _check(tag, get_engine(n).get_state(), (x, s, q), pr, sd, opr, osd, price_floor=floor)
+    _check(tag, get_engine(n, path_offset=rank * n).get_state(), (x, s, q), pr, sd, opr, osd, price_floor=floor)
     return pr, sd
 
 
@@ -156,6 +167,19 @@ def test_c4_rank_share_full_size_same_stream(sv, cpu):
     strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
     types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
     _logsv_chain_gpu_vs_cpu(sv, cpu, "C4 share", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types, 20240604)
+
+
+@pytest.mark.parametrize("rank", [7, 3])
+def test_c4_last_ranks_share_full_size_same_stream(sv, cpu, rank):
+    """C4 as rank 7 (and rank 3) of the 8-GPU job sees it: 2^21 paths at path offset rank x 2^21 of the 2^24 -- the shares
+    the one-GPU suite never ran before round 5 (every other full-size case is rank 0's share, offset 0): the counter's
+    path words beyond 2^21, the engine's path_offset plumbing and the whole-chain kernel at a non-zero offset, against the
+    oracle at the same offset"""
+    ttms, fw, dfs = _c4_chain()
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    _logsv_chain_gpu_vs_cpu(sv, cpu, f"C4 share of rank {rank}", sv.LOGSV_BTC_PARAMS, 1 << 21, ttms, fw, dfs, strikes, types,
+                            20240604, rank=rank, world=8)
 
 
 def test_c4_rank_share_inverse_options(sv, cpu):
@@ -254,3 +278,15 @@ def test_c5_monte_carlo_leg_rank_share(sv, cpu, golden, tag):
     np.testing.assert_allclose(an, g[f"{tag}_analytic"], rtol=0, atol=2e-6 * float(fw[0]))
     np.testing.assert_array_equal(verdict, g[f"{tag}_pass"], err_msg=f"C5 {tag}: the GPU's accept / reject map differs from the "
                                   "reference's")
+
+
+@pytest.mark.parametrize("tag", ["btc", "test"])
+def test_c5_monte_carlo_leg_at_the_stated_2e23_paths_on_one_gpu(sv, cpu, tag):
+    """C5's Monte Carlo leg at the path count SURVEY.md 8d states -- 2^23 paths on ONE device, not a rank's 2^20 share (it
+    fits: 2^23 x 11 state / snapshot rows = 740 MB) -- for the BTC set and the stiff kappa2 = 12 set, GPU vs the oracle on the
+    same stream, path by path and option by option"""
+    p = sv.LOGSV_BTC_PARAMS if C5_SETS[tag] is None else sv.LogSvParams(**C5_SETS[tag])
+    ttms, fw, dfs = _c4_chain(4)
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, fw))
+    _logsv_chain_gpu_vs_cpu(sv, cpu, f"C5 {tag} 2^23", p, 1 << 23, ttms, fw, dfs, strikes, types, 20240611)
