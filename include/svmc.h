@@ -376,6 +376,25 @@ SVMC_API int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const dou
                                                const double *const *W0s, const double *const *W1s,
                                                const int *nb_steps_host, const double *dts_host, size_t ldw,
                                                double *prices_host, double *stderrs_host, double *ivols_host);
+/* The calibration chain with NO resident randoms: the fixed randoms of an MC calibration (pricers/logsv_pricer.py:244-265,
+ * :520-527 draw them once and re-price on them at every optimizer iterate) are the counter-based stream of (seed, call_id),
+ * regenerated in registers by every evaluation -- the same draws every time, nothing in HBM (10^5 paths x 364 steps of
+ * resident W0 / W1 are 582 MB, and streaming them back is the floor of svmc_logsv_chain_price_fixed*).  n_sets parameter
+ * sets (params_host [n_sets][6 + n_expiries] as for svmc_logsv_chain_price_fixed_sets) are stepped by ONE launch per 8 sets,
+ * every lane drawing its path's normals once per step and advancing all the sets on them; outputs [n_sets][sum K_i].
+ * Set q's prices are those of svmc_logsv_chain_price(seed, call_id) with set q's parameters on the grid (nb_steps_host,
+ * dts_host), BIT FOR BIT (the same step arithmetic; tests/test_gpu_parity.py).  The session must be created for n_sets
+ * chains (svmc_session_create(.., max_expiries >= min(n_sets, 8) x n_expiries, max_strikes_total >= min(n_sets, 8) x
+ * sum K_i)).  The launches are captured into one hipGraph per set count and replayed; with a communicator attached
+ * they are issued directly, the two all-reduces between them (global path ids: the job's result does not depend on the
+ * sharding).  ivols_host may be NULL. */
+SVMC_API int svmc_logsv_chain_price_frozen_sets(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                                const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                                const int8_t *types_host, const size_t *strike_offsets_host, int n_sets,
+                                                const double *params_host, int is_spot_measure, int variable_type,
+                                                const int *nb_steps_host, const double *dts_host, uint64_t seed,
+                                                uint32_t call_id, double *prices_host, double *stderrs_host,
+                                                double *ivols_host);
 /* svmc_logsv_chain_price_fixed captures its launches (ONE stepping launch for all expiries that also initialises the
  * state and writes the spot sums' partials, their reduce, the payoff sums, D2H; a launch per expiry beyond 16 expiries)
  * into a hipGraph the first time it sees a (chain, randoms) combination and replays it afterwards -- the model

@@ -113,6 +113,8 @@ def _declare(L: C.CDLL) -> None:
                                             i32),
         "svmc_logsv_chain_price_fixed_sets": ([vp, pf64, pf64, pf64, i32, pf64, pi8, psz, i32, pf64, i32, i32, C.POINTER(vp),
                                                C.POINTER(vp), C.POINTER(i32), pf64, sz, pf64, pf64, pf64], i32),
+        "svmc_logsv_chain_price_frozen_sets": ([vp, pf64, pf64, pf64, i32, pf64, pi8, psz, i32, pf64, i32, i32, C.POINTER(i32),
+                                                pf64, u64, u32, pf64, pf64, pf64], i32),
         "svmc_session_use_graphs": ([vp, i32], i32),
         "svmc_session_graph_launches": ([vp, psz], i32),
         "svmc_heston_chain_price": ([vp, pf64, pf64, pf64, i32, pf64, pi8, psz, f64, f64, f64, f64, f64, i32, i32, i32,

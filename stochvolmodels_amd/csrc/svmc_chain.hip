@@ -48,6 +48,8 @@ struct Session {
     size_t graph_launches = 0;
     FixedGraph fixed;
     FixedGraph fixed_sets;                  // svmc_logsv_chain_price_fixed_sets: several parameter sets per replay
+    FixedGraph frozen[MAX_FUSED_SETS + 1];  // svmc_logsv_chain_price_frozen_sets: one captured chain per set count (an SLSQP
+                                            // iterate alternates between its base point, 1 set, and its bumped neighbours)
     size_t n_path = 0;
     int max_expiries = 0;
     size_t max_strikes = 0;
@@ -77,6 +79,7 @@ static void session_release(Session *s)
     if (s == nullptr) return;
     fixed_graph_release(s->fixed);
     fixed_graph_release(s->fixed_sets);
+    for (FixedGraph &g : s->frozen) fixed_graph_release(g);
     for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar),
                     static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
         if (p != nullptr) (void)hipFree(p);
@@ -621,6 +624,160 @@ int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms
     SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
     ++s->graph_launches;
     const double n_all = static_cast<double>(s->n_path);
+    for (int q = 0; q < P; ++q)
+        for (int i = 0; i < c.m; ++i) {
+            const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;
+            if (int rc = svmc_payoff_finalize(g.sums_host + 3 * (K * q + k0), shifts.data() + k0, k, c.discfactors[i], n_all,
+                                              prices_host + K * q + k0, stderrs_host + K * q + k0))
+                return rc;
+        }
+    if (ivols_host != nullptr) {
+        if (g.ivols_host != nullptr) {
+            memcpy(ivols_host, g.ivols_host, K * P * sizeof(double));
+        } else {
+            for (int q = 0; q < P; ++q) implied_vols_on_host(c, variable_type, prices_host + K * q, ivols_host + K * q);
+        }
+    }
+    return SVMC_OK;
+}
+
+int svmc_logsv_chain_price_frozen_sets(svmc_session_t session, const double *ttms_host, const double *forwards_host,
+                                       const double *discfactors_host, int n_expiries, const double *strikes_host,
+                                       const int8_t *types_host, const size_t *strike_offsets_host, int n_sets,
+                                       const double *params_host, int is_spot_measure, int variable_type,
+                                       const int *nb_steps_host, const double *dts_host, uint64_t seed, uint32_t call_id,
+                                       double *prices_host, double *stderrs_host, double *ivols_host)
+{
+    const char *fn = "svmc_logsv_chain_price_frozen_sets";
+    Session *s = reinterpret_cast<Session *>(session);
+    const ChainView c = {n_expiries, ttms_host, forwards_host, discfactors_host, strikes_host, types_host, strike_offsets_host};
+    if (int rc = check_chain(fn, s, c, variable_type, prices_host, stderrs_host)) return rc;
+    SVMC_REQUIRE(nb_steps_host && dts_host && params_host, std::string(fn) + ": null grids / parameters");
+    SVMC_REQUIRE(n_sets >= 1, std::string(fn) + ": n_sets must be positive");
+    SVMC_REQUIRE(call_id < (1u << 24), std::string(fn) + ": call_id must fit 24 bits");
+    const size_t K = c.offsets[c.m], row = 6 + static_cast<size_t>(c.m);          // doubles per parameter set
+    for (int i = 0; i < c.m; ++i)
+        SVMC_REQUIRE(dts_host[i] > 0.0 && nb_steps_host[i] > 0, std::string(fn) + ": dt and nb_steps must be positive");
+    if (n_sets > MAX_FUSED_SETS) {              // more sets than a launch takes: in launches of MAX_FUSED_SETS
+        for (int q = 0; q < n_sets; q += MAX_FUSED_SETS) {
+            const int P = (n_sets - q < MAX_FUSED_SETS) ? n_sets - q : MAX_FUSED_SETS;
+            if (int rc = svmc_logsv_chain_price_frozen_sets(session, ttms_host, forwards_host, discfactors_host, n_expiries,
+                                                            strikes_host, types_host, strike_offsets_host, P, params_host + row * q,
+                                                            is_spot_measure, variable_type, nb_steps_host, dts_host, seed, call_id,
+                                                            prices_host + K * q, stderrs_host + K * q,
+                                                            ivols_host ? ivols_host + K * q : nullptr))
+                return rc;
+        }
+        return SVMC_OK;
+    }
+    const int P = n_sets;
+    SVMC_REQUIRE(c.m <= MAX_FUSED_SLICES, std::string(fn) + ": at most 16 expiries");
+    SVMC_REQUIRE(c.m * P <= s->max_expiries && K * static_cast<size_t>(P) <= s->max_strikes &&
+                     static_cast<size_t>(wave_rows(s->n_path)) * 2 * static_cast<size_t>(c.m) * P * sizeof(double) <= s->ws_bytes,
+                 std::string(fn) + ": the session must be created for n_sets chains (max_expiries >= n_sets x n_expiries, "
+                                   "max_strikes_total >= n_sets x sum K_i)");
+    const size_t n = s->n_path;
+    const bool graph = s->use_graphs && !s->sharded();
+    const int want_iv = (ivols_host != nullptr && variable_type == SVMC_LOG_RETURN) ? 1 : 0;
+    // everything that shapes the launches; the model constants travel in the parameter block
+    std::vector<unsigned char> key;
+    const int sharded = s->sharded() ? 1 : 0;
+    key_append(key, &c.m, 1);
+    key_append(key, &P, 1);
+    key_append(key, &variable_type, 1);
+    key_append(key, &want_iv, 1);
+    key_append(key, &sharded, 1);
+    key_append(key, &seed, 1);
+    key_append(key, &call_id, 1);
+    key_append(key, &s->path_offset, 1);
+    key_append(key, c.ttms, c.m);
+    key_append(key, c.discfactors, want_iv ? c.m : 0);
+    key_append(key, c.forwards, c.m);
+    key_append(key, c.offsets, c.m + 1);
+    key_append(key, c.strikes, K);
+    key_append(key, c.types, K);
+    key_append(key, nb_steps_host, c.m);
+    FixedGraph &g = s->frozen[P];
+    // parameter block: [P] initial volatilities, then [m][P] LogsvFast (log units)
+    const size_t n_params = static_cast<size_t>(P) + static_cast<size_t>(c.m) * P * LOGSV_FAST_CONSTS_DOUBLES, n_sums = 3 * K * P;
+    const size_t n_quotes = K * P;
+    const double n_all = static_cast<double>(s->sharded() ? s->n_total : s->n_path);
+    std::vector<double> shifts(K);
+    for (int i = 0; i < c.m; ++i)
+        for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k)
+            shifts[k] = payoff_shift(c.strikes[k], c.types[k], c.forwards[i], variable_type);
+    // the chain's launches, queued on the session's stream: captured into the graph, or issued as they are (a communicator
+    // attached, graphs off) with the two all-reduces between them
+    auto enqueue = [&]() -> int {
+        SVMC_HIP_TRY(hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        double *qsnaps = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * P * n : nullptr;
+        if (int rc = logsv_chain_rng_sets(n, P, c.m, nb_steps_host, g.params_dev + P, g.params_dev, c.forwards, seed, call_id,
+                                          s->path_offset, s->snap, qsnaps, s->spot, s->ws, s->ws_bytes, s->stream))
+            return rc;
+        if (int rc = all_reduce(s, s->spot, 2 * static_cast<size_t>(c.m) * P)) return rc;
+        for (int q = 0; q < P; ++q)
+            if (int rc = enqueue_payoff_sums_of_set(s, c, variable_type, shifts, q, P)) return rc;
+        if (int rc = all_reduce(s, s->sums, n_sums)) return rc;
+        if (n_sums) SVMC_HIP_TRY(hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        if (g.ivols_dev != nullptr) {
+            if (int rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, n_all, IV_VOL_LO, IV_VOL_HI, g.ivols_dev, s->stream))
+                return rc;
+            SVMC_HIP_TRY(hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        }
+        return SVMC_OK;
+    };
+    if (g.params_dev == nullptr || g.key != key) {
+        fixed_graph_release(g);
+        g.params_doubles = n_params;
+        g.sums_doubles = n_sums;
+        SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.params_host), n_params * sizeof(double), hipHostMallocDefault));
+        SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.sums_host), (n_sums ? n_sums : 1) * sizeof(double), hipHostMallocDefault));
+        SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.params_dev), n_params * sizeof(double)));
+        if (want_iv && n_quotes) {
+            std::vector<double> quotes(IV_QUOTE_DOUBLES_HOST * n_quotes);
+            for (int q = 0; q < P; ++q)
+                for (int i = 0; i < c.m; ++i)
+                    for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k) {
+                        double *qd = quotes.data() + IV_QUOTE_DOUBLES_HOST * (K * q + k);
+                        qd[0] = c.strikes[k];
+                        qd[1] = static_cast<double>(c.types[k]);
+                        qd[2] = shifts[k];
+                        qd[3] = c.forwards[i];
+                        qd[4] = c.ttms[i];
+                        qd[5] = c.discfactors[i];
+                    }
+            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.quotes_dev), quotes.size() * sizeof(double)));
+            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.ivols_dev), n_quotes * sizeof(double)));
+            SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.ivols_host), n_quotes * sizeof(double), hipHostMallocDefault));
+            SVMC_HIP_TRY(hipMemcpy(g.quotes_dev, quotes.data(), quotes.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (graph) {
+            SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+            const int rc = enqueue();
+            const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
+            if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
+            if (e_end != hipSuccess) {
+                fixed_graph_release(g);
+                return fail(SVMC_ERR_HIP, std::string(fn) + ": graph capture: " + hipGetErrorString(e_end));
+            }
+            SVMC_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        }
+        g.key = key;
+    }
+    for (int q = 0; q < P; ++q) {
+        const double *pr = params_host + row * q;
+        g.params_host[q] = pr[0];
+        for (int i = 0; i < c.m; ++i)
+            logsv_fast_to_doubles(dts_host[i], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6 + i], is_spot_measure,
+                                  g.params_host + P + (static_cast<size_t>(i) * P + q) * LOGSV_FAST_CONSTS_DOUBLES);
+    }
+    if (graph) {
+        SVMC_HIP_TRY(hipGraphLaunch(g.exec, s->stream));
+        ++s->graph_launches;
+    } else if (int rc = enqueue()) {
+        return rc;
+    }
+    SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
     for (int q = 0; q < P; ++q)
         for (int i = 0; i < c.m; ++i) {
             const size_t k0 = c.offsets[i], k = c.offsets[i + 1] - k0;

@@ -617,6 +617,94 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_w_sets_kernel(size_t n, Cha
     }
 }
 
+// The calibration chain WITHOUT resident randoms: P parameter sets stepped on randoms that are REGENERATED in registers
+// from (seed, call_id) on every evaluation.  A counter-based stream is already "frozen by its seed": the fixed randoms of
+// an MC calibration (pricers/logsv_pricer.py:244-265, :520-527 draw them once with RandomState and keep the arrays) need
+// not exist anywhere -- the round-4 route drew 582 MB into HBM for 10^5 x 364 and streamed them back at every objective
+// evaluation (5.3 TB/s, the kernel's floor).  Here a lane draws its path's normals once per step (one Philox call per
+// two steps, the inversion per word: 28 of the single-set generator's 49 instructions per step) and advances ALL P states
+// on them; the P chains of a lane are independent, so their exp-table round trips overlap and one wave per SIMD -- what a
+// calibration-sized path set gives this chip -- keeps its SIMD busy.  No HBM term inside the time loop at all.
+// Per set the arithmetic is logsv_chain_rng_kernel's, statement for statement (logsv_step_acc on the constants in log
+// units, L re-derived with log_state at every slice start, logsv_fold_acc, slice_epilogue): set q of the launch is
+// logsv_mc_chain_pricer(seed, call_id) with set q's parameters, bit for bit.  The constants of the (slice, set) pairs sit
+// in LDS and are re-read at every trip (as logsv_chain_w_sets_kernel: 5 P doubles would not fit the scalar registers and
+// in vector registers they would be spilled); x and qvar stay in registers (they are dead inside the loop, but a
+// calibration-sized launch runs one or two waves per SIMD: there are registers to spare).
+// consts: [m][P] LogsvFast in log units, init: [P] initial volatilities; snapshot rows and partial column pairs set-major.
+struct ChainRngSetsSlices {
+    double forward[MAX_CHAIN_SLICES];
+    int nb_steps[MAX_CHAIN_SLICES];
+    int m;
+};
+constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(double));
+
+template <int P>
+__global__ __launch_bounds__(BLOCK) void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs,
+                                                                     const LogsvFast *__restrict__ consts,
+                                                                     const double *__restrict__ init, uint64_t seed, uint32_t c3,
+                                                                     uint64_t path_offset, uint32_t step_offset,
+                                                                     double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                     double *__restrict__ partials)
+{
+    __shared__ RngTablesLds s_tab;
+    __shared__ double s_exp[256];
+    __shared__ LogsvFast s_c[P];
+    const RngTables tab = stage_tables(s_tab, s_exp);
+    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    const bool active = p < n;
+    double xv[P], sg[P], q[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        xv[s] = 0.0;
+        sg[s] = init[s];
+        q[s] = 0.0;
+    }
+    // every lane steps (the lanes past the last path on a real path's counter: their results are never stored)
+    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
+    uint32_t tg = step_offset;
+    for (int i = 0; i < cs.m; ++i) {
+        __syncthreads();                                   // everybody is done with the previous slice's constants
+        {
+            constexpr int ND = P * LOGSV_FAST_DOUBLES;
+            const double *src = reinterpret_cast<const double *>(consts + static_cast<size_t>(i) * P);
+            double *dst = reinterpret_cast<double *>(s_c);
+            for (int j = threadIdx.x; j < ND; j += BLOCK) dst[j] = src[j];
+        }
+        __syncthreads();
+        const int nb = cs.nb_steps[i];
+        double L[P], acc[P], xacc[P], s2_start[P];
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            L[s] = log_state(sg[s]) * LOG_UNITS_PER_NAT;                                              // :1039
+            s2_start[s] = square_rn(sg[s]);
+            acc[s] = 0.0;
+            xacc[s] = 0.0;
+        }
+        rng_time_loop(lane, tg, nb, tab, [&](double z0, double z1) {
+            unsigned zero = 0;                             // opaque: the constants are re-read from LDS, not hoisted
+            asm volatile("" : "+v"(zero));
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const LogsvFast &c = s_c[s + zero];
+                double s2_unused = 0.0;
+                logsv_step_acc(c, xacc[s], L[s], sg[s], s2_unused, acc[s], z0, z1, exp_of);
+            }
+        });
+        tg += static_cast<uint32_t>(nb);
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const LogsvFast c = s_c[s];
+            logsv_fold_acc(c, xv[s], q[s], xacc[s], acc[s], s2_start[s], square_rn(sg[s]));
+            const int row = s * cs.m + i;
+            const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
+                                 partials + 2 * static_cast<size_t>(row) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
+            slice_epilogue(so, p, active, xv[s], q[s]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__restrict__ x, double *__restrict__ vol,
                                                                     double *__restrict__ qvar, size_t n,
                                                                     const double *__restrict__ vol0)
@@ -1660,6 +1748,65 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
                        wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
+}
+
+// P parameter sets of a chain on randoms regenerated from (seed, call_id) in one launch + one column reduce
+// (svmc_logsv_chain_price_frozen_sets): consts_dev = [m][P] LogsvFast in log units (logsv_fast_to_doubles), vol0_dev = [P];
+// snapshots [P m][n] set-major, spot_sums [P m][2]
+template <int P>
+static void launch_chain_rng_sets(unsigned g, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs, const double *consts_dev,
+                                  const double *vol0_dev, uint64_t seed, uint32_t c3, uint64_t path_offset, double *x_snapshots,
+                                  double *qvar_snapshots, void *workspace)
+{
+    hipLaunchKernelGGL(logsv_chain_rng_sets_kernel<P>, dim3(g), dim3(BLOCK), 0, stream, n_path, cs,
+                       reinterpret_cast<const LogsvFast *>(consts_dev), vol0_dev, seed, c3, path_offset, 0u, x_snapshots,
+                       qvar_snapshots, static_cast<double *>(workspace));
+}
+
+int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
+                         const double *vol0_dev, const double *forwards_host, uint64_t seed, uint32_t call_id,
+                         uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums, void *workspace,
+                         size_t workspace_bytes, hipStream_t stream)
+{
+    const char *fn = "logsv_chain_rng_sets";
+    if (n_slices < 1 || n_slices > MAX_CHAIN_SLICES || n_sets < 1 || n_sets > MAX_CHAIN_SETS || n_path == 0)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
+    if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
+    const unsigned g = grid_for(n_path);
+    const int cols = 2 * n_slices * n_sets;
+    if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * cols * sizeof(double))
+        return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
+    ChainRngSetsSlices cs;
+    cs.m = n_slices;
+    for (int i = 0; i < MAX_CHAIN_SLICES; ++i) {
+        const int j = (i < n_slices) ? i : 0;
+        if (nb_steps_host[j] <= 0) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad step counts");
+        cs.forward[i] = forwards_host[j];
+        cs.nb_steps[i] = (i < n_slices) ? nb_steps_host[j] : 0;
+    }
+    const uint32_t c3 = make_c3(call_id);
+    switch (n_sets) {
+    case 1: launch_chain_rng_sets<1>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 2: launch_chain_rng_sets<2>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 3: launch_chain_rng_sets<3>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 4: launch_chain_rng_sets<4>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 5: launch_chain_rng_sets<5>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 6: launch_chain_rng_sets<6>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    case 7: launch_chain_rng_sets<7>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    default: launch_chain_rng_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+    }
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
+                       wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
+    return check_launch(fn);
+}
+
+// the constants of one (slice, set) pair as the generators take them: LogsvFast in log units (what logsv_rng_launch passes)
+void logsv_fast_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
+                           int is_spot_measure, double *out)
+{
+    const LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, eta, is_spot_measure)));
+    static_assert(sizeof(LogsvFast) == LOGSV_FAST_CONSTS_DOUBLES * sizeof(double), "LogsvFast layout");
+    memcpy(out, &c, sizeof(c));
 }
 
 // The price -> implied-vol step of a calibration objective on the device, where the payoff sums already are: one lane per

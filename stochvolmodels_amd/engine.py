@@ -519,6 +519,27 @@ class DeviceRandoms:
         _lib.check(lib.svmc_stream_synchronize(None))
         return self
 
+    @classmethod
+    def frozen(cls, nb_steps: Sequence[int], dts: Sequence[float], nb_path: int, n_local: int, col0: int, seed: int,
+               call_id: int = 0) -> "DeviceRandoms":
+        """the chain's fixed randoms as NOTHING BUT their definition: the counter-based stream of (seed, call_id).  No array
+        exists, on the host or in HBM -- every pricing regenerates the same normals in registers (svmc_logsv_chain_price_
+        frozen_sets), so a chain priced on this object is logsv_mc_chain_pricer(seed=seed) with the given call id, bit for
+        bit, at every call.  The reference's MC calibration keeps RandomState arrays for the same purpose
+        (pricers/logsv_pricer.py:244-265, 520-527); drawn_on_device() kept 16 bytes per path-step of HBM."""
+        self = cls.__new__(cls)
+        self.nb_path, self.n_local, self.col0 = int(nb_path), int(n_local), int(col0)
+        self.dts = [float(d) for d in dts]
+        self.nb_steps, self.w0, self.w1 = [int(n) for n in nb_steps], [], []
+        self._session, self._session_strikes = None, 0
+        self._session_sets, self._session_sets_size = None, (0, 0)
+        self.frozen_stream = (int(seed), int(call_id))
+        return self
+
+    @property
+    def is_frozen(self) -> bool:
+        return getattr(self, "frozen_stream", None) is not None
+
     def __len__(self):
         return len(self.nb_steps)
 
@@ -548,6 +569,10 @@ class DeviceRandoms:
         one synchronisation, prices and stderrs back -- the inner loop of an MC calibration.  Same kernels in the
         same order as mc_chain.price_chain_on_engine, hence the same bits.  want_ivols: a third list, the Black-76
         implied vols of the prices, computed by the graph's last kernel (svmc_logsv_chain_price_fixed_iv)."""
+        if self.is_frozen:
+            row = np.concatenate([[v0, theta, kappa1, kappa2, beta, volvol], np.asarray(etas, dtype=np.float64).ravel()])
+            return self.price_logsv_chain_sets(ttms, forwards, discfactors, strikes, codes, row[None, :], is_spot_measure,
+                                               variable_type, want_ivols=want_ivols, use_graph=use_graph)[0]
         lib = _lib.load()
         m = len(self)
         offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
@@ -582,7 +607,8 @@ class DeviceRandoms:
 
 
     def price_logsv_chain_sets(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
-                               params_rows: np.ndarray, is_spot_measure: bool, variable_type: int, want_ivols: bool = False):
+                               params_rows: np.ndarray, is_spot_measure: bool, variable_type: int, want_ivols: bool = False,
+                               use_graph: bool = True, comm_handle=None, rank: int = 0, world: int = 1):
         """SEVERAL parameter sets on these randoms in one call of svmc_logsv_chain_price_fixed_sets: with 2..8 sets one
         replayed graph whose stepping launch reads the randoms once for all of them.  params_rows [n_sets][6 + m] =
         (v0, theta, kappa1, kappa2, beta, volvol, vol-backbone eta per expiry).  Returns per set what price_logsv_chain
@@ -595,13 +621,18 @@ class DeviceRandoms:
             raise ValueError("params_rows must have shape [n_sets, 6 + n_expiries]")
         offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
         total = int(offs[-1])
-        need = (m * n_sets, max(total * n_sets, 1))
+        per_launch = min(n_sets, 8)
+        need = (m * per_launch, max(total * per_launch, 1))
+        if self.is_frozen:
+            need = (m * 8, max(total * 8, 1))       # one session for every set count of an optimizer run (1 .. 8 per launch)
         if self._session_sets is None or self._session_sets_size[0] < need[0] or self._session_sets_size[1] < need[1]:
             if self._session_sets is not None:
                 _lib.check(lib.svmc_session_destroy(self._session_sets))
             sess = C.c_void_p()
             _lib.check(lib.svmc_session_create(C.byref(sess), self.n_local, need[0], need[1]))
             self._session_sets, self._session_sets_size = sess, need
+            if comm_handle is not None:
+                _lib.check(lib.svmc_session_set_comm(sess, comm_handle, int(rank), int(world), self.nb_path, self.col0))
         dp = C.POINTER(C.c_double)
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)      # noqa: E731
         ttms, forwards, discfactors = f64(ttms), f64(forwards), f64(discfactors)
@@ -614,6 +645,18 @@ class DeviceRandoms:
         shape = (n_sets, max(total, 1))
         prices, stderrs = np.empty(shape), np.empty(shape)
         ivols = np.empty(shape) if want_ivols else None
+        split = lambda a, q: [a[q, offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
+        if self.is_frozen:
+            _lib.check(lib.svmc_session_use_graphs(self._session_sets, int(bool(use_graph))))
+            seed, call_id = self.frozen_stream
+            _lib.check(lib.svmc_logsv_chain_price_frozen_sets(
+                self._session_sets, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp), m,
+                k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
+                n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), nbs,
+                dts.ctypes.data_as(dp), seed, call_id, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp),
+                ivols.ctypes.data_as(dp) if want_ivols else None))
+            return [(split(prices, q), split(stderrs, q), split(ivols, q)) if want_ivols else (split(prices, q), split(stderrs, q))
+                    for q in range(n_sets)]
         _lib.check(lib.svmc_logsv_chain_price_fixed_sets(
             self._session_sets, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp), m,
             k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),

@@ -272,10 +272,13 @@ class LogSVPricer(ModelPricer):
                 model_vols_batch = None
         elif calibration_engine == CalibrationEngine.MC:
             if kwargs.get("device_randoms", False):
-                # the fixed randoms drawn in HBM (milliseconds) instead of by NumPy on the host (the reference's
-                # RandomState arrays: about a second per 10^5 paths): same estimator, another sample
+                # the fixed randoms are the counter-based stream of `seed` instead of NumPy's RandomState arrays (about a
+                # second of host draws per 10^5 paths, 582 MB of upload at 10^5 x 364): same estimator, another sample.
+                # device_randoms=True keeps NOTHING resident -- every objective evaluation regenerates the draws in
+                # registers (svmc_logsv_chain_price_frozen_sets: no HBM term in the stepping, the draw shared by the
+                # bumped parameter sets of a gradient); device_randoms="hbm" materialises them in HBM as round 4 did
                 resident = draw_fixed_randoms_on_device(ttms=option_chain.ttms, nb_path=nb_path, nb_steps_per_year=nb_steps,
-                                                        seed=seed, comm=comm)
+                                                        seed=seed, comm=comm, in_hbm=kwargs["device_randoms"] == "hbm")
             else:
                 resident = upload_fixed_randoms(*get_randoms_for_chain_valuation(
                     ttms=option_chain.ttms, nb_path=nb_path, nb_steps_per_year=nb_steps, seed=seed), comm=comm)
@@ -501,14 +504,25 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
                                     beta, volvol, vol_backbone_etas, is_spot_measure, nb_steps_per_year, vt_code, rng_seed,
                                     call_id)
     comm = comm or svdist.get_default_comm()
-    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
-    eng = get_engine(n_local, path_offset=offset)
     rng_seed, call_id = next_rng_call(seed)
     grids, t0 = [], 0.0
     for ttm in ttms:
         nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)
         grids.append((nb, dt))
         t0 = ttm
+    return _logsv_mc_chain_on_grids(grids, rng_seed, call_id, comm, ttms, forwards, discfactors, strikes_ttms, optiontypes_ttms,
+                                    v0, theta, kappa1, kappa2, beta, volvol, vol_backbone_etas, is_spot_measure, nb_path,
+                                    variable_type)
+
+
+def _logsv_mc_chain_on_grids(grids, rng_seed: int, call_id: int, comm, ttms, forwards, discfactors, strikes_ttms,
+                             optiontypes_ttms, v0, theta, kappa1, kappa2, beta, volvol, vol_backbone_etas, is_spot_measure,
+                             nb_path, variable_type) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """the on-device-RNG chain on explicit per-expiry grids [(nb_steps_i, dt_i)] and an explicit stream (seed, call id):
+    logsv_mc_chain_pricer after its bookkeeping, and what a chain on FROZEN randoms (DeviceRandoms.frozen) runs when it is
+    sharded over ranks"""
+    offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
+    eng = get_engine(n_local, path_offset=offset)
     step0 = [0]
     for g in grids:
         step0.append(step0[-1] + g[0])
@@ -555,11 +569,14 @@ def upload_fixed_randoms(W0s: Sequence[np.ndarray], W1s: Sequence[np.ndarray], d
 
 
 def draw_fixed_randoms_on_device(ttms: np.ndarray, nb_path: int = 100000, nb_steps_per_year: int = 360, seed: int = 10,
-                                 comm=None) -> DeviceRandoms:
+                                 comm=None, in_hbm: bool = False) -> DeviceRandoms:
     """the device-side twin of get_randoms_for_chain_valuation + upload_fixed_randoms (no reference counterpart): the
-    same per-expiry grids, the N(0,1) draws made in HBM by the counter-based generator -- the draws logsv_mc_chain_pricer
-    (seed=seed) consumes, frozen.  Milliseconds where the host draw of the same arrays takes about a second per 10^5
-    paths; statistically equivalent to, not bit-identical with, the RandomState(seed) arrays of the reference."""
+    same per-expiry grids, the N(0,1) draws of the counter-based generator -- the draws logsv_mc_chain_pricer(seed=seed)
+    consumes at its call 0 -- frozen.  By default NOTHING is stored: the object is the stream's definition (seed, call 0)
+    and every pricing on it regenerates the same normals in registers (DeviceRandoms.frozen), bit-identical to
+    logsv_mc_chain_pricer on that stream.  in_hbm=True materialises them in HBM instead (16 bytes per path-step, priced
+    by the streamed-randoms kernels in the reference's evaluation order: the same draws, rounding-level different prices).
+    Either way statistically equivalent to, not bit-identical with, the RandomState(seed) arrays of the reference."""
     comm = comm or svdist.get_default_comm()
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     grids, t0 = [], 0.0
@@ -568,7 +585,8 @@ def draw_fixed_randoms_on_device(ttms: np.ndarray, nb_path: int = 100000, nb_ste
         grids.append((nb, dt))
         t0 = ttm
     get_engine(n_local, path_offset=offset)               # the library and the device are up before the first launch
-    return DeviceRandoms.drawn_on_device([g[0] for g in grids], [g[1] for g in grids], nb_path, n_local, offset, seed)
+    make = DeviceRandoms.drawn_on_device if in_hbm else DeviceRandoms.frozen
+    return make([g[0] for g in grids], [g[1] for g in grids], nb_path, n_local, offset, seed)
 
 
 def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,
@@ -597,6 +615,17 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                          vol_backbone_etas, is_spot_measure, variable_type_code(variable_type),
                                          want_ivols=return_ivols)
         return tuple([a.reshape(np.shape(k)) for a, k in zip(part, strikes_ttms)] for part in out)
+    if resident and resident.is_frozen:
+        # frozen randoms, sharded over ranks (or the fused driver switched off): the on-device-RNG chain on the stream the
+        # object names -- the same numbers the fused route gives on one GPU
+        fr_seed, fr_call = resident.frozen_stream
+        prices, stderrs = _logsv_mc_chain_on_grids(list(zip(resident.nb_steps, resident.dts)), fr_seed, fr_call, comm, ttms,
+                                                   forwards, discfactors, strikes_ttms, optiontypes_ttms, v0, theta, kappa1,
+                                                   kappa2, beta, volvol, vol_backbone_etas, is_spot_measure, nb_path,
+                                                   variable_type)
+        if not return_ivols:
+            return prices, stderrs
+        return prices, stderrs, _host_ivols(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)
     eng = get_engine(n_local, path_offset=offset)
     eng.fill_state(0.0, v0, 0.0)
 
@@ -617,11 +646,14 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                             optiontypes_ttms, variable_type, advance)
     if not return_ivols:
         return prices, stderrs
+    return prices, stderrs, _host_ivols(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)
+
+
+def _host_ivols(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors) -> List[np.ndarray]:
     from ..data.option_chain import black_ivols_native           # the host twin of the graph's implied-vol kernel
-    ivols = [black_ivols_native(np.asarray(p, dtype=float).ravel(), float(t), float(f), np.asarray(k, dtype=float).ravel(),
-                                np.asarray(ty).ravel(), float(d)).reshape(np.shape(k))
-             for p, t, f, k, ty, d in zip(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)]
-    return prices, stderrs, ivols
+    return [black_ivols_native(np.asarray(p, dtype=float).ravel(), float(t), float(f), np.asarray(k, dtype=float).ravel(),
+                               np.asarray(ty).ravel(), float(d)).reshape(np.shape(k))
+            for p, t, f, k, ty, d in zip(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)]
 
 
 def logsv_mc_chain_pricer_fixed_randoms_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,

@@ -134,7 +134,7 @@ def test_multi_session_errors_and_rccl_refusal(sv):
     with pytest.raises(SvmcError) as exc:
         MultiDeviceSession([0, 0], 1024, 1, 1, reduce="rccl")
     assert "share a device" in str(exc.value)
-    ms = MultiDeviceSession([0, 0], 4096, 2, 8, reduce="auto")
+    ms = MultiDeviceSession([0, 0], 4096, 2, 16, reduce="auto")
     try:
         assert ms.info()["reduce"] == "host"
         ttms, fw, df, strikes, types = _small_chain()

@@ -1090,6 +1090,90 @@ def test_parameter_sets_share_one_pass_over_the_randoms(sv):
     res.free()
 
 
+def test_frozen_randoms_regenerated_in_registers(sv):
+    """draw_fixed_randoms_on_device() keeps NOTHING: the object names the stream (seed, call 0) and every pricing regenerates
+    the normals in registers (svmc_logsv_chain_price_frozen_sets, logsv_chain_rng_sets_kernel<P>: one draw per step shared by
+    the P parameter sets of a launch).  Per set the prices, standard errors and implied vols are those of
+    logsv_mc_chain_pricer(seed=...) with that set's parameters BIT FOR BIT -- 1, 2, 3, 6, 8 and 9 sets (9 = a launch of 8 and
+    a single), with vol backbones, in both measures, LOG_RETURN and Q_VAR, graph capture and replay, graphs off, one expiry
+    -- and no HBM is held for randoms."""
+    from stochvolmodels_amd.data.option_chain import black_ivols_native
+    import pandas as pd
+    ttms = np.array([0.1, 0.3, 0.75])
+    k = np.linspace(0.7, 1.3, 7)
+    ty = np.where(k >= 1.0, "C", "P")
+    common = dict(ttms=ttms, forwards=np.array([1.0, 1.01, 1.02]), discfactors=np.array([0.999, 0.99, 0.98]),
+                  strikes_ttms=(k,) * 3, optiontypes_ttms=(ty,) * 3)
+    n, seed = 20011, 77
+    rng = np.random.default_rng(9)
+    sets = []
+    for j in range(9):
+        bb = None if j % 2 == 0 else pd.Series(1.0 + 0.1 * rng.standard_normal(3), index=ttms)
+        sets.append(sv.LogSvParams(sigma0=0.8 + 0.02 * j, theta=1.0 + 0.01 * j, kappa1=3.0 + 0.1 * j, kappa2=3.0 - 0.1 * j,
+                                   beta=0.15 - 0.03 * j, volvol=1.8 - 0.05 * j, vol_backbone=bb))
+
+    def rng_route(p, chain=common, **kw):
+        return sv.logsv_mc_chain_pricer(v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                        vol_backbone_etas=p.get_vol_backbone_etas(ttms=chain["ttms"]), nb_path=n,
+                                        nb_steps_per_year=360, seed=seed, **chain, **kw)
+
+    res = sv.draw_fixed_randoms_on_device(ttms, nb_path=n, nb_steps_per_year=360, seed=seed)
+    assert res.is_frozen and res.w0 == [] and res.w1 == []
+    for spot in (True, False):
+        for n_sets in (1, 2, 3, 6, 8, 9):
+            for rep in range(2):                                    # capture, then replay
+                out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets[:n_sets], W0s=res, return_ivols=True,
+                                                                   is_spot_measure=spot, **common)
+                assert len(out) == n_sets
+                for p, got in zip(sets, out):
+                    want = rng_route(p, is_spot_measure=spot)
+                    for a, b in zip(got[0] + got[1], want[0] + want[1]):
+                        np.testing.assert_array_equal(a, b, err_msg=f"{n_sets} sets, rep {rep}, spot {spot}")
+                    for iv, pr, t, f, d in zip(got[2], got[0], ttms, common["forwards"], common["discfactors"]):
+                        np.testing.assert_allclose(iv, black_ivols_native(pr, float(t), float(f), k, ty, float(d)), rtol=1e-9,
+                                                   equal_nan=True)
+    # the single-set entry point (an objective evaluation), graph on and off
+    p = sets[3]
+    want = rng_route(p)
+    for use_graph in (True, False):
+        got = res.price_logsv_chain(ttms, common["forwards"], common["discfactors"], [k] * 3, [np.where(k >= 1.0, 0, 1).astype(np.int8)] * 3,
+                                    p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, p.get_vol_backbone_etas(ttms=ttms), True,
+                                    1, use_graph=use_graph)
+        for a, b in zip(got[0] + got[1], want[0] + want[1]):
+            np.testing.assert_array_equal(a, b)
+    got = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+                                                 kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                                 vol_backbone_etas=p.get_vol_backbone_etas(ttms=ttms), **common)
+    for a, b in zip(got[0] + got[1], want[0] + want[1]):
+        np.testing.assert_array_equal(a, b)
+    # options on the quadratic variance
+    qv = dict(common, strikes_ttms=(np.array([0.2, 0.6, 1.0]),) * 3, optiontypes_ttms=(np.array(["C", "P", "C"]),) * 3)
+    out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets[:4], W0s=res, variable_type=sv.VariableType.Q_VAR, **qv)
+    for p, got in zip(sets, out):
+        want = rng_route(p, chain=qv, variable_type=sv.VariableType.Q_VAR)
+        for a, b in zip(got[0] + got[1], want[0] + want[1]):
+            np.testing.assert_array_equal(a, b)
+    res.free()
+    # one expiry: the whole-chain kernel with m = 1 against the one-slice generator
+    one = dict(ttms=ttms[:1], forwards=common["forwards"][:1], discfactors=common["discfactors"][:1], strikes_ttms=(k,),
+               optiontypes_ttms=(ty,))
+    res1 = sv.draw_fixed_randoms_on_device(ttms[:1], nb_path=n, nb_steps_per_year=360, seed=seed)
+    out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets[:3], W0s=res1, **one)
+    for p, got in zip(sets, out):
+        want = rng_route(p, chain=one)
+        for a, b in zip(got[0] + got[1], want[0] + want[1]):
+            np.testing.assert_array_equal(a, b)
+    res1.free()
+    # the materialised form is still there on request: the same draws in HBM, priced by the streamed kernels (rounding-level apart)
+    hbm = sv.draw_fixed_randoms_on_device(ttms, nb_path=n, nb_steps_per_year=360, seed=seed, in_hbm=True)
+    assert not hbm.is_frozen and len(hbm.w0) == 3
+    a, _ = sv.logsv_mc_chain_pricer_fixed_randoms(W0s=hbm, W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
+                                                  kappa2=p.kappa2, beta=p.beta, volvol=p.volvol, vol_backbone_etas=np.ones(3), **common)
+    b, _ = rng_route(sv.LogSvParams(sigma0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol))
+    np.testing.assert_allclose(np.concatenate(a), np.concatenate(b), rtol=1e-12, atol=1e-12)
+    hbm.free()
+
+
 def test_implied_vols_from_the_graph(sv, oracle):
     """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
     (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
