@@ -701,6 +701,7 @@ def main():
     offset, n_local = svdist.shard_range(n_total, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)
     wd.arm(t_leg, "timed region")
+    svlib.check(svlib.load().svmc_clock_probe_arm(1))     # this thread's stepping launches stamp the shader clock (off otherwise)
     barrier()
     if os.environ.get("SVMC_BENCH_NO_KERNEL_EVENTS") != "1":     # diagnostics: the HIP events around the stepping launches
         eng.start_kernel_timing()
@@ -719,6 +720,7 @@ def main():
     import ctypes as C
     stamps = (C.c_uint64 * 8)()
     svlib.check(svlib.load().svmc_clock_probe_read(stamps, eng.stream))
+    svlib.check(svlib.load().svmc_clock_probe_arm(0))
     elapsed = max_over_ranks(elapsed)
     value = float(n_total) * nb * args.steps / elapsed
     k_ms_all = gather_over_ranks(float(np.mean(kernel_ms)))

@@ -95,11 +95,15 @@ SVMC_API int svmc_event_create(svmc_event_t *event);
 SVMC_API int svmc_event_destroy(svmc_event_t event);
 SVMC_API int svmc_event_record(svmc_event_t event, svmc_stream_t stream);
 SVMC_API int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms); /* synchronises on `stop` */
-/* The shader clock the LAST on-device-RNG LogSV stepping launch (svmc_logsv_*_rng*) ran at, measured inside that kernel
- * (no reference counterpart: measurement plumbing of bench.py's roofline): thread 0 of the launch's first and
- * last block stamp s_memtime (tick = shader cycle) and s_memrealtime (100 MHz) at kernel entry and after the time loop.
- * stamps[8] = [first block | last block][t_entry, r_entry, t_exit, r_exit]; clock = (t_exit - t_entry) / (r_exit -
- * r_entry) x 100 MHz.  Synchronises `stream` (the launch's stream) first; the stamps are per device, latest launch wins. */
+/* The shader clock an on-device-RNG LogSV stepping launch (svmc_logsv_*_rng*, svmc_logsv_vol_paths) ran at, measured inside
+ * that kernel (no reference counterpart: measurement plumbing of bench.py's roofline).  OFF by default -- the
+ * kernels take a null probe pointer and do nothing.  svmc_clock_probe_arm(1) arms the CALLING THREAD: it gets its own 8-word
+ * device buffer (on the current device) and its later launches hand it to the kernel, where thread 0 of the launch's first
+ * and last block stamp s_memtime (tick = shader cycle) and s_memrealtime (100 MHz) at kernel entry and after the time loop.
+ * svmc_clock_probe_read synchronises `stream` and returns stamps[8] = [first block | last block][t_entry, r_entry, t_exit,
+ * r_exit] of the thread's latest armed launch; clock = (t_exit - t_entry) / (r_exit - r_entry) x 100 MHz.
+ * svmc_clock_probe_arm(0) disarms and frees.  Per thread, not global: engines on other threads neither see nor disturb it. */
+SVMC_API int svmc_clock_probe_arm(int enable);
 SVMC_API int svmc_clock_probe_read(uint64_t *stamps, svmc_stream_t stream);
 
 /* ---- state ----------------------------------------------------------------------------------------

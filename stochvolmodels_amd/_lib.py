@@ -53,6 +53,7 @@ def _declare(L: C.CDLL) -> None:
         "svmc_event_destroy": ([vp], i32),
         "svmc_event_record": ([vp, vp], i32),
         "svmc_event_elapsed_ms": ([vp, vp, pf], i32),
+        "svmc_clock_probe_arm": ([i32], i32),
         "svmc_clock_probe_read": ([C.POINTER(u64), vp], i32),
         "svmc_fill_state": ([vp, vp, vp, sz, f64, f64, f64, vp], i32),
         "svmc_fill_normals": ([vp, vp, sz, sz, i32, u64, u32, u64, u32, vp], i32),

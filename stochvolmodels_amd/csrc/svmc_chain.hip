@@ -711,8 +711,9 @@ int svmc_logsv_chain_price_frozen_sets(svmc_session_t session, const double *ttm
     auto enqueue = [&]() -> int {
         SVMC_HIP_TRY(hipMemcpyAsync(g.params_dev, g.params_host, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
         double *qsnaps = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * P * n : nullptr;
+        // (a captured launch never carries the thread's clock probe: the graph outlives the probe's buffer)
         if (int rc = logsv_chain_rng_sets(n, P, c.m, nb_steps_host, g.params_dev + P, g.params_dev, c.forwards, seed, call_id,
-                                          s->path_offset, s->snap, qsnaps, s->spot, s->ws, s->ws_bytes, s->stream))
+                                          s->path_offset, s->snap, qsnaps, s->spot, s->ws, s->ws_bytes, s->stream, !graph))
             return rc;
         if (int rc = all_reduce(s, s->spot, 2 * static_cast<size_t>(c.m) * P)) return rc;
         for (int q = 0; q < P; ++q)
@@ -751,18 +752,18 @@ int svmc_logsv_chain_price_frozen_sets(svmc_session_t session, const double *ttm
             SVMC_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.ivols_host), n_quotes * sizeof(double), hipHostMallocDefault));
             SVMC_HIP_TRY(hipMemcpy(g.quotes_dev, quotes.data(), quotes.size() * sizeof(double), hipMemcpyHostToDevice));
         }
-        if (graph) {
-            SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
-            const int rc = enqueue();
-            const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
-            if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
-            if (e_end != hipSuccess) {
-                fixed_graph_release(g);
-                return fail(SVMC_ERR_HIP, std::string(fn) + ": graph capture: " + hipGetErrorString(e_end));
-            }
-            SVMC_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-        }
         g.key = key;
+    }
+    if (graph && g.exec == nullptr) {      // captured at the first replayed call of this shape (an un-replayed call may come first)
+        SVMC_HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue();
+        const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
+        if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
+        if (e_end != hipSuccess) {
+            fixed_graph_release(g);
+            return fail(SVMC_ERR_HIP, std::string(fn) + ": graph capture: " + hipGetErrorString(e_end));
+        }
+        SVMC_HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
     }
     for (int q = 0; q < P; ++q) {
         const double *pr = params_host + row * q;

@@ -52,7 +52,7 @@ constexpr int LOGSV_FAST_CONSTS_DOUBLES = 9;
 int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
                          const double *vol0_dev, const double *forwards_host, uint64_t seed, uint32_t call_id,
                          uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums, void *workspace,
-                         size_t workspace_bytes, hipStream_t stream);
+                         size_t workspace_bytes, hipStream_t stream, bool allow_probe);
 void logsv_fast_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
                            int is_spot_measure, double *out);
 constexpr int IV_QUOTE_DOUBLES_HOST = 6;   // = IV_QUOTE_DOUBLES of svmc_kernels.hip: {strike, code, shift, forward, ttm, df}

@@ -7,6 +7,7 @@
 // transcendentals (DESIGN.md "Rooflines").
 #include "svmc_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include "svmc_black.h"
@@ -34,26 +35,36 @@ static inline unsigned rng_grid(size_t n) { return static_cast<unsigned>((n + rn
 
 static inline unsigned grid_for(size_t n) { return static_cast<unsigned>((n + BLOCK - 1) / BLOCK); }
 
-// In-kernel clock probe of the on-device-RNG LogSV generators (svmc_clock_probe_read; bench.py roofline.clock_mhz_in_kernel).
-// Thread 0 of the launch's FIRST and LAST block stamp s_memtime (tick = shader cycle) and s_memrealtime (100 MHz, chip-wide)
-// at kernel entry and again after the time loop: (t_exit - t_entry) / (r_exit - r_entry) x 100 MHz is the shader clock that
-// wave saw while it stepped -- measured in the timed launch itself, where the SMU's sysfs sensor (absent on some boxes of the
-// pool) lags and averages.  First block = the launch's first residency round, last block = its last one.  A dozen scalar /
-// lane-0 instructions outside the time loop, nothing held in registers across it (the entry stamps go straight to memory).
-// Layout: [which = 0 first block | 1 last block][t_entry, r_entry, t_exit, r_exit]; the latest launch wins.
-__device__ uint64_t g_clock_probe[8];
-
-__device__ __forceinline__ void clock_probe_stamp(int at_exit)
+// In-kernel clock probe of the on-device-RNG LogSV generators (svmc_clock_probe_arm / _read; bench.py
+// roofline.clock_mhz_in_kernel): measurement plumbing, OFF unless the calling host thread armed it.  The stepping kernels
+// take a nullable `probe` argument -- null in every product launch: one scalar test, nothing else.  When a thread has armed
+// the probe, ITS launches pass that thread's own 8-word device buffer and thread 0 of the launch's FIRST and LAST block stamp
+// s_memtime (tick = shader cycle) and s_memrealtime (100 MHz, chip-wide) at kernel entry and again after the time loop:
+// (t_exit - t_entry) / (r_exit - r_entry) x 100 MHz is the shader clock that wave saw while it stepped -- measured in the
+// timed launch itself, where the SMU's sysfs sensor (absent on some boxes of the pool) lags and averages.  No global: two
+// engines on two streams (tests/test_gpu_parity.py::test_two_engines_on_their_own_streams) never share stamps, and a
+// thread that did not arm the probe never writes any (round 4 kept one __device__ array every launch of three kernels
+// wrote: a race between engines and bench-only code on the hot path).
+// Layout: [which = 0 first block | 1 last block][t_entry, r_entry, t_exit, r_exit]; the latest armed launch wins.
+__device__ __forceinline__ void clock_probe_stamp(uint64_t *probe, int at_exit)
 {
+    if (probe == nullptr) return;                                                    // wave-uniform (a kernel argument)
     const bool first = blockIdx.x == 0u, last = blockIdx.x == gridDim.x - 1u;        // wave-uniform
     if (first || last) {
         const uint64_t t = __builtin_readcyclecounter(), r = wall_clock64();
         if (threadIdx.x == 0u) {
-            uint64_t *o = g_clock_probe + (first ? 0 : 4) + 2 * at_exit;
+            uint64_t *o = probe + (first ? 0 : 4) + 2 * at_exit;
             o[0] = t;
             o[1] = r;
         }
     }
+}
+
+// the calling host thread's armed probe buffer (device memory of the device that was current at svmc_clock_probe_arm), or null
+static uint64_t *&armed_probe()
+{
+    thread_local uint64_t *p = nullptr;
+    return p;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -241,12 +252,12 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
                                                           double *__restrict__ qvar, size_t n, int nb_steps,
                                                           LogsvFast c, uint64_t seed, uint32_t c3,
                                                           uint64_t path_offset, uint32_t step_offset, SliceOut so,
-                                                          StateInit init)
+                                                          StateInit init, uint64_t *probe)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
-    clock_probe_stamp(0);
+    clock_probe_stamp(probe, 0);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
         sigma[p] = s;
         qvar[p] = q;
     }
-    clock_probe_stamp(1);
+    clock_probe_stamp(probe, 1);
 #ifdef SVMC_TAIL_PROBE
     if ((threadIdx.x & 63u) == 0u && so.q_snap != nullptr) {
         so.q_snap[2 * (p >> 6)] = static_cast<double>(probe_t0);
@@ -328,13 +339,13 @@ static inline unsigned chain_grid(size_t n) { return static_cast<unsigned>((n + 
 __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVMC_CHAIN_WAVES), amdgpu_num_sgpr(SVMC_CHAIN_SGPRS))) void logsv_chain_rng_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
-    double *__restrict__ partials, StateInit init)
+    double *__restrict__ partials, StateInit init, uint64_t *probe)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     __shared__ double s_park[2 * CHAIN_BLOCK];             // [0, B): x, [B, 2B): qvar -- lane t owns elements t and B + t
     const RngTables tab = stage_tables(s_tab, s_exp);
-    clock_probe_stamp(0);
+    clock_probe_stamp(probe, 0);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     // the path index is re-derived from threadIdx.x wherever it is needed (opaque to CSE): one VGPR across the time loop
     // instead of the 64-bit index and the addresses formed from it
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
         sigma[p] = s;
         qvar[p] = s_park[CHAIN_BLOCK + threadIdx.x];
     }
-    clock_probe_stamp(1);
+    clock_probe_stamp(probe, 1);
 }
 
 // Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
@@ -639,18 +650,28 @@ struct ChainRngSetsSlices {
 };
 constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(double));
 
-template <int P>
-__global__ __launch_bounds__(BLOCK) void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs,
-                                                                     const LogsvFast *__restrict__ consts,
-                                                                     const double *__restrict__ init, uint64_t seed, uint32_t c3,
-                                                                     uint64_t path_offset, uint32_t step_offset,
-                                                                     double *__restrict__ x_snap, double *__restrict__ q_snap,
-                                                                     double *__restrict__ partials)
+//
+// Launch shape.  A calibration-sized path set (10^5 paths = 1563 waves) is LESS than one wave per SIMD pair of the chip, and the
+// step is a dependent chain of ~20 fp64 operations around an LDS round trip: what matters is that the waves are spread over
+// ALL the SIMDs, each with about two of them to overlap (the dispatcher packs blocks onto a CU as long as its LDS and
+// registers last -- four 256-thread blocks of this kernel fit one CU -- and the packed CUs then run 4 waves per SIMD while
+// others idle).  So: TB threads per block (256 / 512 / 1024) chosen by the launcher so that the grid is at most one block
+// per CU where the path count allows, and `lds_pad` bytes of unused dynamic LDS that make a second block on the same CU
+// impossible in that case (profiles/r05_frozen_launch_shape.txt).
+template <int P, int TB>
+__global__ __launch_bounds__(TB) void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs,
+                                                                  const LogsvFast *__restrict__ consts,
+                                                                  const double *__restrict__ init, uint64_t seed, uint32_t c3,
+                                                                  uint64_t path_offset, uint32_t step_offset,
+                                                                  double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                  double *__restrict__ partials, uint64_t *probe)
 {
+    constexpr int BLOCK = TB;                              // shadows the file-wide block size inside this kernel
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     __shared__ LogsvFast s_c[P];
     const RngTables tab = stage_tables(s_tab, s_exp);
+    clock_probe_stamp(probe, 0);
     const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
@@ -703,6 +724,7 @@ __global__ __launch_bounds__(BLOCK) void logsv_chain_rng_sets_kernel(size_t n, C
             slice_epilogue(so, p, active, xv[s], q[s]);
         }
     }
+    clock_probe_stamp(probe, 1);
 }
 
 __global__ __launch_bounds__(BLOCK) void fill_state_indirect_kernel(double *__restrict__ x, double *__restrict__ vol,
@@ -763,13 +785,14 @@ __device__ __forceinline__ void vol_paths_store(double *ptr, double v)
 template <bool RNG>
 __global__ __launch_bounds__(RNG ? VOLPATHS_RNG_BLOCK : BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, int nb_steps, double v0, VolPathConsts c,
-                            const double *__restrict__ brownians, size_t ldb, uint64_t seed, uint32_t c3, uint64_t path_offset)
+                            const double *__restrict__ brownians, size_t ldb, uint64_t seed, uint32_t c3, uint64_t path_offset,
+                            uint64_t *probe)
 {
     constexpr int TB = RNG ? VOLPATHS_RNG_BLOCK : BLOCK;
     __shared__ RngTablesLdsIf<RNG> s_tab;                  // the draw's table only where the kernel draws
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables_if(s_tab, s_exp);
-    clock_probe_stamp(0);
+    clock_probe_stamp(probe, 0);
     const size_t p = static_cast<size_t>(blockIdx.x) * TB + threadIdx.x;
     if (p < n) {
         double s = v0, L = c.L0;
@@ -834,7 +857,7 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
             for (; t < nb_steps; ++t) step(w[static_cast<size_t>(t) * ldb]);
         }
     }
-    clock_probe_stamp(1);
+    clock_probe_stamp(probe, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1451,7 +1474,7 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
     hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init);
+                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, armed_probe());
     return check_launch(fn);
 }
 
@@ -1561,7 +1584,7 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
         hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
                            cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
-                           (i0 == 0) ? init : StateInit());
+                           (i0 == 0) ? init : StateInit(), armed_probe());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
@@ -1753,26 +1776,69 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
 // P parameter sets of a chain on randoms regenerated from (seed, call_id) in one launch + one column reduce
 // (svmc_logsv_chain_price_frozen_sets): consts_dev = [m][P] LogsvFast in log units (logsv_fast_to_doubles), vol0_dev = [P];
 // snapshots [P m][n] set-major, spot_sums [P m][2]
-template <int P>
-static void launch_chain_rng_sets(unsigned g, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs, const double *consts_dev,
-                                  const double *vol0_dev, uint64_t seed, uint32_t c3, uint64_t path_offset, double *x_snapshots,
-                                  double *qvar_snapshots, void *workspace)
+template <int P, int TB>
+static void launch_chain_rng_sets(unsigned g, size_t lds_pad, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs,
+                                  const double *consts_dev, const double *vol0_dev, uint64_t seed, uint32_t c3,
+                                  uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace,
+                                  uint64_t *probe)
 {
-    hipLaunchKernelGGL(logsv_chain_rng_sets_kernel<P>, dim3(g), dim3(BLOCK), 0, stream, n_path, cs,
+    if (lds_pad != 0) {            // once per instantiation: let the launch ask for more dynamic LDS than the default allowance
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&logsv_chain_rng_sets_kernel<P, TB>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+        (void)attr;
+    }
+    hipLaunchKernelGGL((logsv_chain_rng_sets_kernel<P, TB>), dim3(g), dim3(TB), lds_pad, stream, n_path, cs,
                        reinterpret_cast<const LogsvFast *>(consts_dev), vol0_dev, seed, c3, path_offset, 0u, x_snapshots,
-                       qvar_snapshots, static_cast<double *>(workspace));
+                       qvar_snapshots, static_cast<double *>(workspace), probe);
+}
+
+// threads per block and LDS padding of a frozen-sets launch (see the kernel): the smallest block size that puts the whole
+// path set into at most one block per CU -- then every block gets a CU of its own -- and, failing that, the plain 256.
+// SVMC_RNG_SETS_BLOCK / SVMC_RNG_SETS_EXCLUSIVE override the choice (tools/r05/bench_frozen.py sweeps them).
+static void rng_sets_launch_shape(size_t n_path, int n_sets, int &tb, size_t &lds_pad)
+{
+    static const int env_tb = std::getenv("SVMC_RNG_SETS_BLOCK") ? std::atoi(std::getenv("SVMC_RNG_SETS_BLOCK")) : 0;
+    static const int env_ex = std::getenv("SVMC_RNG_SETS_EXCLUSIVE") ? std::atoi(std::getenv("SVMC_RNG_SETS_EXCLUSIVE")) : -1;
+    static int n_cu = 0;
+    static size_t lds_per_block = 64 << 10;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+            n_cu = prop.multiProcessorCount;
+            lds_per_block = prop.sharedMemPerBlock;
+        }
+    }
+    const int max_tb = (n_sets >= 5) ? 512 : 1024;         // 1024 threads = 4 waves per SIMD = 128 registers; 5+ sets need more
+    tb = 256;
+    bool fits = false;
+    for (int cand = 256; cand <= max_tb; cand *= 2)
+        if ((n_path + cand - 1) / cand <= static_cast<size_t>(n_cu)) {
+            tb = cand;
+            fits = true;
+            break;
+        }
+    if (env_tb == 256 || env_tb == 512 || (env_tb == 1024 && max_tb == 1024)) {
+        tb = env_tb;
+        fits = (n_path + tb - 1) / tb <= static_cast<size_t>(n_cu);
+    }
+    const bool exclusive = (env_ex >= 0) ? (env_ex != 0) : fits;
+    // the kernel's static LDS is 35 KB: 48 KB more and two blocks exceed a CU's 160 KB (2 x 83); where a block may not hold
+    // that much, as much as it may (then two blocks fit a CU, three do not)
+    const size_t want = 48u << 10, room = lds_per_block > (37u << 10) ? lds_per_block - (37u << 10) : 0;
+    lds_pad = exclusive ? (want < room ? want : room) : 0;
 }
 
 int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
                          const double *vol0_dev, const double *forwards_host, uint64_t seed, uint32_t call_id,
                          uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums, void *workspace,
-                         size_t workspace_bytes, hipStream_t stream)
+                         size_t workspace_bytes, hipStream_t stream, bool allow_probe)
 {
     const char *fn = "logsv_chain_rng_sets";
     if (n_slices < 1 || n_slices > MAX_CHAIN_SLICES || n_sets < 1 || n_sets > MAX_CHAIN_SETS || n_path == 0)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": bad sizes");
     if (call_id >= (1u << 24)) return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": call_id must fit 24 bits");
-    const unsigned g = grid_for(n_path);
     const int cols = 2 * n_slices * n_sets;
     if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * cols * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
@@ -1785,16 +1851,32 @@ int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_
         cs.nb_steps[i] = (i < n_slices) ? nb_steps_host[j] : 0;
     }
     const uint32_t c3 = make_c3(call_id);
+    int tb = 256;
+    size_t pad = 0;
+    rng_sets_launch_shape(n_path, n_sets, tb, pad);
+    const unsigned g = static_cast<unsigned>((n_path + tb - 1) / tb);
+    uint64_t *probe = allow_probe ? armed_probe() : nullptr;
+#define SVMC_RNG_SETS_CASE(P)                                                                                                    \
+    case P:                                                                                                                      \
+        if (tb == 256) launch_chain_rng_sets<P, 256>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset,   \
+                                                     x_snapshots, qvar_snapshots, workspace, probe);                            \
+        else if (tb == 512) launch_chain_rng_sets<P, 512>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3,           \
+                                                          path_offset, x_snapshots, qvar_snapshots, workspace, probe);          \
+        else launch_chain_rng_sets<(P <= 4 ? P : 4), 1024>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3,          \
+                                                           path_offset, x_snapshots, qvar_snapshots, workspace, probe);         \
+        break
     switch (n_sets) {
-    case 1: launch_chain_rng_sets<1>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 2: launch_chain_rng_sets<2>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 3: launch_chain_rng_sets<3>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 4: launch_chain_rng_sets<4>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 5: launch_chain_rng_sets<5>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 6: launch_chain_rng_sets<6>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    case 7: launch_chain_rng_sets<7>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
-    default: launch_chain_rng_sets<8>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, workspace); break;
+        SVMC_RNG_SETS_CASE(1);
+        SVMC_RNG_SETS_CASE(2);
+        SVMC_RNG_SETS_CASE(3);
+        SVMC_RNG_SETS_CASE(4);
+        SVMC_RNG_SETS_CASE(5);
+        SVMC_RNG_SETS_CASE(6);
+        SVMC_RNG_SETS_CASE(7);
+    default:
+        SVMC_RNG_SETS_CASE(8);
     }
+#undef SVMC_RNG_SETS_CASE
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
                        wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
@@ -1870,11 +1952,11 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
     c.L0 = log(v0) * K;
     if (brownians != nullptr)
         hipLaunchKernelGGL(logsv_vol_paths_kernel<false>, dim3(grid_for(n_path)), dim3(BLOCK), 0, as_stream(stream),
-                           sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb, seed, make_c3(call_id), path_offset);
+                           sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb, seed, make_c3(call_id), path_offset, armed_probe());
     else
         hipLaunchKernelGGL(logsv_vol_paths_kernel<true>, dim3(static_cast<unsigned>((n_path + VOLPATHS_RNG_BLOCK - 1) / VOLPATHS_RNG_BLOCK)),
                            dim3(VOLPATHS_RNG_BLOCK), 0, as_stream(stream), sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb,
-                           seed, make_c3(call_id), path_offset);
+                           seed, make_c3(call_id), path_offset, armed_probe());
     return check_launch("svmc_logsv_vol_paths");
 }
 
@@ -2202,11 +2284,26 @@ int svmc_heston_qe_terminal_w(double *x, double *var, double *qvar, size_t n_pat
     return check_launch("svmc_heston_qe_terminal_w");
 }
 
+int svmc_clock_probe_arm(int enable)
+{
+    uint64_t *&p = armed_probe();
+    if (enable && p == nullptr) {
+        SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), 8 * sizeof(uint64_t)));
+        SVMC_HIP_TRY(hipMemset(p, 0, 8 * sizeof(uint64_t)));
+    } else if (!enable && p != nullptr) {
+        SVMC_HIP_TRY(hipDeviceSynchronize());               // no launch that still stamps it
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    return SVMC_OK;
+}
+
 int svmc_clock_probe_read(uint64_t *stamps, svmc_stream_t stream)
 {
     SVMC_REQUIRE(stamps != nullptr, "svmc_clock_probe_read: null output");
+    SVMC_REQUIRE(armed_probe() != nullptr, "svmc_clock_probe_read: this thread has not armed the probe (svmc_clock_probe_arm)");
     SVMC_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
-    SVMC_HIP_TRY(hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_clock_probe), 8 * sizeof(uint64_t), 0, hipMemcpyDeviceToHost));
+    SVMC_HIP_TRY(hipMemcpy(stamps, armed_probe(), 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SVMC_OK;
 }
 

@@ -8,6 +8,8 @@ for 1 set (an objective evaluation, prices + implied vols) and 6, 7 and 8 sets (
 finite-difference gradient), and checks that the frozen route's prices are logsv_mc_chain_pricer(seed)'s bit for bit.
 
     python tools/r05/bench_frozen.py [nb_path] [calls]            one JSON line
+    python tools/r05/bench_frozen.py [nb_path] [calls] --shapes   the frozen route under each launch shape (block size x
+                                                                  one-block-per-CU padding), one JSON line per shape
 """
 import json
 import os
@@ -21,7 +23,28 @@ import numpy as np  # noqa: E402
 import stochvolmodels_amd as sv  # noqa: E402
 
 
+def clock_mhz_of_last_launch():
+    """the shader clock inside this thread's latest armed stepping launch (svmc_clock_probe_arm / _read)"""
+    import ctypes as C
+    from stochvolmodels_amd import _lib
+    st = (C.c_uint64 * 8)()
+    _lib.check(_lib.load().svmc_clock_probe_read(st, None))
+    t0, r0, t1, r1 = st[0:4]
+    return 100.0 * (t1 - t0) / (r1 - r0) if r1 > r0 else None
+
+
 def main():
+    if "--shapes" in sys.argv:
+        import subprocess
+        args = [a for a in sys.argv[1:] if a != "--shapes"]
+        for tb in ("256", "512", "1024"):
+            for ex in ("0", "1"):
+                env = dict(os.environ, SVMC_RNG_SETS_BLOCK=tb, SVMC_RNG_SETS_EXCLUSIVE=ex, SVMC_BENCH_FROZEN_ONLY="1")
+                run = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, env=env, capture_output=True, text=True)
+                line = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+                print(json.dumps({"block": int(tb), "one_block_per_cu": ex == "1", **(json.loads(line[-1])["frozen"] if line else
+                                                                                      {"error": run.stderr[-300:]})}), flush=True)
+        return
     nb_path = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
@@ -43,7 +66,8 @@ def main():
         return 1e3 * float(np.median(ts))
 
     out = {"nb_path": nb_path, "steps": None, "calls": calls}
-    for tag, in_hbm in (("frozen", False), ("hbm", True)):
+    routes = (("frozen", False),) if os.environ.get("SVMC_BENCH_FROZEN_ONLY") == "1" else (("frozen", False), ("hbm", True))
+    for tag, in_hbm in routes:
         res = sv.draw_fixed_randoms_on_device(ttms, nb_path=nb_path, nb_steps_per_year=360, seed=10, in_hbm=in_hbm)
         out["steps"] = int(sum(res.nb_steps))
 
@@ -63,6 +87,15 @@ def main():
                                             nb_steps_per_year=360, seed=10, **chain)
             row["bit_equal_to_logsv_mc_chain_pricer"] = bool(all(np.array_equal(a, b) for a, b in zip(got[0] + got[1], want[0] + want[1])))
             row["hbm_bytes_held_for_randoms"] = 0
+            from stochvolmodels_amd import _lib
+            _lib.check(_lib.load().svmc_clock_probe_arm(1))
+            from stochvolmodels_amd.engine import option_type_codes
+            q0 = sets[0]
+            for _ in range(30):            # un-replayed launches (a captured launch never carries the probe)
+                res.price_logsv_chain(ttms, chain["forwards"], chain["discfactors"], [k] * 4, [option_type_codes(ty)] * 4, q0.sigma0,
+                                      q0.theta, q0.kappa1, q0.kappa2, q0.beta, q0.volvol, np.ones(4), True, 1, use_graph=False)
+            row["clock_mhz_in_kernel_one_set"] = clock_mhz_of_last_launch()
+            _lib.check(_lib.load().svmc_clock_probe_arm(0))
         else:
             row["hbm_bytes_held_for_randoms"] = int(16 * nb_path * out["steps"])
         out[tag] = row
