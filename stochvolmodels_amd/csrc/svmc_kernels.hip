@@ -651,28 +651,30 @@ struct ChainRngSetsSlices {
 constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(double));
 
 //
-// Launch shape.  A calibration-sized path set (10^5 paths = 1563 waves) is LESS than one wave per SIMD pair of the chip, and the
-// step is a dependent chain of ~20 fp64 operations around an LDS round trip: what matters is that the waves are spread over
-// ALL the SIMDs, each with about two of them to overlap (the dispatcher packs blocks onto a CU as long as its LDS and
-// registers last -- four 256-thread blocks of this kernel fit one CU -- and the packed CUs then run 4 waves per SIMD while
-// others idle).  So: TB threads per block (256 / 512 / 1024) chosen by the launcher so that the grid is at most one block
-// per CU where the path count allows, and `lds_pad` bytes of unused dynamic LDS that make a second block on the same CU
-// impossible in that case (profiles/r05_frozen_launch_shape.txt).
-template <int P, int TB>
-__global__ __launch_bounds__(TB) void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs,
-                                                                  const LogsvFast *__restrict__ consts,
-                                                                  const double *__restrict__ init, uint64_t seed, uint32_t c3,
-                                                                  uint64_t path_offset, uint32_t step_offset,
-                                                                  double *__restrict__ x_snap, double *__restrict__ q_snap,
-                                                                  double *__restrict__ partials, uint64_t *probe)
+// Latency, not issue, bounds a calibration-sized launch: 10^5 paths are 1563 waves for 1024 SIMDs, one or two per SIMD, and a
+// step is a dependent chain of about twenty fp64 operations around an LDS round trip.  Hence (profiles/r05_frozen_*.txt):
+//   * the register allocator is told the launch runs one or two waves per SIMD (amdgpu_waves_per_eu(1, 2): 256 registers) --
+//     left at its default it schedules for eight, reuses a handful of registers for every LDS read and waits for each read
+//     before issuing the next (185 full lgkmcnt waits per trip at P = 8);
+//   * the step runs piece by piece across the P states (logsv_step_acc_sets), all P exp-table reads in flight together;
+//   * an interior Philox call turns all four of its words into normals before the first of its two steps (eight table reads
+//     in flight), the edge calls of a slice that starts or ends on an odd step take the one half they own -- which
+//     (path, step) sees which word is rng_time_loop's rule, unchanged;
+//   * the (slice, set) constants are plain loads from the block's LDS copy: loop-invariant, the compiler keeps them in
+//     registers across the time loop where the budget allows and re-reads them where it does not.
+// The launch shape (block size, one block per CU) was measured NOT to matter: the dispatcher spreads 391 blocks evenly.
+template <int P>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFast *__restrict__ consts,
+                                 const double *__restrict__ init, uint64_t seed, uint32_t c3, uint64_t path_offset,
+                                 uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                 double *__restrict__ partials, uint64_t *probe)
 {
-    constexpr int BLOCK = TB;                              // shadows the file-wide block size inside this kernel
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     __shared__ LogsvFast s_c[P];
     const RngTables tab = stage_tables(s_tab, s_exp);
     clock_probe_stamp(probe, 0);
-    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };     // L is carried in units of ln2/256
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
     double xv[P], sg[P], q[P];
@@ -695,24 +697,45 @@ __global__ __launch_bounds__(TB) void logsv_chain_rng_sets_kernel(size_t n, Chai
         }
         __syncthreads();
         const int nb = cs.nb_steps[i];
-        double L[P], acc[P], xacc[P], s2_start[P];
+        double L[P], acc[P], xacc[P], s2_start[P], k1[P], k2[P], k3[P], kb[P], ke[P];
 #pragma unroll
         for (int s = 0; s < P; ++s) {
             L[s] = log_state(sg[s]) * LOG_UNITS_PER_NAT;                                              // :1039
             s2_start[s] = square_rn(sg[s]);
             acc[s] = 0.0;
             xacc[s] = 0.0;
+            k1[s] = s_c[s].c1;
+            k2[s] = s_c[s].c2;
+            k3[s] = s_c[s].c3;
+            kb[s] = s_c[s].bs;
+            ke[s] = s_c[s].es;
         }
-        rng_time_loop(lane, tg, nb, tab, [&](double z0, double z1) {
-            unsigned zero = 0;                             // opaque: the constants are re-read from LDS, not hoisted
-            asm volatile("" : "+v"(zero));
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                const LogsvFast &c = s_c[s + zero];
-                double s2_unused = 0.0;
-                logsv_step_acc(c, xacc[s], L[s], sg[s], s2_unused, acc[s], z0, z1, exp_of);
+        const auto step = [&](double z0, double z1) { logsv_step_acc_sets<P>(k1, k2, k3, kb, ke, xacc, L, sg, acc, z0, z1, s_exp); };
+        if (nb > 0) {
+            // rng_time_loop's rule -- call c serves the steps 2c (words 0, 1) and 2c + 1 (words 2, 3) -- as an odd-start half
+            // call, the full calls, an even-end half call
+            const uint32_t first = tg, last = tg + static_cast<uint32_t>(nb) - 1u;
+            uint32_t c = first >> 1, r[4];
+            double a0, a1, b0, b1;
+            if (first & 1u) {
+                philox_draw(lane, c, r);
+                normals_from_words(r[2], r[3], tab, b0, b1);
+                step(b0, b1);
+                ++c;
             }
-        });
+            for (const uint32_t c_end = (last + 1u) >> 1; c < c_end; ++c) {
+                philox_draw(lane, c, r);
+                normals_from_words(r[0], r[1], tab, a0, a1);
+                normals_from_words(r[2], r[3], tab, b0, b1);
+                step(a0, a1);
+                step(b0, b1);
+            }
+            if (!(last & 1u)) {
+                philox_draw(lane, last >> 1, r);
+                normals_from_words(r[0], r[1], tab, a0, a1);
+                step(a0, a1);
+            }
+        }
         tg += static_cast<uint32_t>(nb);
 #pragma unroll
         for (int s = 0; s < P; ++s) {
@@ -1776,58 +1799,15 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
 // P parameter sets of a chain on randoms regenerated from (seed, call_id) in one launch + one column reduce
 // (svmc_logsv_chain_price_frozen_sets): consts_dev = [m][P] LogsvFast in log units (logsv_fast_to_doubles), vol0_dev = [P];
 // snapshots [P m][n] set-major, spot_sums [P m][2]
-template <int P, int TB>
-static void launch_chain_rng_sets(unsigned g, size_t lds_pad, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs,
+template <int P>
+static void launch_chain_rng_sets(unsigned g, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs,
                                   const double *consts_dev, const double *vol0_dev, uint64_t seed, uint32_t c3,
                                   uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace,
                                   uint64_t *probe)
 {
-    if (lds_pad != 0) {            // once per instantiation: let the launch ask for more dynamic LDS than the default allowance
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&logsv_chain_rng_sets_kernel<P, TB>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
-        (void)attr;
-    }
-    hipLaunchKernelGGL((logsv_chain_rng_sets_kernel<P, TB>), dim3(g), dim3(TB), lds_pad, stream, n_path, cs,
+    hipLaunchKernelGGL(logsv_chain_rng_sets_kernel<P>, dim3(g), dim3(BLOCK), 0, stream, n_path, cs,
                        reinterpret_cast<const LogsvFast *>(consts_dev), vol0_dev, seed, c3, path_offset, 0u, x_snapshots,
                        qvar_snapshots, static_cast<double *>(workspace), probe);
-}
-
-// threads per block and LDS padding of a frozen-sets launch (see the kernel): the smallest block size that puts the whole
-// path set into at most one block per CU -- then every block gets a CU of its own -- and, failing that, the plain 256.
-// SVMC_RNG_SETS_BLOCK / SVMC_RNG_SETS_EXCLUSIVE override the choice (tools/r05/bench_frozen.py sweeps them).
-static void rng_sets_launch_shape(size_t n_path, int n_sets, int &tb, size_t &lds_pad)
-{
-    static const int env_tb = std::getenv("SVMC_RNG_SETS_BLOCK") ? std::atoi(std::getenv("SVMC_RNG_SETS_BLOCK")) : 0;
-    static const int env_ex = std::getenv("SVMC_RNG_SETS_EXCLUSIVE") ? std::atoi(std::getenv("SVMC_RNG_SETS_EXCLUSIVE")) : -1;
-    static int n_cu = 0;
-    static size_t lds_per_block = 64 << 10;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
-            n_cu = prop.multiProcessorCount;
-            lds_per_block = prop.sharedMemPerBlock;
-        }
-    }
-    const int max_tb = (n_sets >= 5) ? 512 : 1024;         // 1024 threads = 4 waves per SIMD = 128 registers; 5+ sets need more
-    tb = 256;
-    bool fits = false;
-    for (int cand = 256; cand <= max_tb; cand *= 2)
-        if ((n_path + cand - 1) / cand <= static_cast<size_t>(n_cu)) {
-            tb = cand;
-            fits = true;
-            break;
-        }
-    if (env_tb == 256 || env_tb == 512 || (env_tb == 1024 && max_tb == 1024)) {
-        tb = env_tb;
-        fits = (n_path + tb - 1) / tb <= static_cast<size_t>(n_cu);
-    }
-    const bool exclusive = (env_ex >= 0) ? (env_ex != 0) : fits;
-    // the kernel's static LDS is 35 KB: 48 KB more and two blocks exceed a CU's 160 KB (2 x 83); where a block may not hold
-    // that much, as much as it may (then two blocks fit a CU, three do not)
-    const size_t want = 48u << 10, room = lds_per_block > (37u << 10) ? lds_per_block - (37u << 10) : 0;
-    lds_pad = exclusive ? (want < room ? want : room) : 0;
 }
 
 int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
@@ -1851,19 +1831,12 @@ int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_
         cs.nb_steps[i] = (i < n_slices) ? nb_steps_host[j] : 0;
     }
     const uint32_t c3 = make_c3(call_id);
-    int tb = 256;
-    size_t pad = 0;
-    rng_sets_launch_shape(n_path, n_sets, tb, pad);
-    const unsigned g = static_cast<unsigned>((n_path + tb - 1) / tb);
+    const unsigned g = grid_for(n_path);
     uint64_t *probe = allow_probe ? armed_probe() : nullptr;
-#define SVMC_RNG_SETS_CASE(P)                                                                                                    \
-    case P:                                                                                                                      \
-        if (tb == 256) launch_chain_rng_sets<P, 256>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset,   \
-                                                     x_snapshots, qvar_snapshots, workspace, probe);                            \
-        else if (tb == 512) launch_chain_rng_sets<P, 512>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3,           \
-                                                          path_offset, x_snapshots, qvar_snapshots, workspace, probe);          \
-        else launch_chain_rng_sets<(P <= 4 ? P : 4), 1024>(g, pad, stream, n_path, cs, consts_dev, vol0_dev, seed, c3,          \
-                                                           path_offset, x_snapshots, qvar_snapshots, workspace, probe);         \
+#define SVMC_RNG_SETS_CASE(P)                                                                                                   \
+    case P:                                                                                                                     \
+        launch_chain_rng_sets<P>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, \
+                                 workspace, probe);                                                                             \
         break
     switch (n_sets) {
         SVMC_RNG_SETS_CASE(1);

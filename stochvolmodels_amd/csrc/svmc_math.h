@@ -215,18 +215,37 @@ SVMC_HD double exp_tab(double x, const double *tab)
 // -- and the accuracy no longer depends on the size of the argument: 2^(r/256) - 1 = r E(r) with a cubic E (5e-18),
 // the table and the scaling as in exp_tab.  11 instructions, three of them plain adds where exp_tab has FMAs, and
 // both constants of the reduction are gone (exp_tab needs one of its two in a VGPR pair).  <= 1.1 ULP.
-SVMC_HD double exp2u_tab(double y, const double *tab)
+// ... in three pieces, so that a kernel that advances SEVERAL independent states per lane can run each piece for all of
+// them (all the table reads in flight together) and still perform, per state, exactly these operations in this order:
+//   exp2u_reduce: n = rint(y) (returned as an integer), r = y - n;  exp2u_tail: r E(r);  exp2u_scale: 2^(n >> 8) T (1 + tail)
+SVMC_HD void exp2u_reduce(double y, int &ni, double &r)
 {
     const double kf = y + 0x1.8p+52;
-    const int ni = static_cast<int>(double_lo(kf));
-    const double r = y - (kf - 0x1.8p+52);
-    const double t = tab[ni & 255];
+    ni = static_cast<int>(double_lo(kf));
+    r = y - (kf - 0x1.8p+52);
+}
+
+SVMC_HD double exp2u_tail(double r)
+{
     double q = 0x1.3b2ab8452c312p-39;
     q = fma_k(q, r, 0x1.c6b0903967234p-29);
     q = fma_k(q, r, 0x1.ebfbdff82c584p-19);
     q = fma_k(q, r, 0x1.62e42fefa39d8p-9);
-    const double p = q * r;
+    return q * r;
+}
+
+SVMC_HD double exp2u_scale(double t, double p, int ni)
+{
     return ldexp(fma(t, p, t), ni >> 8);
+}
+
+SVMC_HD double exp2u_tab(double y, const double *tab)
+{
+    int ni;
+    double r;
+    exp2u_reduce(y, ni, r);
+    const double t = tab[ni & 255];
+    return exp2u_scale(t, exp2u_tail(r), ni);
 }
 
 // -ln(u) for any positive normal u (the RNG calls it on (0,1); Heston QE on arguments around 1).  u = m 2^k with m in [sqrt(1/2), sqrt(2)) taken from the exponent field,

@@ -152,6 +152,44 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc,
     (void)s2;                                     // sigma^2 is not carried: the fold squares the terminal sigma itself
 }
 
+// logsv_step_acc for P independent states of one lane (P parameter sets on the same two normals), piece by piece ACROSS the
+// states: the reciprocals, the five updates of L, the exp's reduction, all P table reads, the tails, the scalings.  Per
+// state these are logsv_step_acc's operations in logsv_step_acc's order -- the same bits -- but the P dependent chains
+// (about twenty fp64 operations around an LDS round trip each) now overlap instead of running one after the other.
+template <int P>
+__device__ __forceinline__ void logsv_step_acc_sets(const double (&c1)[P], const double (&c2)[P], const double (&c3)[P],
+                                                    const double (&bs)[P], const double (&es)[P], double (&xacc)[P],
+                                                    double (&L)[P], double (&sigma)[P], double (&acc)[P], double z0, double z1,
+                                                    const double *exp_table)
+{
+    double y[P], r[P], t[P];
+    int ni[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) y[s] = rcp_1n(sigma[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) xacc[s] = fma(sigma[s], z0, xacc[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        double l = fma(c2[s], sigma[s], L[s]);
+        l = fma(c1[s], y[s], l);
+        l = l + c3[s];
+        l = fma(bs[s], z0, l);
+        L[s] = fma(es[s], z1, l);
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s) exp2u_reduce(L[s], ni[s], r[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) t[s] = exp_table[ni[s] & 255];
+#pragma unroll
+    for (int s = 0; s < P; ++s) r[s] = exp2u_tail(r[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const double sn = exp2u_scale(t[s], r[s], ni[s]);
+        acc[s] = fma(sn, sn, acc[s]);
+        sigma[s] = sn;
+    }
+}
+
 // sigma^2 as a rounded product of its own: without this the compiler may fuse the multiplication into the subtraction of
 // logsv_fold_acc (s2_start - sigma_T^2 as one FMA) in one kernel and not in another -- whichever way the inlined code around
 // it falls -- and the one-slice, whole-chain and streamed generators must agree to the bit (a persistent-launch variant of

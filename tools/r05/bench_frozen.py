@@ -8,8 +8,6 @@ for 1 set (an objective evaluation, prices + implied vols) and 6, 7 and 8 sets (
 finite-difference gradient), and checks that the frozen route's prices are logsv_mc_chain_pricer(seed)'s bit for bit.
 
     python tools/r05/bench_frozen.py [nb_path] [calls]            one JSON line
-    python tools/r05/bench_frozen.py [nb_path] [calls] --shapes   the frozen route under each launch shape (block size x
-                                                                  one-block-per-CU padding), one JSON line per shape
 """
 import json
 import os
@@ -34,17 +32,6 @@ def clock_mhz_of_last_launch():
 
 
 def main():
-    if "--shapes" in sys.argv:
-        import subprocess
-        args = [a for a in sys.argv[1:] if a != "--shapes"]
-        for tb in ("256", "512", "1024"):
-            for ex in ("0", "1"):
-                env = dict(os.environ, SVMC_RNG_SETS_BLOCK=tb, SVMC_RNG_SETS_EXCLUSIVE=ex, SVMC_BENCH_FROZEN_ONLY="1")
-                run = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, env=env, capture_output=True, text=True)
-                line = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
-                print(json.dumps({"block": int(tb), "one_block_per_cu": ex == "1", **(json.loads(line[-1])["frozen"] if line else
-                                                                                      {"error": run.stderr[-300:]})}), flush=True)
-        return
     nb_path = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
