@@ -653,7 +653,7 @@ constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(d
 //
 // Latency, not issue, bounds a calibration-sized launch: 10^5 paths are 1563 waves for 1024 SIMDs, one or two per SIMD, and a
 // step is a dependent chain of about twenty fp64 operations around an LDS round trip.  Hence (profiles/r05_frozen_*.txt):
-//   * the register allocator is told the launch runs one or two waves per SIMD (amdgpu_waves_per_eu(1, 2): 256 registers) --
+//   * the register allocator is told the launch runs two waves per SIMD (amdgpu_waves_per_eu(2, 2): 256 registers) --
 //     left at its default it schedules for eight, reuses a handful of registers for every LDS read and waits for each read
 //     before issuing the next (185 full lgkmcnt waits per trip at P = 8);
 //   * the step runs piece by piece across the P states (logsv_step_acc_sets), all P exp-table reads in flight together;
@@ -664,7 +664,7 @@ constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(d
 //     registers across the time loop where the budget allows and re-reads them where it does not.
 // The launch shape (block size, one block per CU) was measured NOT to matter: the dispatcher spreads 391 blocks evenly.
 template <int P>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFast *__restrict__ consts,
                                  const double *__restrict__ init, uint64_t seed, uint32_t c3, uint64_t path_offset,
                                  uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
@@ -673,6 +673,11 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     __shared__ LogsvFast s_c[P];
+    // six and more sets: x and qvar -- dead inside the time loop, live across it -- are parked in LDS (lane t owns its own
+    // 2 P words, no barrier), as the whole-chain generator does: with them the eight-set kernel needed 266 registers, one
+    // wave per SIMD, and a 10^5-path launch then runs in two rounds
+    constexpr bool PARK = P >= 6;
+    __shared__ double s_park[PARK ? 2 * P * BLOCK : 1];
     const RngTables tab = stage_tables(s_tab, s_exp);
     clock_probe_stamp(probe, 0);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
@@ -683,6 +688,10 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
         xv[s] = 0.0;
         sg[s] = init[s];
         q[s] = 0.0;
+        if constexpr (PARK) {
+            s_park[(2 * s) * BLOCK + threadIdx.x] = 0.0;
+            s_park[(2 * s + 1) * BLOCK + threadIdx.x] = 0.0;
+        }
     }
     // every lane steps (the lanes past the last path on a real path's counter: their results are never stored)
     const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
@@ -723,6 +732,8 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
                 step(b0, b1);
                 ++c;
             }
+            // (drawing call c + 1's normals while call c's steps run -- the draw does not depend on the state -- was measured
+            // and is SLOWER, 100 -> 115 us at one set: the scheduler does not interleave the two, the registers cost)
             for (const uint32_t c_end = (last + 1u) >> 1; c < c_end; ++c) {
                 philox_draw(lane, c, r);
                 normals_from_words(r[0], r[1], tab, a0, a1);
@@ -740,7 +751,15 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
 #pragma unroll
         for (int s = 0; s < P; ++s) {
             const LogsvFast c = s_c[s];
+            if constexpr (PARK) {
+                xv[s] = s_park[(2 * s) * BLOCK + threadIdx.x];
+                q[s] = s_park[(2 * s + 1) * BLOCK + threadIdx.x];
+            }
             logsv_fold_acc(c, xv[s], q[s], xacc[s], acc[s], s2_start[s], square_rn(sg[s]));
+            if constexpr (PARK) {
+                s_park[(2 * s) * BLOCK + threadIdx.x] = xv[s];
+                s_park[(2 * s + 1) * BLOCK + threadIdx.x] = q[s];
+            }
             const int row = s * cs.m + i;
             const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
                                  partials + 2 * static_cast<size_t>(row) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
