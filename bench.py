@@ -32,6 +32,16 @@ the CPU oracle (a port of the reference's algorithm) timed on one host core on a
 Every line carries `c_abi_route`: the same workload through ONE call of the fused C driver svmc_logsv_chain_price per step
 (the boundary's headline entry point; include/svmc.h), its prices compared with the Python route's.
 
+The collective layer of an N > 1 run is chosen by a LADDER (stochvolmodels_amd.dist.init_with_fallback): a gloo control
+plane first, then torch's RCCL backend -> libsvmc's own RCCL entry points -> the gloo group itself, each rung probed in a child
+process under a deadline before the ranks commit to it -- a node whose RCCL fails or hangs still yields a number, flagged
+(`comm_ladder.rung`, `comm_fallback_reason`).  `single_process_route` = the same job by ONE process driving all N devices
+(svmc_multi_*: a host thread and a session per device), run as a child of rank 0 after the timed region.
+`python bench.py --gpus N --single-process` times that route on its own.
+At N = 1 the line ends with `secondary`: the other BASELINE configurations in compact form -- C1, C3 (Euler and QE, both
+parameter sets), C5 (analytic batch, Monte Carlo per set, the reference's 4-stderr verdict), the frozen-randoms calibration
+objective (f3) and C2's rate at 2^21 paths -- each with a parity scalar against the oracle on the same stream at a reduced size.
+
 The N > 1 line PROVES ITSELF (exit status != 0 when a proof fails, the line still printed with `self_check.failed`):
 `sharded_vs_one_gpu_max_rel_dev` -- the sharded job and the whole job on rank 0's device, same seed, must agree to
 reduction-order rounding (<= 1e-12); on the RCCL backend `rccl_ranks_seen` must equal --gpus; `kernel_ms_over_ranks`
@@ -85,9 +95,8 @@ INT32_IN_FP64_STREAM_CYCLES = 3.9
 # generation-2 garbage collection -- profiles/r03_gc_stall.json: gc callbacks put a 53-67 ms full collection exactly there
 # -- and the timed region now runs after gc.collect() + gc.freeze(), as any latency-sensitive Python service does.)
 PREWARM = int(os.environ.get("SVMC_BENCH_PREWARM", "10"))         # the environment override exists for the test suite
-# SURVEY.md 8(d)'s ESTIMATE of the algorithmic work per LogSV path-step in fp64 op-equivalents (34 simple flops + div 10
-# + sqrt 10 + exp/log/sincos 25 each + Philox/conversion ~ 11): a model of the reference's arithmetic, not a count
-LOGSV_FLOP_EQ_PER_PATH_STEP = 140.0
+# (SURVEY.md 8d's flop-equivalent ESTIMATE -- 140 op-eq per path-step, a model of the reference's Box-Muller arithmetic -- is no
+# longer printed: the kernel draws by table inversion and the model's "fraction" exceeded 1 by construction)
 
 
 def parse():
@@ -104,6 +113,13 @@ def parse():
     ap.add_argument("--no-self-check", action="store_true",
                     help="N > 1: skip the sharded-vs-one-GPU price comparison (it prices the whole job on rank 0's device)")
     ap.add_argument("--cpu-sample-paths", type=int, default=1 << 19)
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives all --gpus devices (svmc_multi_*: a host thread and a session per device)")
+    ap.add_argument("--reduce", choices=("auto", "host", "rccl"), default="auto",
+                    help="--single-process: transport of the two all-reduces (auto = RCCL when its probe passes, else host)")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ids (default 0..N-1)")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the `secondary` block (C1, C3, C5, f3)")
+    ap.add_argument("--no-single-process-leg", action="store_true", help="N > 1: skip the single_process_route leg")
     return ap.parse_args()
 
 
@@ -137,12 +153,12 @@ def make_workload(name: str, sv):
                 grids=grids, nb_total=sum(g[0] for g in grids), n_strikes=sum(len(k) for k in strikes))
 
 
-def price(sv, wl, P, n_path, seed, comm=None):
+def price(sv, wl, P, n_path, seed, comm=None, devices=None, reduce=None):
     return sv.logsv_mc_chain_pricer(ttms=wl["ttms"], forwards=wl["forwards"], discfactors=wl["dfs"],
                                     strikes_ttms=wl["strikes"], optiontypes_ttms=wl["types"], v0=P.sigma0, theta=P.theta,
                                     kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta, volvol=P.volvol,
                                     vol_backbone_etas=np.ones(len(wl["ttms"])), nb_path=n_path,
-                                    nb_steps_per_year=wl["spy"], seed=seed, comm=comm)
+                                    nb_steps_per_year=wl["spy"], seed=seed, comm=comm, devices=devices, reduce=reduce)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -356,8 +372,7 @@ def clock_from_stamps(stamps) -> dict:
 
 def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, isa, pmc, clock_mhz, stamps=None) -> dict:
     """the stepping kernel of one chain call against (a) the VALU issue port -- the roof that binds it: the time loop's
-    instructions by opcode class (from the loaded library's assembly) x the measured issue cost of each class, (b) HBM,
-    (c) SURVEY's flop-equivalent estimate"""
+    instructions by opcode class (from the loaded library's assembly) x the measured issue cost of each class, (b) HBM"""
     nb, m = wl["nb_total"], len(wl["grids"])
     hist = isa["kernels"].get(kernel, {})
     prof = pmc.get(kernel, {})
@@ -430,14 +445,6 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
     out["roofline_hbm"] = hbm
     if "roofline" not in out:                  # no histogram for this kernel (libsvmc.isa.json missing): report the HBM roof
         out["roofline"] = dict(hbm, stale=True)
-    rate = n_local * nb / (k_ms * 1e-3)
-    out["roofline_valu_flop_estimate"] = {
-        "kernel": kernel, "bound": "valu_fp64", "achieved": rate * LOGSV_FLOP_EQ_PER_PATH_STEP / 1e12,
-        "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": rate * LOGSV_FLOP_EQ_PER_PATH_STEP / 1e12 / FP64_VALU_PEAK_TFLOPS,
-        "flop_eq_per_path_step": LOGSV_FLOP_EQ_PER_PATH_STEP, "kernel_path_steps_per_s": rate,
-        "note": "ESTIMATE: SURVEY.md 8d's model of the reference's arithmetic (140 fp64 op-equivalents per path-step), "
-                "not instructions this kernel executes -- it rises as the kernel does less; `roofline` is the measured one"}
     return out
 
 
@@ -563,6 +570,263 @@ def c_abi_route_leg(make_chain, python_step, calls: int, n_paths_job: int, nb: i
         chain.close()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# `secondary`: the other BASELINE configurations, compact, each with a parity scalar against the oracle (N = 1 only)
+# ---------------------------------------------------------------------------------------------------------------
+C5_SETS = (("btc", None), ("readme", dict(sigma0=0.8327, theta=1.0139, kappa1=4.8609, kappa2=4.7940, beta=0.1988, volvol=2.3694)),
+           ("quick", dict(sigma0=1.0, theta=1.0, kappa1=5.0, kappa2=5.0, beta=0.2, volvol=2.0)),
+           ("test", dict(sigma0=0.2, theta=0.22, kappa1=3.0, kappa2=12.0, beta=-0.3, volvol=0.4)),
+           ("fig3", dict(sigma0=1.5, theta=1.0, kappa1=4.0, kappa2=4.0, beta=0.0, volvol=1.5)))
+
+
+def _sig(v, digits=4):
+    return float(f"{float(v):.{digits}g}")
+
+
+def _median_ms(fn, reps, warm):
+    import ctypes as C  # noqa: F401
+    from stochvolmodels_amd import _lib
+    sync = lambda: _lib.load().svmc_stream_synchronize(None)          # noqa: E731
+    for _ in range(warm):
+        fn()
+    sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        sync()
+        ts.append(time.perf_counter() - t0)
+    return 1e3 * float(np.median(ts)), out
+
+
+def _prices_dev(got, ref, floor):
+    """largest |gpu - oracle| / (|oracle| + floor) over a chain's prices"""
+    g, o = np.concatenate([np.ravel(a) for a in got]), np.concatenate([np.ravel(a) for a in ref])
+    return float(np.max(np.abs(g - o) / (np.abs(o) + floor)))
+
+
+def secondary_block(sv, P) -> dict:
+    """BASELINE configs 1, 3, 5 and the rows the default line does not time, in the line's own process.  Every
+    figure is the median wall time of whole product calls; every `dev` is the largest deviation of the GPU's PRICES from the
+    oracle's on the SAME counter-based stream at a reduced path count (the full-size comparisons are tests/test_gpu_fullsize.py).
+    Compact on purpose: the block is the END of the line, the part a truncating log keeps."""
+    from oracle import oracle                              # the checker of the parity scalars, never the thing timed
+    from stochvolmodels_amd.engine import get_engine
+    oracle.build()
+    oracle.set_threads(oracle.effective_cores())
+    t_start = time.perf_counter()
+    out = {"note": "ms = median wall time of one product call; psps = path-steps/s; dev = max |gpu - oracle| / (|oracle| + 1e-3 F) "
+                   "of the prices at n_dev paths, same stream"}
+    n_dev = 1 << 14
+    kk = np.linspace(0.5, 1.5, 21)
+    types = np.where(kk >= 1.0, "C", "P")
+
+    # ---- C1: Heston Euler, 10 000 paths x 100 steps, 5 strikes (the reference's CPU-runnable case)
+    k5, t5 = np.array([0.8, 0.9, 1.0, 1.1, 1.2]), np.array(["P", "P", "C", "C", "C"])
+    h0 = dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)
+    c1 = dict(ttms=np.array([1.0]), forwards=np.ones(1), discfactors=np.ones(1), strikes_ttms=(k5,), optiontypes_ttms=(t5,))
+    ms, (pr, _) = _median_ms(lambda: sv.heston_mc_chain_pricer(nb_path=10_000, nb_steps_per_year=99, seed=20240601, **c1, **h0), 20, 3)
+    x, v, q = oracle.heston_terminal_rng(np.zeros(10_000), h0["v0"] * np.ones(10_000), np.zeros(10_000), 100, 0.01, h0["theta"],
+                                         h0["kappa"], h0["rho"], h0["volvol"], 20240601)
+    opr, _ = oracle.payoff(x, q, 1.0, 1.0, k5, t5)
+    out["c1"] = {"ms": _sig(ms), "psps": _sig(1e6 / (ms * 1e-3)), "dev": _sig(_prices_dev(pr, [opr], 1e-3), 2)}
+
+    # ---- C3: Heston, 2^22 paths x 4 x 128 steps, 4 x 21 strikes; Euler (the reference's scheme) and QE, both parameter sets
+    ttms = np.array([0.25, 0.5, 0.75, 1.0])
+    chain4 = dict(ttms=ttms, forwards=np.ones(4), discfactors=np.ones(4), strikes_ttms=(kk,) * 4, optiontypes_ttms=(types,) * 4)
+    hb = sv.BTC_HESTON_PARAMS
+    c3 = {"paths": 1 << 22, "steps": 512, "n_dev": n_dev}
+    for tag, par in (("base", h0), ("btc", dict(v0=hb.v0, theta=hb.theta, kappa=hb.kappa, rho=hb.rho, volvol=hb.volvol))):
+        for scheme in ("euler", "qe"):
+            ms, _ = _median_ms(lambda: sv.heston_mc_chain_pricer(nb_path=1 << 22, scheme=scheme, nb_steps_per_year=508, seed=20240603,
+                                                                 **chain4, **par), 3, 1)
+            pr, _ = sv.heston_mc_chain_pricer(nb_path=n_dev, scheme=scheme, nb_steps_per_year=508, seed=20240603, **chain4, **par)
+            x, v, q = np.zeros(n_dev), par["v0"] * np.ones(n_dev), np.zeros(n_dev)
+            ref, step0 = [], 0
+            for ttm in ttms:
+                x, v, q = oracle.heston_terminal_rng(x, v, q, 128, 0.25 / 128, par["theta"], par["kappa"], par["rho"], par["volvol"],
+                                                     20240603, scheme=oracle.HESTON_QE if scheme == "qe" else oracle.HESTON_EULER_FLOOR,
+                                                     step_offset=step0)
+                ref.append(oracle.payoff(x, q, float(ttm), 1.0, kk, types)[0])
+                step0 += 128
+            c3[f"{scheme}_{tag}"] = {"ms": _sig(ms), "psps": _sig((1 << 22) * 512 / (ms * 1e-3)), "dev": _sig(_prices_dev(pr, ref, 1e-3), 2)}
+    out["c3"] = c3
+
+    # ---- C5: five parameter sets; analytic chain of all five in one batch; 2^23-path Monte Carlo per set; the reference's verdict
+    t5_ = np.arange(1, 5) / 8.0                            # C4's first four expiries: ttm = k / 8
+    fw = 67000.0 * np.exp(0.05 * t5_)
+    strikes5 = tuple(f * np.linspace(0.6, 1.6, 21) for f in fw)
+    types5 = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes5, fw))
+    chain5 = dict(ttms=t5_, forwards=fw, discfactors=np.exp(-0.05 * t5_), strikes_ttms=strikes5, optiontypes_ttms=types5)
+    sets = [P if v is None else sv.LogSvParams(**v) for _, v in C5_SETS]
+    oc = sv.OptionChain(ttms=t5_, forwards=fw, strikes_ttms=strikes5, optiontypes_ttms=types5, ids=None, discfactors=chain5["discfactors"])
+    pricer = sv.LogSVPricer()
+    ms_an, an = _median_ms(lambda: pricer.price_chain_batch(oc, sets), 5, 1)
+    c5 = {"paths": 1 << 23, "steps": 512, "sets": [t for t, _ in C5_SETS], "analytic_batch_ms": _sig(ms_an), "mc_ms": [], "dev": [],
+          "pass_of_84": [], "n_dev": n_dev}
+    for p_, a_ in zip(sets, an):
+        kw = dict(v0=p_.sigma0, theta=p_.theta, kappa1=p_.kappa1, kappa2=p_.kappa2, beta=p_.beta, volvol=p_.volvol,
+                  vol_backbone_etas=np.ones(4), nb_steps_per_year=1016, seed=20240610, **chain5)
+        ms, (pr, sd) = _median_ms(lambda: sv.logsv_mc_chain_pricer(nb_path=1 << 23, **kw), 2, 1)
+        z = (np.stack(pr) - np.stack(a_)) / np.where(np.stack(sd) > 0, np.stack(sd), np.nan)
+        c5["mc_ms"].append(_sig(ms))
+        c5["pass_of_84"].append(int(np.sum(np.abs(z) <= 4.0)))     # |analytic - MC| <= 4 stderr, the reference's criterion
+        pr, _ = sv.logsv_mc_chain_pricer(nb_path=n_dev, **kw)
+        x, s_, q = np.zeros(n_dev), p_.sigma0 * np.ones(n_dev), np.zeros(n_dev)
+        ref, step0 = [], 0
+        for i, ttm in enumerate(t5_):
+            x, s_, q = oracle.logsv_terminal_rng(x, s_, q, 128, 0.125 / 128, p_.theta, p_.kappa1, p_.kappa2, p_.beta, p_.volvol,
+                                                 20240610, step_offset=step0)
+            ref.append(oracle.payoff(x, q, float(ttm), float(fw[i]), strikes5[i], types5[i], float(chain5["discfactors"][i]))[0])
+            step0 += 128
+        c5["dev"].append(_sig(_prices_dev(pr, ref, 1e-3 * float(fw[0])), 2))
+    c5["mc_psps"] = _sig((1 << 23) * 512 / (np.mean(c5["mc_ms"]) * 1e-3))
+    o_an = oracle.logsv_chain_pricer(sets[0], t5_, fw, chain5["discfactors"], strikes5, types5)
+    c5["analytic_dev_btc"] = _sig(_prices_dev(an[0], o_an, 1e-3 * float(fw[0])), 2)
+    out["c5"] = c5
+
+    # ---- f3: one calibration objective evaluation on FROZEN randoms (nothing resident), 4 x 13 chain, 10^5 paths x 364 steps
+    tt = np.array([1 / 12, 0.25, 0.5, 1.0])
+    k13 = np.linspace(0.7, 1.3, 13)
+    ch = dict(ttms=tt, forwards=np.ones(4), discfactors=np.ones(4), strikes_ttms=(k13,) * 4, optiontypes_ttms=(np.where(k13 >= 1.0, "C", "P"),) * 4)
+    res = sv.draw_fixed_randoms_on_device(tt, nb_path=100_000, nb_steps_per_year=360, seed=10)
+    bumped = [sv.LogSvParams(sigma0=P.sigma0 + 1e-3 * j, theta=P.theta, kappa1=P.kappa1 + 1e-2 * j, kappa2=P.kappa2, beta=P.beta,
+                             volvol=P.volvol - 1e-2 * j) for j in range(7)]
+    one = lambda: sv.logsv_mc_chain_pricer_fixed_randoms(W0s=res, W1s=None, dts=None, v0=P.sigma0, theta=P.theta, kappa1=P.kappa1,  # noqa: E731
+                                                         kappa2=P.kappa2, beta=P.beta, volvol=P.volvol, vol_backbone_etas=np.ones(4),
+                                                         return_ivols=True, **ch)
+    ms1, got = _median_ms(one, 50, 3)
+    ms7, _ = _median_ms(lambda: sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=bumped, W0s=res, return_ivols=True, **ch), 30, 3)
+    want = sv.logsv_mc_chain_pricer(v0=P.sigma0, theta=P.theta, kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta, volvol=P.volvol,
+                                    vol_backbone_etas=np.ones(4), nb_path=100_000, nb_steps_per_year=360, seed=10, **ch)
+    res.free()
+    out["f3_frozen"] = {"paths": 100_000, "steps": 364, "one_set_with_ivols_ms": _sig(ms1), "seven_sets_with_ivols_ms": _sig(ms7),
+                        "hbm_bytes_for_randoms": 0,
+                        "bit_equal_to_mc_chain_pricer": bool(all(np.array_equal(a, b) for a, b in zip(got[0] + got[1], want[0] + want[1])))}
+
+    # ---- C2's call at 2^21 paths: the asymptotic rate (the 2^20-path launch ends in a second, partial residency round)
+    wl = dict(ttms=np.array([1.0]), forwards=np.ones(1), discfactors=np.ones(1), strikes_ttms=(kk,), optiontypes_ttms=(types,))
+    ms, _ = _median_ms(lambda: sv.logsv_mc_chain_pricer(v0=P.sigma0, theta=P.theta, kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta,
+                                                        volvol=P.volvol, vol_backbone_etas=np.ones(1), nb_path=1 << 21,
+                                                        nb_steps_per_year=1023, seed=20240602, **wl), 5, 2)
+    out["c2_at_2e21_paths"] = {"ms": _sig(ms), "psps": _sig((1 << 21) * 1024 / (ms * 1e-3))}
+    for n in (1 << 22, 1 << 23, 1 << 21, 100_000, n_dev, 10_000):            # give the legs' HBM back
+        try:
+            get_engine(n).close()
+        except Exception:                                   # noqa: BLE001
+            pass
+    out["seconds"] = _sig(time.perf_counter() - t_start, 3)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one process, N devices (svmc_multi_*)
+# ---------------------------------------------------------------------------------------------------------------
+def probe_single_process_rccl(devices, timeout: float):
+    """can ncclCommInitAll + one all-reduce over `devices` come up in ONE process?  Asked of a child process under a deadline
+    (an RCCL initialisation that hangs cannot be interrupted from inside): -> (ok, reason)"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from stochvolmodels_amd.multi import MultiDeviceSession\n"
+            "ms = MultiDeviceSession(%r, 1 << 16, 1, 8, reduce='rccl'); i = ms.info(); ms.close()\n"
+            "assert i['reduce'] == 'rccl' and i['rccl_ranks_seen'] == %d, i\n" % (ROOT, list(devices), len(devices)))
+    if os.environ.get("SVMC_BENCH_FAULT") == "multi_rccl_init":
+        return False, "fault injection: the single-process RCCL probe fails"
+    try:
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout,
+                             env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    except subprocess.TimeoutExpired:
+        return False, f"probe did not finish within {timeout:.0f} s (killed)"
+    if run.returncode == 0:
+        return True, ""
+    tail = [ln for ln in (run.stdout + run.stderr).strip().splitlines() if ln.strip()]
+    return False, (tail[-1] if tail else f"exit status {run.returncode}")[:240]
+
+
+def single_process_leg(args, cfg: str, per_gpu: int, world: int, n_devices: int, steps: int, timeout: float) -> dict:
+    """rank 0 of a launched N > 1 run starts `bench.py --gpus N --single-process` as a CHILD (its own process: nothing it does --
+    an RCCL initialisation that hangs included -- can take the launched run down) on the same job and returns its line's essentials"""
+    devices = [r % max(n_devices, 1) for r in range(world)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", str(steps), "--warmup", "1",
+           "--config", cfg, "--paths-per-gpu", str(per_gpu), "--devices", ",".join(str(d) for d in devices)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                        "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "SVMC_DIST_BACKEND", "SVMC_BENCH_SELF_LAUNCHED")
+           and not k.startswith("TORCHELASTIC")}
+    env["SVMC_BENCH_PREWARM"] = "2"
+    try:
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the single-process child did not finish within {timeout:.0f} s (killed)"}
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": ("exit status %d: " % run.returncode) + (run.stderr.strip().splitlines() or ["no output"])[-1][:240]}
+    out = json.loads(lines[-1])
+    out["child_exit_status"] = run.returncode
+    return out
+
+
+def single_process_main(args) -> int:
+    """`python bench.py --gpus N --single-process`: the C4 (or --config) job of N x paths-per-gpu paths by ONE process driving N
+    devices through a multi-session -- no launcher, no rendezvous.  Same timed region as the launched form (W warm-up calls, K
+    timed calls between synchronisations); prints one JSON line."""
+    import ctypes as C
+
+    import stochvolmodels_amd as sv
+    from stochvolmodels_amd import _lib as svlib
+    from stochvolmodels_amd.multi import get_multi_session
+    wd = Watchdog(0)
+    n_dev = C.c_int(0)
+    svlib.check(svlib.load().svmc_device_count(C.byref(n_dev)))
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit(f"--devices names {len(devices)} devices, --gpus {args.gpus}")
+    if max(devices) >= n_dev.value:
+        raise SystemExit(f"bench.py --single-process --gpus {args.gpus}: only {n_dev.value} GPU(s) visible (--devices 0,0,.. lets "
+                         f"shards share a device for testing)")
+    P = sv.LOGSV_BTC_PARAMS
+    cfg = args.config or ("c2" if args.gpus == 1 else "c4")
+    wl = make_workload(cfg, sv)
+    per_gpu = args.paths_per_gpu or ((1 << 20) if cfg == "c2" else (1 << 21))
+    n_total, nb = per_gpu * args.gpus, wl["nb_total"]
+    reduce, why = args.reduce, None
+    if reduce == "auto":
+        if len(set(devices)) < len(devices):
+            reduce, why = "host", "shards share a device (RCCL takes one rank per device)"
+        else:
+            ok, why = probe_single_process_rccl(devices, float(os.environ.get("SVMC_BENCH_INIT_TIMEOUT", "120")))
+            reduce = "rccl" if ok else "host"
+    wd.arm(float(os.environ.get("SVMC_BENCH_LEG_TIMEOUT", "600")), "single-process multi-device run")
+
+    def step(i):
+        return price(sv, wl, P, n_total, 20240602 + i, devices=devices, reduce=reduce)
+
+    step(-2000)
+    gc.collect()
+    gc.freeze()
+    for i in range(PREWARM + args.warmup):
+        step(-1000 - i)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        prices, stderrs = step(i)
+    elapsed = time.perf_counter() - t0
+    info = get_multi_session(devices, n_total, len(wl["ttms"]), wl["n_strikes"], reduce=reduce).info()
+    p777, _ = step(777)
+    wd.disarm()
+    line = {"metric": "MC path-steps/sec", "value": float(n_total) * nb * args.steps / elapsed, "unit": "path-steps/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["label"], "paths_per_gpu": per_gpu, "paths_total": n_total, "time_steps": nb,
+                       "expiries": len(wl["grids"]), "strikes": wl["n_strikes"],
+                       "parallelism": f"path-sharded x{args.gpus}, one process (svmc_multi_*)"},
+            "comm": "single-process multi-session", "reduce": info["reduce"], "reduce_fallback_reason": why or None,
+            "rccl_ranks_seen": info["rccl_ranks_seen"] or None, "shards_agree_bitwise": info["shards_agree"],
+            "devices": devices, "shard_ms_last_call": [round(s_["last_call_ms"], 3) for s_ in info["shards"]],
+            "prices_seed_777": [float(v) for v in np.concatenate(p777)],
+            "prices_head": [float(v) for v in prices[0][:3]], "stderr_head": [float(v) for v in stderrs[0][:3]]}
+    print(json.dumps(line), flush=True)
+    return 0 if info["shards_agree"] else 3
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
@@ -580,31 +844,52 @@ def self_launch(args) -> int:
     from stochvolmodels_amd import _lib
     count = C.c_int(0)
     _lib.check(_lib.load().svmc_device_count(C.byref(count)))
-    sharing = os.environ.get("SVMC_DIST_BACKEND") == "gloo"        # test mode: the ranks share the GPUs there are
+    # test modes: the ranks share the GPUs there are -- straight on the gloo rung, or through the whole fallback ladder
+    sharing = os.environ.get("SVMC_DIST_BACKEND") == "gloo" or os.environ.get("SVMC_BENCH_SHARE_DEVICES") == "1"
     if count.value < args.gpus and not sharing:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {count.value} GPU(s) visible -- one rank per GPU is required "
-                         f"(RCCL refuses two ranks on one device; SVMC_DIST_BACKEND=gloo lets ranks share a GPU for testing)")
+                         f"(RCCL refuses two ranks on one device; SVMC_BENCH_SHARE_DEVICES=1 lets ranks share a GPU for testing: "
+                         f"the ladder then lands on its gloo rung)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SVMC_BENCH_SELF_LAUNCHED="1")
     limit = float(os.environ.get("SVMC_BENCH_TIMEOUT", "1500"))
     proc = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        return proc.wait(timeout=limit)
-    except subprocess.TimeoutExpired:
-        sys.stderr.write(f"bench.py --gpus {args.gpus}: the ranks did not finish within {limit:.0f} s -- killing them\n")
+
+    def kill_ranks():
         try:
             os.killpg(proc.pid, signal.SIGKILL)        # the launcher and every rank it started (its own session)
         except ProcessLookupError:
             pass
         proc.wait()
+
+    # the ranks live in a session of their own (so that the deadline can end them all at once): a Ctrl-C or SIGTERM that
+    # reaches only THIS process must take them along, or they stay on the GPUs as orphans
+    def on_term(signum, frame):
+        raise SystemExit(128 + signum)
+
+    old_term = signal.signal(signal.SIGTERM, on_term)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: the ranks did not finish within {limit:.0f} s -- killing them\n")
+        kill_ranks()
         return 124
+    except (KeyboardInterrupt, SystemExit):
+        kill_ranks()
+        raise
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.single_process:
+        if world > 1:
+            raise SystemExit("--single-process is ONE process: run it without a launcher")
+        sys.exit(single_process_main(args))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -630,17 +915,27 @@ def main():
     def on_phase(name):
         if name == "rendezvous":
             wd.arm(t_rdv, "rendezvous of the ranks (torch.distributed.init_process_group)")
+        elif name == "collective_probe":
+            wd.arm(t_init + 60.0, "probe of a collective rung in a child process (the child has its own deadline)")
         elif name == "collective_init":
             wd.arm(t_init, "initialisation of the collective layer (RCCL communicator + first all-reduce)")
         else:
             wd.disarm()
 
-    comm = svdist.init_from_env(on_phase=on_phase if world > 1 else None)
-    if world == 1:
+    ladder = None
+    if world > 1:
+        # the collective layer by the fallback ladder: gloo control plane, then torch-nccl -> libsvmc RCCL -> gloo, each probed in
+        # a child process first (SVMC_DIST_BACKEND=gloo, the ranks-share-a-GPU test mode, asks for the last rung outright)
+        rungs = ("gloo",) if os.environ.get("SVMC_DIST_BACKEND") == "gloo" else ("nccl", "rccl", "gloo")
+        comm, ladder = svdist.init_with_fallback(rungs=rungs, on_phase=on_phase, probe_timeout=t_init)
+        backend = ladder["backend"]
+    else:
+        comm = svdist.init_from_env()            # SVMC_DIST_SINGLE_RANK_GROUP=1: a lone rank with a real process group
         torch.cuda.set_device(0)
-    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+        backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
     grouped = torch.distributed.is_initialized()
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    # the bench's own bookkeeping collectives (barriers, maxima) run on the DEFAULT group: the gloo control plane at N > 1
+    coll_dev = "cuda" if (grouped and torch.distributed.get_backend() == "nccl") else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -750,6 +1045,13 @@ def main():
     extra["rccl_ranks_seen"] = None
     if isinstance(comm, svdist.RcclComm):
         extra["rccl_ranks_seen"] = comm.ranks_seen()
+    elif world > 1 and isinstance(comm, svdist.TorchComm) and backend == "nccl":
+        # the ranks the DATA plane sees: a sum all-reduce of ones through the nccl group the chains' collectives run on
+        t = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        torch.distributed.all_reduce(t, group=comm.group)
+        extra["rccl_ranks_seen"] = int(round(float(t.item())))
+        if extra["rccl_ranks_seen"] != world:
+            failures.append(f"the nccl group saw {extra['rccl_ranks_seen']} of {world} ranks")
 
     # ---- the fused C driver of the boundary on the line's own workload (single GPU: here; N > 1: inside the RCCL leg)
     if world == 1 and not args.no_c_abi_route:
@@ -761,7 +1063,23 @@ def main():
     svlib.check(svlib.load().svmc_device_count(C.byref(dev_count)))
     ranks_share_a_device = world > dev_count.value
     want_rccl_leg = grouped and not isinstance(comm, svdist.RcclComm) and (backend == "nccl" or not args.no_extra_legs)
-    if want_rccl_leg and ranks_share_a_device:
+    rccl_probe_failed = None
+    if want_rccl_leg and ladder is not None and not ranks_share_a_device:
+        tried = {p_["rung"]: p_ for p_ in ladder["probes"]}
+        if "rccl" in tried and not tried["rccl"]["ok"]:
+            rccl_probe_failed = tried["rccl"]["reason"]                # the ladder already tried this rung and it failed
+        elif "rccl" not in tried:
+            # the nccl rung held: libsvmc's own RCCL route has not been tried on this node yet -- probe it in child processes
+            # before the ranks themselves create a second communicator
+            wd.arm(t_init + 60.0, "probe of libsvmc's RCCL route")
+            box = [free_port() if rank == 0 else None]
+            torch.distributed.broadcast_object_list(box, src=0)
+            ok, why = svdist._run_probe("rccl", int(box[0]), t_init)
+            if not all_ranks_ok(ok):
+                rccl_probe_failed = why or "the probe failed on another rank"
+    if want_rccl_leg and rccl_probe_failed is not None:
+        extra["rccl_route"] = {"skipped": "probe failed: " + str(rccl_probe_failed)[:200]}
+    elif want_rccl_leg and ranks_share_a_device:
         # the gloo test mode (several ranks on one GPU): RCCL refuses two ranks per device (ncclCommInitRank: invalid
         # usage; tests/test_gpu_parity.py::test_two_rccl_ranks_on_one_gpu records the refusal) -- nothing to time
         extra["rccl_route"] = {"skipped": f"{world} ranks share {dev_count.value} device(s): RCCL needs one device per rank"}
@@ -814,8 +1132,12 @@ def main():
                         leg, err = None, f"{type(exc).__name__}: {exc}"[:300]
                     extra["c_abi_route"] = leg if all_ranks_ok(leg is not None) else {"error": err or "failed on another rank"}
             rc.close()
-    if (backend == "nccl" or isinstance(comm, svdist.RcclComm)) and extra["rccl_ranks_seen"] != world:
-        failures.append(f"rccl_ranks_seen {extra['rccl_ranks_seen']} != --gpus {world} on the RCCL backend")
+    if isinstance(comm, svdist.RcclComm) and extra["rccl_ranks_seen"] != world:
+        failures.append(f"rccl_ranks_seen {extra['rccl_ranks_seen']} != --gpus {world} on the RCCL rung")
+    if ladder is not None:
+        extra["comm_ladder"] = {"rung": ladder["rung"], "control_plane": ladder["control_plane"],
+                                "probes": [[p_["rung"], bool(p_["ok"]), p_["seconds"]] for p_ in ladder["probes"]]}
+        extra["comm_fallback_reason"] = ladder["comm_fallback_reason"]
 
     if world > 1 and not args.no_self_check:
         # ---- the line proves itself: the sharded job against the WHOLE job on one device (rank 0's), same seed.  The paths
@@ -874,6 +1196,32 @@ def main():
         if grouped:
             torch.distributed.barrier()
 
+    if world > 1 and not args.no_single_process_leg and not args.no_extra_legs:
+        # ---- the same job by ONE process driving all the devices (svmc_multi_*), as a child of rank 0; the other ranks wait
+        wd.arm(3 * t_leg + t_init, "single_process_route (a child process of rank 0)")
+        leg = None
+        if rank == 0:
+            k = max(3, min(args.steps, 10))
+            leg = single_process_leg(args, cfg, per_gpu, world, dev_count.value, k, 2 * t_leg + t_init)
+        barrier()                                      # the other ranks idle meanwhile: their devices belong to the child
+        p_ref, _ = step(777)                           # the launched ranks' prices for the child's comparison seed
+        if rank == 0:
+            if "error" in leg:
+                extra["single_process_route"] = leg
+            else:
+                dev = max_rel_dev([np.asarray(leg["prices_seed_777"])], [np.concatenate([np.ravel(a) for a in p_ref])])
+                extra["single_process_route"] = {
+                    "entry_point": "svmc_multi_logsv_chain_price (one process, a host thread and a session per device)",
+                    "value": leg["value"], "ms_per_step": leg["ms_per_step"], "steps": leg["steps"], "reduce": leg["reduce"],
+                    "reduce_fallback_reason": leg.get("reduce_fallback_reason"), "rccl_ranks_seen": leg.get("rccl_ranks_seen"),
+                    "devices": leg["devices"], "shards_agree_bitwise": leg["shards_agree_bitwise"],
+                    "shard_ms_last_call": leg["shard_ms_last_call"], "max_rel_dev_vs_launched_ranks": dev,
+                    "speedup_over_the_launched_ranks": leg["value"] / value}
+                if not (dev <= 1e-12 and leg["shards_agree_bitwise"]):
+                    failures.append(f"single-process route deviates from the launched ranks by {dev:.3e} (or its shards disagree)")
+        if grouped:
+            torch.distributed.barrier()
+
     result = None
     if rank == 0:
         wd.arm(2 * t_leg, "roofline legs + CPU baselines (rank 0)")
@@ -921,6 +1269,13 @@ def main():
                 result["cpu_baseline_numpy"] = cpu_baseline_numpy(1024, P)
         if failures:
             result["self_check_failed"] = failures
+        if world == 1 and cfg == "c2" and not args.no_secondary and not args.no_extra_legs:
+            # LAST key of the line (the part a truncating log keeps): the other BASELINE configurations, compact
+            wd.arm(2 * t_leg, "secondary block (C1, C3, C5, f3)")
+            try:
+                result["secondary"] = secondary_block(sv, P)
+            except Exception as exc:                         # noqa: BLE001  -- a secondary leg never costs the headline line
+                result["secondary"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     # ranks > 0 get here while rank 0 still runs its roofline legs and the CPU baselines: their deadline covers that
     wd.arm(t_init if rank == 0 else 2 * t_leg + t_init, "final barrier + process-group teardown")
     n_fail = len(failures)

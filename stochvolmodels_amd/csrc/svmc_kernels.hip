@@ -666,10 +666,12 @@ constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(d
 template <int P>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFast *__restrict__ consts,
-                                 const double *__restrict__ init, uint64_t seed, uint32_t c3, uint64_t path_offset,
-                                 uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
-                                 double *__restrict__ partials, uint64_t *probe)
+                                 const double *__restrict__ init, int p_total, int s0, uint64_t seed, uint32_t c3,
+                                 uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap,
+                                 double *__restrict__ q_snap, double *__restrict__ partials, uint64_t *probe)
 {
+    // this launch advances the sets s0 .. s0 + P - 1 of the call's p_total (eight sets run as two launches of four: eight
+    // states per lane need more than the 256 registers two waves per SIMD leave)
     __shared__ RngTablesLds s_tab;
     __shared__ double s_exp[256];
     __shared__ LogsvFast s_c[P];
@@ -686,7 +688,7 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         xv[s] = 0.0;
-        sg[s] = init[s];
+        sg[s] = init[s0 + s];
         q[s] = 0.0;
         if constexpr (PARK) {
             s_park[(2 * s) * BLOCK + threadIdx.x] = 0.0;
@@ -700,7 +702,7 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
         __syncthreads();                                   // everybody is done with the previous slice's constants
         {
             constexpr int ND = P * LOGSV_FAST_DOUBLES;
-            const double *src = reinterpret_cast<const double *>(consts + static_cast<size_t>(i) * P);
+            const double *src = reinterpret_cast<const double *>(consts + static_cast<size_t>(i) * p_total + s0);
             double *dst = reinterpret_cast<double *>(s_c);
             for (int j = threadIdx.x; j < ND; j += BLOCK) dst[j] = src[j];
         }
@@ -760,7 +762,7 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
                 s_park[(2 * s) * BLOCK + threadIdx.x] = xv[s];
                 s_park[(2 * s + 1) * BLOCK + threadIdx.x] = q[s];
             }
-            const int row = s * cs.m + i;
+            const int row = (s0 + s) * cs.m + i;
             const SliceOut so = {x_snap + static_cast<size_t>(row) * n, q_snap ? q_snap + static_cast<size_t>(row) * n : nullptr,
                                  partials + 2 * static_cast<size_t>(row) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
             slice_epilogue(so, p, active, xv[s], q[s]);
@@ -1820,13 +1822,13 @@ int logsv_chain_w_sets(size_t n_path, int n_sets, int n_slices, const int *nb_st
 // snapshots [P m][n] set-major, spot_sums [P m][2]
 template <int P>
 static void launch_chain_rng_sets(unsigned g, hipStream_t stream, size_t n_path, const ChainRngSetsSlices &cs,
-                                  const double *consts_dev, const double *vol0_dev, uint64_t seed, uint32_t c3,
-                                  uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace,
+                                  const double *consts_dev, const double *vol0_dev, int p_total, int s0, uint64_t seed,
+                                  uint32_t c3, uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace,
                                   uint64_t *probe)
 {
     hipLaunchKernelGGL(logsv_chain_rng_sets_kernel<P>, dim3(g), dim3(BLOCK), 0, stream, n_path, cs,
-                       reinterpret_cast<const LogsvFast *>(consts_dev), vol0_dev, seed, c3, path_offset, 0u, x_snapshots,
-                       qvar_snapshots, static_cast<double *>(workspace), probe);
+                       reinterpret_cast<const LogsvFast *>(consts_dev), vol0_dev, p_total, s0, seed, c3, path_offset, 0u,
+                       x_snapshots, qvar_snapshots, static_cast<double *>(workspace), probe);
 }
 
 int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_steps_host, const double *consts_dev,
@@ -1852,21 +1854,21 @@ int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_
     const uint32_t c3 = make_c3(call_id);
     const unsigned g = grid_for(n_path);
     uint64_t *probe = allow_probe ? armed_probe() : nullptr;
-#define SVMC_RNG_SETS_CASE(P)                                                                                                   \
-    case P:                                                                                                                     \
-        launch_chain_rng_sets<P>(g, stream, n_path, cs, consts_dev, vol0_dev, seed, c3, path_offset, x_snapshots, qvar_snapshots, \
-                                 workspace, probe);                                                                             \
-        break
+#define SVMC_RNG_SETS_CASE(P, S0)                                                                                               \
+    launch_chain_rng_sets<P>(g, stream, n_path, cs, consts_dev, vol0_dev, n_sets, S0, seed, c3, path_offset, x_snapshots,       \
+                             qvar_snapshots, workspace, probe)
     switch (n_sets) {
-        SVMC_RNG_SETS_CASE(1);
-        SVMC_RNG_SETS_CASE(2);
-        SVMC_RNG_SETS_CASE(3);
-        SVMC_RNG_SETS_CASE(4);
-        SVMC_RNG_SETS_CASE(5);
-        SVMC_RNG_SETS_CASE(6);
-        SVMC_RNG_SETS_CASE(7);
-    default:
-        SVMC_RNG_SETS_CASE(8);
+    case 1: SVMC_RNG_SETS_CASE(1, 0); break;
+    case 2: SVMC_RNG_SETS_CASE(2, 0); break;
+    case 3: SVMC_RNG_SETS_CASE(3, 0); break;
+    case 4: SVMC_RNG_SETS_CASE(4, 0); break;
+    case 5: SVMC_RNG_SETS_CASE(5, 0); break;
+    case 6: SVMC_RNG_SETS_CASE(6, 0); break;
+    case 7: SVMC_RNG_SETS_CASE(7, 0); break;
+    default:                                   // eight: two launches of four (register budget, see the kernel)
+        SVMC_RNG_SETS_CASE(4, 0);
+        SVMC_RNG_SETS_CASE(4, 4);
+        break;
     }
 #undef SVMC_RNG_SETS_CASE
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),

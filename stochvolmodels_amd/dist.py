@@ -272,3 +272,229 @@ def _share_rng_seed(comm) -> None:
     comm._dist.broadcast(buf, src=0, group=comm.group)
     lo, hi, calls = (int(v) for v in buf.cpu().tolist())
     funcs.set_rng_state((hi << 32) | lo, calls)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A start that cannot come back empty: the collective layer chosen by a ladder of rungs, each PROBED in a child process first.
+#
+# The first contact of this code with an 8-GPU node must produce prices (and bench.py a number) whatever the node's RCCL does:
+# an RCCL initialisation can fail (an exception: the next rung takes over) or HANG inside the runtime, where no Python timer
+# can interrupt it and a watchdog can only end the rank.  So every rank first forms a gloo group over TCP on 127.0.0.1 -- the
+# control plane: agreement votes, the RCCL unique id, the seed -- and then, rung by rung,
+#     "nccl"  torch.distributed's RCCL backend                      (TorchComm on a second, nccl process group)
+#     "rccl"  libsvmc's own RCCL entry points, include/svmc.h        (RcclComm: ncclCommInitRank below the C ABI)
+#     "gloo"  the control plane itself carries the two all-reduces   (TorchComm on the gloo group: a few KB through the host)
+# starts a CHILD process per rank that initialises that rung and runs one sum all-reduce under a deadline.  Only a rung whose
+# probe succeeded on EVERY rank is initialised in the ranks themselves; a child that hangs is killed by its parent (its exact
+# pid) and costs the deadline, nothing else.  The collectives of a chain are 4 KB: on the gloo rung the job is a few per cent
+# slower and says so (`report["rung"]`, `report["comm_fallback_reason"]`).
+# ---------------------------------------------------------------------------------------------------------------------
+def _probe_main(rung: str) -> int:
+    """child process of init_with_fallback (python -m stochvolmodels_amd.dist --probe <rung>): bring the rung up among the
+    probe children of all ranks (their own rendezvous port), one sum all-reduce, exit 0 when it counted every rank"""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    fault = os.environ.get("SVMC_BENCH_FAULT", "")
+    if fault in (f"{rung}_init", f"{rung}_init:{rank}"):
+        raise RuntimeError(f"fault injection: {rung} initialisation fails")
+    if fault in (f"{rung}_hang", f"{rung}_hang:{rank}"):
+        import time
+        time.sleep(3600)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if rung == "nccl":
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible to torch")
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=device)
+        t = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+        seen = int(round(float(t.item())))
+    elif rung == "rccl":
+        import ctypes as C
+
+        from . import _lib
+        count = C.c_int(0)
+        _lib.check(_lib.load().svmc_device_count(C.byref(count)))
+        if count.value < 1:
+            raise RuntimeError("no HIP device visible")
+        _lib.check(_lib.load().svmc_set_device(local_rank % count.value))
+        dist.init_process_group(backend="gloo")
+        box = [RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rc = RcclComm(rank, world, box[0])          # creates the communicator and runs one all-reduce
+        seen = rc.ranks_seen()
+        rc.close()
+    else:
+        raise ValueError(f"unknown rung {rung}")
+    if seen != world:
+        raise RuntimeError(f"{rung}: the collective saw {seen} of {world} ranks")
+    dist.destroy_process_group()
+    print(f"probe {rung}: ok, {seen} ranks", flush=True)
+    return 0
+
+
+def _run_probe(rung: str, port: int, timeout: float):
+    """-> (ok, reason) of this rank's probe child for `rung`"""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    try:
+        proc = subprocess.Popen([sys.executable, "-m", "stochvolmodels_amd.dist", "--probe", rung], env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    except OSError as exc:
+        return False, f"probe did not start: {exc}"
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()                                   # this child, by its pid
+        proc.communicate()
+        return False, f"probe did not finish within {timeout:.0f} s (killed)"
+    if proc.returncode == 0:
+        return True, ""
+    tail = [ln for ln in (out or "").strip().splitlines() if ln.strip()]
+    return False, (tail[-1] if tail else f"probe exited with status {proc.returncode}")[:240]
+
+
+def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_timeout: Optional[float] = None):
+    """one process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): form
+    the gloo control plane, pick the first rung of `rungs` that works on every rank (see above), make its communicator the
+    default of the chain pricers and return (comm, report).  report: {"rung", "comm", "backend", "control_plane",
+    "comm_fallback_reason" (None when the first rung held), "probes": [{rung, ok, reason, seconds}], "ranks_share_a_device"}.
+    A world of one returns the single-GPU communicator.  SVMC_DIST_RUNGS overrides `rungs` (comma-separated)."""
+    import time
+    phase = on_phase if on_phase is not None else (lambda name: None)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    report = {"rung": "single", "comm": "SingleComm", "backend": None, "control_plane": None, "comm_fallback_reason": None,
+              "probes": [], "ranks_share_a_device": False}
+    if world <= 1:
+        set_default_comm(None)
+        return get_default_comm(), report
+    if os.environ.get("SVMC_DIST_RUNGS"):
+        rungs = tuple(r.strip() for r in os.environ["SVMC_DIST_RUNGS"].split(",") if r.strip())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    n_dev = 0
+    try:
+        import ctypes as C
+
+        from . import _lib
+        count = C.c_int(0)
+        _lib.check(_lib.load().svmc_device_count(C.byref(count)))
+        n_dev = count.value
+        if n_dev > 0:
+            _lib.check(_lib.load().svmc_set_device(local_rank % n_dev))
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    except Exception:                                   # a CPU-only box (the gloo tests): the engines are test doubles there
+        n_dev = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    phase("rendezvous")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo")
+    control = TorchComm()                                # the gloo world group
+    report["control_plane"] = "gloo"
+    report["ranks_share_a_device"] = bool(n_dev and world > n_dev)
+
+    def everyone(ok: bool) -> bool:
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def first_reason(reason: str) -> str:
+        box = [None] * world
+        dist.all_gather_object(box, reason)
+        return next((f"rank {r}: {msg}" for r, msg in enumerate(box) if msg), "")
+
+    timeout = float(probe_timeout if probe_timeout is not None else os.environ.get("SVMC_DIST_PROBE_TIMEOUT", "180"))
+    reasons, chosen = [], None
+    for rung in rungs:
+        t0 = time.perf_counter()
+        if rung == "gloo":
+            chosen = control
+            report["probes"].append({"rung": rung, "ok": True, "reason": "", "seconds": 0.0})
+            break
+        if rung not in ("nccl", "rccl"):
+            raise ValueError(f"unknown rung {rung!r}")
+        if n_dev == 0 and os.environ.get("SVMC_DIST_FORCE_PROBE") != "1":      # (forced: the CPU tests of the probe machinery)
+            ok, why = False, "no HIP device visible"
+        elif report["ranks_share_a_device"] and os.environ.get("SVMC_DIST_FORCE_PROBE") != "1":
+            ok, why = False, f"{world} ranks share {n_dev} device(s): RCCL takes one rank per device"
+        else:
+            port = [None]
+            if rank == 0:
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port[0] = sk.getsockname()[1]
+            dist.broadcast_object_list(port, src=0)
+            phase("collective_probe")
+            ok, why = _run_probe(rung, int(port[0]), timeout)
+        all_ok = everyone(ok)
+        why_all = "" if all_ok else (first_reason(why) or "the probe failed on another rank")
+        if all_ok:
+            # the probe passed everywhere: bring the rung up in the ranks themselves
+            phase("collective_init")
+            comm_, err = None, ""
+            try:
+                if rung == "nccl":
+                    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+                    group = dist.new_group(backend="nccl", device_id=device) if _new_group_takes_device_id(dist) \
+                        else dist.new_group(backend="nccl")
+                    warm = torch.ones(1, dtype=torch.float64, device=device)
+                    dist.all_reduce(warm, group=group)
+                    torch.cuda.synchronize(device)
+                    if int(round(float(warm.item()))) != world:
+                        raise RuntimeError(f"the nccl group counted {warm.item():.0f} of {world} ranks")
+                    comm_ = TorchComm(group)
+                else:
+                    box = [RcclComm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    comm_ = RcclComm(rank, world, box[0])
+            except Exception as exc:                     # noqa: BLE001
+                err = f"{type(exc).__name__}: {exc}"[:240]
+            all_ok = everyone(comm_ is not None)
+            if all_ok:
+                chosen = comm_
+            else:
+                why_all = first_reason(err) or "initialisation failed on another rank"
+                if isinstance(comm_, RcclComm):
+                    comm_.close()
+        report["probes"].append({"rung": rung, "ok": bool(all_ok), "reason": why_all, "seconds": round(time.perf_counter() - t0, 2)})
+        if all_ok:
+            break
+        reasons.append(f"{rung}: {why_all}")
+    if chosen is None:
+        raise RuntimeError("no collective layer could be initialised: " + "; ".join(reasons))
+    report["rung"] = report["probes"][-1]["rung"]
+    report["comm"] = type(chosen).__name__
+    report["backend"] = "gloo" if chosen is control else ("nccl" if isinstance(chosen, TorchComm) else "rccl (libsvmc)")
+    report["comm_fallback_reason"] = "; ".join(reasons) or None
+    _share_rng_seed(control)
+    set_default_comm(chosen)
+    phase("ready")
+    return chosen, report
+
+
+def _new_group_takes_device_id(dist) -> bool:
+    import inspect
+    try:
+        return "device_id" in inspect.signature(dist.new_group).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 3 and sys.argv[1] == "--probe":
+        sys.exit(_probe_main(sys.argv[2]))
+    raise SystemExit("usage: python -m stochvolmodels_amd.dist --probe nccl|rccl")

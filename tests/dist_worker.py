@@ -19,7 +19,14 @@ def main(out_path):
     from stochvolmodels_amd.utils.config import VariableType
 
     phases = []
-    comm = svdist.init_from_env(backend="gloo", on_phase=phases.append)
+    ladder = None
+    if os.environ.get("SVMC_TEST_LADDER") == "1":
+        # the fallback ladder on a box without a GPU: the nccl and rccl rungs fail (in their probe children when the probe is
+        # forced, else at the device count) and the job runs on the gloo control plane
+        comm, ladder = svdist.init_with_fallback(on_phase=phases.append,
+                                                 probe_timeout=float(os.environ.get("SVMC_TEST_PROBE_TIMEOUT", "60")))
+    else:
+        comm = svdist.init_from_env(backend="gloo", on_phase=phases.append)
     engines = {}
 
     def fake_get_engine(n_path, path_offset=0, device=None):
@@ -65,6 +72,9 @@ def main(out_path):
     pr, sd = logsv_pricer.logsv_mc_chain_pricer(**{**short, "seed": None})
     res["unseeded_prices"] = np.stack(pr)
     res["phases"] = np.array(phases)
+    if ladder is not None:
+        import json
+        res["ladder"] = np.array(json.dumps(ladder))
     res["rank_paths"] = np.array([e.n_path for e in engines.values()])
     res["rank_offsets"] = np.array([e.path_offset for e in engines.values()])
     np.savez(out_path + f".rank{comm.rank}.npz", **res)

@@ -104,3 +104,44 @@ def test_shard_range_partitions_exactly():
                 assert off == lo and cnt >= 0
                 lo += cnt
             assert lo == n
+
+
+@pytest.mark.parametrize("mode", ["no_gpu", "probe_fails", "probe_hangs"])
+def test_fallback_ladder_lands_on_gloo_with_a_result(oracle, tmp_path, mode):
+    """dist.init_with_fallback on a box where RCCL cannot come up: every rung above gloo is tried -- directly refused without a
+    device ("no_gpu"), failing inside its probe child ("probe_fails": the children really start, rendezvous on their own
+    port and report why they failed), or HANGING inside its probe child ("probe_hangs": fault injection; the parent kills
+    the child at the deadline) -- and the job still prices on the gloo control plane: the same numbers, the reasons reported"""
+    import json
+    world = 2
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29651 + ["no_gpu", "probe_fails", "probe_hangs"].index(mode)),
+               WORLD_SIZE=str(world), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), SVMC_TEST_LADDER="1")
+    if mode != "no_gpu":
+        env["SVMC_DIST_FORCE_PROBE"] = "1"
+    if mode == "probe_hangs":
+        env.update(SVMC_BENCH_FAULT="nccl_hang", SVMC_TEST_PROBE_TIMEOUT="6", SVMC_DIST_RUNGS="nccl,gloo")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), out],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    exp = _expected(oracle)
+    for r in range(world):
+        got = np.load(out + f".rank{r}.npz")
+        for key in ("logsv_prices", "logsv_stderrs", "heston_prices", "fixed_prices"):
+            np.testing.assert_allclose(got[key], exp[key], rtol=1e-11, atol=1e-14, err_msg=f"{key} rank {r}")
+        rep = json.loads(str(got["ladder"]))
+        assert rep["rung"] == "gloo" and rep["comm"] == "TorchComm" and rep["backend"] == "gloo" and rep["control_plane"] == "gloo"
+        tried = [p["rung"] for p in rep["probes"]]
+        assert tried == (["nccl", "gloo"] if mode == "probe_hangs" else ["nccl", "rccl", "gloo"])
+        assert all(not p["ok"] for p in rep["probes"][:-1]) and rep["probes"][-1]["ok"]
+        reason = rep["comm_fallback_reason"]
+        if mode == "no_gpu":
+            assert "no HIP device visible" in reason
+        elif mode == "probe_fails":
+            assert "nccl: rank 0:" in reason and "rccl: rank 0:" in reason       # the children's own last words
+        else:
+            assert "did not finish within 6 s (killed)" in reason and 5.0 <= rep["probes"][0]["seconds"] < 60.0
+        phases = list(got["phases"])
+        assert phases[0] == "rendezvous" and phases[-1] == "ready"
