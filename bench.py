@@ -681,7 +681,9 @@ def secondary_block(sv, P) -> dict:
             step0 += 128
         c5["dev"].append(_sig(_prices_dev(pr, ref, 1e-3 * float(fw[0])), 2))
     c5["mc_psps"] = _sig((1 << 23) * 512 / (np.mean(c5["mc_ms"]) * 1e-3))
-    o_an = oracle.logsv_chain_pricer(sets[0], t5_, fw, chain5["discfactors"], strikes5, types5)
+    p0 = sets[0]
+    o_an = oracle.logsv_chain_pricer((p0.sigma0, p0.theta, p0.kappa1, p0.kappa2, p0.beta, p0.volvol), t5_, fw, chain5["discfactors"],
+                                     strikes5, types5)
     c5["analytic_dev_btc"] = _sig(_prices_dev(an[0], o_an, 1e-3 * float(fw[0])), 2)
     out["c5"] = c5
 

@@ -94,6 +94,7 @@ SVMC_API int svmc_stream_synchronize(svmc_stream_t stream);
 SVMC_API int svmc_event_create(svmc_event_t *event);
 SVMC_API int svmc_event_destroy(svmc_event_t event);
 SVMC_API int svmc_event_record(svmc_event_t event, svmc_stream_t stream);
+SVMC_API int svmc_event_synchronize(svmc_event_t event);
 SVMC_API int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms); /* synchronises on `stop` */
 /* The shader clock an on-device-RNG LogSV stepping launch (svmc_logsv_*_rng*, svmc_logsv_vol_paths) ran at, measured inside
  * that kernel (no reference counterpart: measurement plumbing of bench.py's roofline).  OFF by default -- the
@@ -178,6 +179,20 @@ SVMC_API int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int
                                   double theta, double kappa1, double kappa2, double beta, double volvol,
                                   int is_spot_measure, const double *brownians, size_t ldb, uint64_t seed,
                                   uint32_t call_id, uint64_t path_offset, svmc_stream_t stream);
+
+/* ---- reductions of a resident [n_rows][ld] path array over the PATH axis: what the reference's callers of simulate_vol_paths
+ * do with the array on the host (papers/logsv_model_with_quadratic_drift/moments_vol_qvar.py:48 -- np.mean / np.std along axis 1
+ * of (sigma_t - theta)^k, k = 1..4 -- and :98 -- of sigma_t and of the expanding time average of sigma_t^2), done in HBM so that
+ * 8 numbers per time step cross PCIe instead of nb_path.
+ *   svmc_row_power_sums          sums[j * n_rows + t] = sum over the n_cols paths of (a[t * ld + p] - center)^(j + 1),
+ *                                j = 0 .. 2 n_moments - 1 (n_moments <= 4): mean_k = S_k / n, var_k = S_2k / n - mean_k^2 of the
+ *                                k-th power; deterministic (fixed tree); workspace >= n_rows x 4 x 2 n_moments doubles
+ *   svmc_expanding_mean_squares  out[t * ldo + p] = mean of a[u * ld + p]^2 over u = 0 .. t (pandas expanding().mean() of the
+ *                                squares, moments_vol_qvar.py:102); out may not alias a */
+SVMC_API int svmc_row_power_sums(const double *a, size_t ld, size_t n_rows, size_t n_cols, double center, int n_moments,
+                                 double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream);
+SVMC_API int svmc_expanding_mean_squares(const double *a, size_t ld, size_t n_rows, size_t n_cols, double *out, size_t ldo,
+                                         svmc_stream_t stream);
 
 /* ---- Black-76 implied vols of one slice, HOST arrays in and out (no device work): the price -> vol step between a
  * pricer and the calibration objective, OptionChain.compute_model_ivols_from_chain_data data/option_chain.py:327-346

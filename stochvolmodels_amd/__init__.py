@@ -33,6 +33,7 @@ _EXPORTS = {
     "logsv_mc_chain_pricer_fixed_randoms": "pricers.logsv_pricer",
     "simulate_logsv_x_vol_terminal": "pricers.logsv_pricer",
     "simulate_vol_paths": "pricers.logsv_pricer",
+    "vol_path_moments": "pricers.logsv_pricer",
     "get_randoms_for_chain_valuation": "pricers.logsv_pricer",
     "upload_fixed_randoms": "pricers.logsv_pricer",
     "draw_fixed_randoms_on_device": "pricers.logsv_pricer",

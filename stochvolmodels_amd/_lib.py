@@ -52,7 +52,10 @@ def _declare(L: C.CDLL) -> None:
         "svmc_event_create": ([pvp], i32),
         "svmc_event_destroy": ([vp], i32),
         "svmc_event_record": ([vp, vp], i32),
+        "svmc_event_synchronize": ([vp], i32),
         "svmc_event_elapsed_ms": ([vp, vp, pf], i32),
+        "svmc_row_power_sums": ([vp, sz, sz, sz, f64, i32, vp, vp, sz, vp], i32),
+        "svmc_expanding_mean_squares": ([vp, sz, sz, sz, vp, sz, vp], i32),
         "svmc_clock_probe_arm": ([i32], i32),
         "svmc_clock_probe_read": ([C.POINTER(u64), vp], i32),
         "svmc_fill_state": ([vp, vp, vp, sz, f64, f64, f64, vp], i32),

@@ -904,6 +904,73 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
     clock_probe_stamp(probe, 1);
 }
 
+// ---- what the callers of simulate_vol_paths do with the array, done where the array is -------------------------------
+// The reference's users of the [nb_steps + 1][nb_path] volatility paths reduce them over the PATH axis at every time step
+// (papers/logsv_model_with_quadratic_drift/moments_vol_qvar.py:48 np.mean / np.std of (sigma_t - theta)^k along axis 1, :98
+// of sigma_t and of the expanding time average of sigma_t^2): 8.6 GB over PCIe to keep 1025 x 8 numbers.  Two kernels on the
+// resident array instead, both HBM-bound single passes:
+//   row_power_sums_kernel      per row t: sums over the paths of (a[t][p] - center)^j, j = 1 .. 2 K  (mean and variance of the
+//                              first K central-ish moments); one block per (row, segment), deterministic tree
+//   expanding_mean_sq_kernel   per path p: out[t][p] = mean of a[u][p]^2 over u <= t  (pandas expanding().mean() of the squares)
+constexpr int ROW_MOMENTS_MAX = 4;
+constexpr int ROW_SEGMENTS = 4;        // blocks per row: 1025 rows x 4 fill the chip; their partial sums are added in order
+
+template <int K>
+__global__ __launch_bounds__(BLOCK) void row_power_sums_kernel(const double *__restrict__ a, size_t ld, size_t n_cols, double center,
+                                                               double *__restrict__ partials /* [rows][ROW_SEGMENTS][2K] */)
+{
+    __shared__ double lds[4 * block_sum_padded(2 * K)];
+    const size_t row = blockIdx.x, seg = blockIdx.y;
+    const double *__restrict__ src = a + row * ld;
+    const size_t lo = n_cols * seg / ROW_SEGMENTS, hi = n_cols * (seg + 1) / ROW_SEGMENTS;
+    double acc[2 * K];
+#pragma unroll
+    for (int j = 0; j < 2 * K; ++j) acc[j] = 0.0;
+    const auto add = [&](double v) {
+        const double d = v - center;
+        double pw = d;
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) {
+            acc[j] += pw;
+            pw *= d;
+        }
+    };
+    size_t i = lo + threadIdx.x;
+    for (; i + 3 * BLOCK < hi; i += 4 * BLOCK) {           // four loads in flight per lane
+        const double v0 = src[i], v1 = src[i + BLOCK], v2 = src[i + 2 * BLOCK], v3 = src[i + 3 * BLOCK];
+        add(v0);
+        add(v1);
+        add(v2);
+        add(v3);
+    }
+    for (; i < hi; i += BLOCK) add(src[i]);
+    block_sum_store<2 * K>(acc, lds, partials + (row * ROW_SEGMENTS + seg) * (2 * K), 2 * K);
+}
+
+__global__ __launch_bounds__(BLOCK) void expanding_mean_sq_kernel(const double *__restrict__ a, size_t ld, size_t n_rows, size_t n_cols,
+                                                                  double *__restrict__ out, size_t ldo)
+{
+    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+    if (p >= n_cols) return;
+    double q = 0.0;
+    size_t t = 0;
+    for (; t + 4 <= n_rows; t += 4) {                      // four rows in flight
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a[(t + u) * ld + p];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            q = fma(v[u], v[u], q);
+            out[(t + u) * ldo + p] = q / static_cast<double>(t + u + 1);
+        }
+    }
+    for (; t < n_rows; ++t) {
+        const double v = a[t * ld + p];
+        q = fma(v, v, q);
+        out[t * ldo + p] = q / static_cast<double>(t + 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Rough LogSV, Markovian lift with N <= 3 factors (pricers/rough_logsv/split_simulation.py:86-128, 228-356):
 // Strang splitting D(h/2) S(h) D(h/2) per step -- RK4 on the factor drift, exact lognormal step of the weighted
@@ -1952,6 +2019,46 @@ int svmc_logsv_vol_paths(double *sigma_t, size_t ld, size_t n_path, int nb_steps
                            dim3(VOLPATHS_RNG_BLOCK), 0, as_stream(stream), sigma_t, ld, n_path, nb_steps, v0, c, brownians, ldb,
                            seed, make_c3(call_id), path_offset, armed_probe());
     return check_launch("svmc_logsv_vol_paths");
+}
+
+int svmc_row_power_sums(const double *a, size_t ld, size_t n_rows, size_t n_cols, double center, int n_moments,
+                        double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(a != nullptr && sums != nullptr && workspace != nullptr, "svmc_row_power_sums: null pointer");
+    SVMC_REQUIRE(n_moments >= 1 && n_moments <= ROW_MOMENTS_MAX, "svmc_row_power_sums: 1 <= n_moments <= 4");
+    SVMC_REQUIRE(ld >= n_cols && n_cols > 0, "svmc_row_power_sums: ld < n_cols or no columns");
+    SVMC_REQUIRE(n_rows < (1u << 30), "svmc_row_power_sums: too many rows");
+    if (n_rows == 0) return SVMC_OK;
+    const size_t need = n_rows * ROW_SEGMENTS * 2 * static_cast<size_t>(n_moments) * sizeof(double);
+    if (workspace_bytes < need) return fail(SVMC_ERR_WORKSPACE, "svmc_row_power_sums: workspace too small (rows x 4 x 2 n_moments doubles)");
+    double *partials = static_cast<double *>(workspace);
+    const dim3 grid(static_cast<unsigned>(n_rows), ROW_SEGMENTS);
+    switch (n_moments) {
+    case 1: hipLaunchKernelGGL(row_power_sums_kernel<1>, grid, dim3(BLOCK), 0, as_stream(stream), a, ld, n_cols, center, partials); break;
+    case 2: hipLaunchKernelGGL(row_power_sums_kernel<2>, grid, dim3(BLOCK), 0, as_stream(stream), a, ld, n_cols, center, partials); break;
+    case 3: hipLaunchKernelGGL(row_power_sums_kernel<3>, grid, dim3(BLOCK), 0, as_stream(stream), a, ld, n_cols, center, partials); break;
+    default: hipLaunchKernelGGL(row_power_sums_kernel<4>, grid, dim3(BLOCK), 0, as_stream(stream), a, ld, n_cols, center, partials); break;
+    }
+    // sums[row][j] = the four segments' partials added in segment order: partials is [rows x 2K outputs][4 addends] read as a
+    // matrix whose "rows" are the addends -- element (r, c) at partials[r * 2K + c * 4 * 2K] would interleave; the layout
+    // [row][seg][j] makes output (row, j) the column sum over seg with row stride 2K and column base row * 4 * 2K + j
+    const int K2 = 2 * n_moments;
+    for (int j = 0; j < K2; ++j)
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(static_cast<unsigned>(n_rows)), dim3(BLOCK), 0, as_stream(stream), partials + j,
+                           static_cast<unsigned>(ROW_SEGMENTS), static_cast<size_t>(K2), static_cast<size_t>(ROW_SEGMENTS) * K2,
+                           sums + static_cast<size_t>(j) * n_rows);
+    return check_launch("svmc_row_power_sums");
+}
+
+int svmc_expanding_mean_squares(const double *a, size_t ld, size_t n_rows, size_t n_cols, double *out, size_t ldo,
+                                svmc_stream_t stream)
+{
+    SVMC_REQUIRE(a != nullptr && out != nullptr, "svmc_expanding_mean_squares: null pointer");
+    SVMC_REQUIRE(ld >= n_cols && ldo >= n_cols, "svmc_expanding_mean_squares: leading dimension < n_cols");
+    if (n_rows == 0 || n_cols == 0) return SVMC_OK;
+    hipLaunchKernelGGL(expanding_mean_sq_kernel, dim3(grid_for(n_cols)), dim3(BLOCK), 0, as_stream(stream), a, ld, n_rows, n_cols, out,
+                       ldo);
+    return check_launch("svmc_expanding_mean_squares");
 }
 
 static int heston_rng_launch(const char *fn, double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,

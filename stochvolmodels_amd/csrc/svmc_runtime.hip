@@ -171,6 +171,12 @@ int svmc_event_record(svmc_event_t event, svmc_stream_t stream)
     return SVMC_OK;
 }
 
+int svmc_event_synchronize(svmc_event_t event)
+{
+    SVMC_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return SVMC_OK;
+}
+
 int svmc_event_elapsed_ms(svmc_event_t start, svmc_event_t stop, float *ms)
 {
     SVMC_REQUIRE(ms != nullptr, "svmc_event_elapsed_ms: null output");

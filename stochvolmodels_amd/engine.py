@@ -74,6 +74,190 @@ class DeviceBuffer:
         return self.ptr + 8 * int(n_doubles)
 
 
+# ---- bulk results: resident, or brought to the host at the PCIe rate ---------------------------------------------------
+# hipMemcpy into a pageable NumPy array goes through the runtime's small staging buffers on one host thread; an 8.6 GB
+# result (simulate_vol_paths at 2^20 x 1024) then takes far longer to fetch than the 2 ms it took to compute.  A bulk
+# download here is a pipeline: the device-to-host copies run back to back, asynchronously, into a ring of page-locked
+# buffers the process keeps, and a few host threads move each finished chunk into the destination array while the next
+# chunks are in flight (NumPy releases the GIL while it copies) -- the GPU link and the host's memory system both stay busy.
+PIPELINE_CHUNK_BYTES = 32 << 20
+PIPELINE_SLOTS = 6
+PIPELINE_THREADS = 4
+PIPELINE_MIN_BYTES = 8 << 20                   # below this a plain copy is as fast
+_pinned_ring = {"ptr": None, "slots": 0, "chunk": 0, "lock": threading.Lock()}
+_copy_pool = None
+
+
+def _ring(lib):
+    r = _pinned_ring
+    if r["ptr"] is None:
+        buf = C.c_void_p()
+        _lib.check(lib.svmc_host_alloc(C.byref(buf), PIPELINE_SLOTS * PIPELINE_CHUNK_BYTES))
+        r["ptr"], r["slots"], r["chunk"] = buf.value, PIPELINE_SLOTS, PIPELINE_CHUNK_BYTES
+    return r
+
+
+def pipelined_download(src_ptr: int, n_doubles: int, stream=None, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """n_doubles from device memory into `out` (a C-contiguous float64 array; a new one when None) through the pinned ring"""
+    global _copy_pool
+    lib = _lib.load()
+    n = int(n_doubles)
+    if out is None:
+        out = np.empty(n, dtype=np.float64)
+    flat = out.reshape(-1)
+    if flat.size != n or flat.dtype != np.float64 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float64 array of the result's size")
+    if 8 * n < PIPELINE_MIN_BYTES:
+        _lib.check(lib.svmc_memcpy_d2h(flat.ctypes.data, src_ptr, 8 * n, stream))
+        _lib.check(lib.svmc_stream_synchronize(stream))
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    with _pinned_ring["lock"]:                     # one bulk download at a time per process: the ring is shared
+        ring = _ring(lib)
+        if _copy_pool is None:
+            _copy_pool = ThreadPoolExecutor(max_workers=PIPELINE_THREADS, thread_name_prefix="svmc-d2h")
+        per = ring["chunk"] // 8
+        events, pending = [], [None] * ring["slots"]
+        for _ in range(ring["slots"]):
+            e = C.c_void_p()
+            _lib.check(lib.svmc_event_create(C.byref(e)))
+            events.append(e)
+
+        def drain(slot, lo, cnt):
+            _lib.check(lib.svmc_event_synchronize(events[slot]))
+            view = np.ctypeslib.as_array(C.cast(ring["ptr"] + slot * ring["chunk"], C.POINTER(C.c_double)), shape=(cnt,))
+            np.copyto(flat[lo:lo + cnt], view)
+
+        try:
+            for i, lo in enumerate(range(0, n, per)):
+                slot, cnt = i % ring["slots"], min(per, n - lo)
+                if pending[slot] is not None:
+                    pending[slot].result()         # the slot's previous chunk has left the ring
+                _lib.check(lib.svmc_memcpy_d2h(ring["ptr"] + slot * ring["chunk"], src_ptr + 8 * lo, 8 * cnt, stream))
+                _lib.check(lib.svmc_event_record(events[slot], stream))
+                pending[slot] = _copy_pool.submit(drain, slot, lo, cnt)
+            for f in pending:
+                if f is not None:
+                    f.result()
+        finally:
+            for e in events:
+                lib.svmc_event_destroy(e)
+    return out
+
+
+class DeviceArray:
+    """a float64 [rows][cols] result left RESIDENT in HBM (simulate_vol_paths(..., return_device=True)): nothing crosses
+    PCIe until asked.  Consumers: torch / cupy take it zero-copy (`torch.as_tensor(a, device="cuda")` through
+    __cuda_array_interface__, `torch.from_dlpack(a)` through __dlpack__); `row_moments` / `expanding_mean_of_squares` do on
+    the device what the reference's callers do with the host array; `numpy()` fetches it through the pinned pipeline."""
+
+    def __init__(self, buf: DeviceBuffer, shape: Tuple[int, int], stream=None, device: int = 0):
+        self._buf, self.shape, self.stream, self.device = buf, (int(shape[0]), int(shape[1])), stream, int(device)
+        self.dtype = np.dtype(np.float64)
+
+    @property
+    def ptr(self) -> int:
+        if self._buf is None or self._buf.ptr is None:
+            raise _lib.SvmcError("this DeviceArray was freed")
+        return self._buf.ptr
+
+    @property
+    def nbytes(self) -> int:
+        return 8 * self.shape[0] * self.shape[1]
+
+    def synchronize(self) -> None:
+        _lib.check(_lib.load().svmc_stream_synchronize(self.stream))
+
+    def numpy(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        res = pipelined_download(self.ptr, self.shape[0] * self.shape[1], self.stream, None if out is None else out)
+        return res.reshape(self.shape)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    @property
+    def __cuda_array_interface__(self):
+        self.synchronize()
+        return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def __dlpack_device__(self):
+        return (10, self.device)                   # kDLROCM
+
+    def __dlpack__(self, stream=None, **_unused):
+        self.synchronize()
+        return _dlpack_capsule(self)
+
+    def row_moments(self, center: float = 0.0, n_moments: int = 4) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean, std) over the paths, per row, of (a - center)^k for k = 1 .. n_moments: arrays [rows][n_moments];
+        std is the population standard deviation (np.std): what moments_vol_qvar.py:48 computes from the host array"""
+        lib = _lib.load()
+        rows, cols = self.shape
+        k2 = 2 * int(n_moments)
+        sums, ws = DeviceBuffer(rows * k2), DeviceBuffer(rows * 4 * k2)
+        try:
+            _lib.check(lib.svmc_row_power_sums(self.ptr, cols, rows, cols, float(center), int(n_moments), sums.ptr, ws.ptr,
+                                               ws.nbytes, self.stream))
+            host = np.empty(rows * k2)
+            _lib.check(lib.svmc_memcpy_d2h(host.ctypes.data, sums.ptr, host.nbytes, self.stream))
+            self.synchronize()
+        finally:
+            sums.free()
+            ws.free()
+        s = host.reshape(k2, rows) / float(cols)               # s[j] = E[d^(j+1)]
+        mean = np.stack([s[k] for k in range(n_moments)], axis=1)
+        var = np.stack([s[2 * k + 1] - np.square(s[k]) for k in range(n_moments)], axis=1)
+        return mean, np.sqrt(np.maximum(var, 0.0))
+
+    def expanding_mean_of_squares(self) -> "DeviceArray":
+        """a new resident array q[t][p] = mean of a[u][p]^2 over u <= t (moments_vol_qvar.py:102: the realised variance so far)"""
+        rows, cols = self.shape
+        out = DeviceBuffer(rows * cols)
+        _lib.check(_lib.load().svmc_expanding_mean_squares(self.ptr, cols, rows, cols, out.ptr, cols, self.stream))
+        return DeviceArray(out, self.shape, self.stream, self.device)
+
+    def free(self) -> None:
+        if self._buf is not None:
+            self.synchronize()
+            self._buf.free()
+            self._buf = None
+
+
+def _dlpack_capsule(arr: "DeviceArray"):
+    """a DLPack capsule ("dltensor") of a DeviceArray: kDLROCM, float64, 2-d, compact strides; the capsule keeps the array
+    alive until the consumer's deleter runs"""
+    class DLDevice(C.Structure):
+        _fields_ = [("device_type", C.c_int), ("device_id", C.c_int)]
+
+    class DLDataType(C.Structure):
+        _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+    class DLTensor(C.Structure):
+        _fields_ = [("data", C.c_void_p), ("device", DLDevice), ("ndim", C.c_int), ("dtype", DLDataType),
+                    ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+    class DLManagedTensor(C.Structure):
+        pass
+    DELETER = C.CFUNCTYPE(None, C.POINTER(DLManagedTensor))
+    DLManagedTensor._fields_ = [("dl_tensor", DLTensor), ("manager_ctx", C.c_void_p), ("deleter", DELETER)]
+    shape = (C.c_int64 * 2)(*arr.shape)
+    m = DLManagedTensor()
+    m.dl_tensor = DLTensor(arr.ptr, DLDevice(10, arr.device), 2, DLDataType(2, 64, 1), shape, None, 0)
+    key = id(m)
+
+    @DELETER
+    def deleter(_p):
+        _DLPACK_ALIVE.pop(key, None)
+    m.deleter = deleter
+    _DLPACK_ALIVE[key] = (m, shape, deleter, arr)          # owner of everything the consumer may touch
+    C.pythonapi.PyCapsule_New.restype = C.py_object
+    C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    return C.pythonapi.PyCapsule_New(C.addressof(m), b"dltensor", None)
+
+
+_DLPACK_ALIVE = {}
+
+
 class HipEngine:
     def __init__(self, n_path: int, device: Optional[int] = None, path_offset: int = 0,
                  n_snapshots: int = 0, stream: Optional[int] = None):
@@ -152,10 +336,7 @@ class HipEngine:
             _lib.check(self.lib.svmc_memcpy_d2h(self._pinned, ptr, 8 * n, self.stream))
             self.synchronize()
             return np.ctypeslib.as_array(C.cast(self._pinned, C.POINTER(C.c_double)), shape=(n,)).copy()
-        out = np.empty(n, dtype=np.float64)
-        _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, ptr, 8 * n, self.stream))
-        self.synchronize()
-        return out
+        return pipelined_download(ptr, n, self.stream)      # bulk (terminal state vectors, path arrays): the pinned pipeline
 
     def upload(self, ptr: int, host: np.ndarray) -> None:
         host = np.ascontiguousarray(host, dtype=np.float64)
@@ -382,8 +563,9 @@ class HipEngine:
             self.stream)))
 
     def logsv_vol_paths(self, nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
-                        brownians: Optional[np.ndarray] = None) -> np.ndarray:
-        """full-grid sigma paths [(nb_steps+1), n_path] (svmc_logsv_vol_paths); returns the host array."""
+                        brownians: Optional[np.ndarray] = None, return_device: bool = False, out_host: Optional[np.ndarray] = None):
+        """full-grid sigma paths [(nb_steps+1), n_path] (svmc_logsv_vol_paths): the host array (fetched through the pinned
+        pipeline, into out_host when given), or with return_device the resident DeviceArray (the caller frees it)"""
         out = DeviceBuffer((nb_steps + 1) * self.n_path)
         b_ptr = None
         if brownians is not None:
@@ -392,8 +574,11 @@ class HipEngine:
                                                  float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
                                                  int(bool(is_spot_measure)), b_ptr, self.n_path, int(seed),
                                                  int(call_id), self.path_offset, self.stream))
-        host = self.download(out.ptr, (nb_steps + 1) * self.n_path).reshape(nb_steps + 1, self.n_path)
-        out.free()
+        arr = DeviceArray(out, (nb_steps + 1, self.n_path), self.stream, self.device)
+        if return_device:
+            return arr
+        host = arr.numpy(out_host)
+        arr.free()
         return host
 
     def heston_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset) -> None:

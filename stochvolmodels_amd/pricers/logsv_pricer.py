@@ -347,6 +347,15 @@ class LogSVPricer(ModelPricer):
                                   is_spot_measure=is_spot_measure, nb_steps_per_year=nb_steps, brownians=brownians,
                                   **kwargs)
 
+    def vol_path_moments(self, params: LogSvParams, ttm: float = 1.0, nb_path: int = 100000, is_spot_measure: bool = True,
+                         nb_steps: int = None, year_days: int = 360, n_terms: int = 4, **kwargs) -> dict:
+        """per-time-step Monte Carlo moments of the volatility paths, computed on the device (module-level vol_path_moments):
+        the reduction the reference's scripts apply to simulate_vol_paths' array, without the 8 bytes per path-step of PCIe"""
+        nb_steps = nb_steps or int(np.ceil(year_days * ttm))
+        return vol_path_moments(ttm=ttm, v0=params.sigma0, theta=params.theta, kappa1=params.kappa1, kappa2=params.kappa2,
+                                beta=params.beta, volvol=params.volvol, is_spot_measure=is_spot_measure, nb_path=nb_path,
+                                nb_steps_per_year=nb_steps, n_terms=n_terms, **kwargs)
+
     @timer
     def simulate_terminal_values(self, params: LogSvParams, ttm: float = 1.0, nb_path: int = 100000,
                                  is_spot_measure: bool = True, **kwargs
@@ -466,10 +475,13 @@ def simulate_logsv_x_vol_terminal(ttm: float, x0: np.ndarray, sigma0: np.ndarray
 
 def simulate_vol_paths(ttm: float, v0: float, theta: float, kappa1: float, kappa2: float, beta: float, volvol: float,
                        is_spot_measure: bool = True, nb_path: int = 100000, nb_steps_per_year: int = 360,
-                       brownians: np.ndarray = None, seed: Optional[int] = None, **kwargs
-                       ) -> Tuple[np.ndarray, np.ndarray]:
+                       brownians: np.ndarray = None, seed: Optional[int] = None, return_device: bool = False,
+                       out: Optional[np.ndarray] = None, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
     """sigma_t of shape (nb_steps + 1, nb_path), first row = v0, and the time grid (reference :870-947).
-    `brownians` are the reference's SCALED increments sqrt(dt)*N(0,1), shape (nb_steps, nb_path)."""
+    `brownians` are the reference's SCALED increments sqrt(dt)*N(0,1), shape (nb_steps, nb_path).
+    The array is 8 bytes per path-step -- 8.6 GB at 2^20 x 1024, two milliseconds to compute: by default it comes back as
+    the reference's NumPy array through a pinned, pipelined download (into `out` when given); return_device=True leaves it in
+    HBM as an engine.DeviceArray (zero-copy into torch / cupy, `.row_moments()`, `.numpy()`) -- see vol_path_moments()."""
     nb_steps, dt, grid_t = set_time_grid(ttm=ttm, nb_steps_per_year=nb_steps_per_year)
     if brownians is not None:
         brownians = np.asarray(brownians)
@@ -478,8 +490,34 @@ def simulate_vol_paths(ttm: float, v0: float, theta: float, kappa1: float, kappa
     rng_seed, call_id = next_rng_call(seed)
     eng = get_engine(nb_path)
     sigma_t = eng.logsv_vol_paths(nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, rng_seed,
-                                  call_id, brownians=brownians)
+                                  call_id, brownians=brownians, return_device=return_device, out_host=out)
     return sigma_t, grid_t
+
+
+def vol_path_moments(ttm: float, v0: float, theta: float, kappa1: float, kappa2: float, beta: float, volvol: float,
+                     is_spot_measure: bool = True, nb_path: int = 100000, nb_steps_per_year: int = 360, n_terms: int = 4,
+                     center: Optional[float] = None, with_qvar: bool = False, seed: Optional[int] = None) -> dict:
+    """What the reference's users of simulate_vol_paths compute from the array (papers/logsv_model_with_quadratic_drift/
+    moments_vol_qvar.py:48, :98-104), without the array ever leaving the GPU: per time step the Monte Carlo mean and
+    population standard deviation over the paths of (sigma_t - center)^k, k = 1 .. n_terms (center = theta by default, as in
+    plot_vol_moments_vs_mc), and with with_qvar those of the expanding time average of sigma_t^2.  -> {"grid_t", "mean"
+    [nb_steps + 1][n_terms], "std" (same shape; divide by sqrt(nb_path) for the standard error), "qvar_mean", "qvar_std"}."""
+    sigma_t, grid_t = simulate_vol_paths(ttm=ttm, v0=v0, theta=theta, kappa1=kappa1, kappa2=kappa2, beta=beta, volvol=volvol,
+                                         is_spot_measure=is_spot_measure, nb_path=nb_path, nb_steps_per_year=nb_steps_per_year,
+                                         seed=seed, return_device=True)
+    try:
+        mean, std = sigma_t.row_moments(center=theta if center is None else center, n_moments=n_terms)
+        out = {"grid_t": grid_t, "mean": mean, "std": std}
+        if with_qvar:
+            q = sigma_t.expanding_mean_of_squares()
+            try:
+                qm, qs = q.row_moments(center=0.0, n_moments=1)
+            finally:
+                q.free()
+            out["qvar_mean"], out["qvar_std"] = qm[:, 0], qs[:, 0]
+        return out
+    finally:
+        sigma_t.free()
 
 
 def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,

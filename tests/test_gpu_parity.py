@@ -807,6 +807,64 @@ def test_vol_paths(sv, oracle, golden):
 
 
 # ---- analytic side (row a11): libsvmc's Fourier kernels ------------------------------------------------------------
+def test_vol_paths_resident_array_moments_and_pipelined_download(sv):
+    """the bulk-output forms of simulate_vol_paths: return_device=True leaves the array in HBM (engine.DeviceArray) -- its
+    .numpy() is the default call's array bit for bit, torch takes it zero-copy through __cuda_array_interface__ and DLPack,
+    row_moments() / expanding_mean_of_squares() equal what the reference's scripts compute from the host array
+    (papers/.../moments_vol_qvar.py:48, :98-104) -- and the NumPy return goes through the pinned pipeline (a 70 MB result,
+    several chunks and a ragged tail; into a caller's array with out=)"""
+    import pandas as pd
+    from stochvolmodels_amd import engine
+    p = sv.LogSvParams(sigma0=1.0, theta=1.0, kappa1=4.0, kappa2=4.0, beta=0.0, volvol=1.75)
+    pricer = sv.LogSVPricer()
+    n, ttm = 20_011, 1.2
+    sig, grid = pricer.simulate_vol_paths(p, ttm=ttm, nb_path=n, seed=21)
+    assert sig.shape == (433, n) and sig.nbytes > engine.PIPELINE_CHUNK_BYTES * 2          # 69 MB: the pipeline, 3 chunks
+    dev, grid2 = pricer.simulate_vol_paths(p, ttm=ttm, nb_path=n, seed=21, return_device=True)
+    assert isinstance(dev, engine.DeviceArray) and dev.shape == sig.shape
+    np.testing.assert_array_equal(grid, grid2)
+    np.testing.assert_array_equal(dev.numpy(), sig)
+    out = np.full(sig.shape, np.nan)
+    got, _ = pricer.simulate_vol_paths(p, ttm=ttm, nb_path=n, seed=21, out=out)
+    assert got is out or np.shares_memory(got, out)
+    np.testing.assert_array_equal(out, sig)
+    with pytest.raises(ValueError):
+        pricer.simulate_vol_paths(p, ttm=ttm, nb_path=n, seed=21, out=np.empty((5, 5)))
+    import torch
+    t = torch.as_tensor(dev, device="cuda")
+    assert t.shape == sig.shape and t.dtype == torch.float64 and t.data_ptr() == dev.ptr
+    np.testing.assert_array_equal(t.cpu().numpy(), sig)
+    t2 = torch.from_dlpack(dev)
+    assert t2.data_ptr() == dev.ptr and torch.equal(t, t2)
+    del t, t2
+    # the reductions of the reference's scripts, on the device
+    mean, std = dev.row_moments(center=p.theta, n_moments=4)
+    for k in range(4):
+        m_k = np.power(sig - p.theta, k + 1)
+        np.testing.assert_allclose(mean[:, k], np.mean(m_k, axis=1), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(std[:, k], np.std(m_k, axis=1), rtol=1e-9, atol=1e-12)
+    q = dev.expanding_mean_of_squares()
+    want_q = pd.DataFrame(np.square(sig)).expanding(axis=0).mean().to_numpy()
+    np.testing.assert_allclose(q.numpy(), want_q, rtol=1e-13)
+    q.free()
+    mom = pricer.vol_path_moments(p, ttm=ttm, nb_path=n, seed=21, n_terms=4, with_qvar=True)
+    np.testing.assert_array_equal(mom["mean"], mean)
+    np.testing.assert_array_equal(mom["std"], std)
+    np.testing.assert_allclose(mom["qvar_mean"], np.mean(want_q, axis=1), rtol=1e-12)
+    np.testing.assert_allclose(mom["qvar_std"], np.std(want_q, axis=1), rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(mom["grid_t"], grid)
+    dev.free()
+    with pytest.raises(Exception):
+        dev.numpy()
+    # a state download big enough for the pipeline (2^22 paths: 3 x 33 MB) equals the state a small engine sees for the same paths
+    x, s, qv = pricer.simulate_terminal_values(p, ttm=0.1, nb_path=1 << 22, seed=8)
+    assert x.shape == (1 << 22,) and np.all(np.isfinite(x)) and np.all(s > 0)
+    from stochvolmodels_amd.engine import pipelined_download, get_engine
+    eng = get_engine(1 << 22)
+    np.testing.assert_array_equal(pipelined_download(eng.x.ptr, 1 << 22), x)
+    np.testing.assert_array_equal(pipelined_download(eng.x.ptr + 8 * 12345, 999_983), x[12345:12345 + 999_983])
+
+
 def test_vol_paths_ragged_sizes(sv, oracle):
     """simulate_vol_paths on every tail of its loops: 1..9 and 18 steps (the drawing loop runs call by call, four steps each;
     the supplied-brownians loop prefetches groups of four) x path counts around the wave size, both measures, device draw
