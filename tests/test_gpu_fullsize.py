@@ -249,7 +249,9 @@ def test_c5_monte_carlo_leg_rank_share(sv, cpu, golden, tag):
     And C5's own criterion on C5's own chain, as VERDICT PARITY: per option, does |analytic - MC| <= 4 stderr hold?  The
     reference's answer is committed (tests/golden/c5_verdict.npz, made by make_golden.py g_c5_verdict: the UNMODIFIED
     reference's analytic chain against the oracle's Monte Carlo on this very stream); the GPU's answer -- its analytic chain
-    against its Monte Carlo -- must be the same map, option by option.  (Four sets pass on all 84 options; the kappa2 = 12
+    against its Monte Carlo -- must be the same map, option by option, outside a dead band around the threshold, and the
+    z-scores themselves must agree (NB the oracle's analytic integrator is a 5(4) pair, the device's an 8(5,3) pair: the two
+    meet at their tolerances, 1e-10, not bit for bit -- on the analytic side the "CPU twin" is a tolerance twin).  (Four sets pass on all 84 options; the kappa2 = 12
     set fails 22 of them at the first expiries, where the standard error of 2^20 paths is far below the truncation error of
     the reference's second-order expansion -- a property of the reference's approximation, tabulated in
     profiles/r02_c5_bias.json, that a drop-in must reproduce, not hide.)"""
@@ -276,8 +278,17 @@ def test_c5_monte_carlo_leg_rank_share(sv, cpu, golden, tag):
     # analytic chain meets the reference's to the reference's own solver tolerance (rtol 1e-3 RK45: 2e-6 of the forward)
     np.testing.assert_allclose(pr, g[f"{tag}_mc"], rtol=1e-11, atol=1e-11 * float(fw[0]))
     np.testing.assert_allclose(an, g[f"{tag}_analytic"], rtol=0, atol=2e-6 * float(fw[0]))
-    np.testing.assert_array_equal(verdict, g[f"{tag}_pass"], err_msg=f"C5 {tag}: the GPU's accept / reject map differs from the "
-                                  "reference's")
+    # verdict parity with a dead band (tests/test_gpu_parity.py VERDICT_DELTA): the z-scores agree to DELTA everywhere some
+    # path reaches the option, and the maps are equal wherever the reference's |z| is more than 10 DELTA from the threshold
+    # (the "test" set's closest option sits 0.11 of a z-unit from it: its side is not a statement about parity)
+    delta = 0.05
+    z_ref = g[f"{tag}_z"]
+    reached = ~np.isnan(z_ref)
+    np.testing.assert_array_equal(np.isnan(z), ~reached)
+    assert np.nanmax(np.abs(z - z_ref)) <= delta, (tag, np.nanmax(np.abs(z - z_ref)))
+    clear = ~reached | (np.abs(np.abs(np.where(reached, z_ref, 0.0)) - 4.0) > 10.0 * delta)
+    np.testing.assert_array_equal(verdict[clear], g[f"{tag}_pass"][clear],
+                                  err_msg=f"C5 {tag}: the GPU's accept / reject map differs from the reference's away from the threshold")
 
 
 @pytest.mark.parametrize("tag", ["btc", "test"])

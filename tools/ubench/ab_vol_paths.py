@@ -36,9 +36,14 @@ n = 1 << 20
 res = {"lib": tag}
 for nb in (1024, 360):
     out = malloc((nb + 1) * n)
-    w0, w1 = malloc(nb * n), malloc(nb * n)
-    assert L.svmc_fill_normals(w0, w1, n, n, nb, 3, 0, 0, 0, None) == 0
-    for mode, b in (("rng", None), ("supplied", w0)):
+    # supplied brownians are the reference's SCALED increments sqrt(dt) N(0,1) (pricers/logsv_pricer.py:925).  Round 4 passed
+    # svmc_fill_normals' UNSCALED N(0,1) here: sigma overflowed within tens of steps, the whole output was NaN (the committed
+    # supplied_360_digest of profiles/r04_vol_paths.json) and NaN operands toggle less, draw less power and clock higher than
+    # real data -- the "supplied" figures of round 4 were measured on that.  Now: scaled, and the digest must be finite.
+    import torch
+    bt = torch.randn(nb, n, dtype=torch.float64, device="cuda") * (1.0 / 360) ** 0.5
+    torch.cuda.synchronize()
+    for mode, b in (("rng", None), ("supplied", vp(bt.data_ptr()))):
         def launch():
             return L.svmc_logsv_vol_paths(out, n, n, nb, 1.0 / 360, 0.8, 1.0, 3.0, 3.0, 0.15, 1.8, 1, b, n, 5, 0, 0, None)
         for _ in range(2):
@@ -57,9 +62,13 @@ for nb in (1024, 360):
         wr = 8.0 * (nb + 1) * n
         rd = 8.0 * nb * n if b else 0.0
         key = f"{mode}_{nb}"
-        if hasattr(L, "svmc_clock_probe_read"):         # round-4 builds: the shader clock inside the last launch
+        if hasattr(L, "svmc_clock_probe_read"):         # round-4+ builds: the shader clock inside the last launch
             st = (C.c_uint64 * 8)()
             L.svmc_clock_probe_read.argtypes = [C.POINTER(C.c_uint64), vp]
+            if hasattr(L, "svmc_clock_probe_arm"):      # round-5 builds: the probe is off unless the thread armed it
+                L.svmc_clock_probe_arm.argtypes = [i32]
+                L.svmc_clock_probe_arm(1)
+                launch()
             L.svmc_clock_probe_read(st, None)
             mhz = [100.0 * (st[i + 2] - st[i]) / (st[i + 3] - st[i + 1]) for i in (0, 4) if st[i + 3] > st[i + 1]]
             res[key + "_clock_mhz"] = [round(v, 1) for v in mhz]
@@ -73,6 +82,8 @@ for nb in (1024, 360):
             L.svmc_stream_synchronize(None)
             samp = host[::4097]
             res[key + "_digest"] = [float(samp.sum()).hex(), float((samp * samp).sum()).hex(), float(host[-n:].sum()).hex()]
-    for p in (out, w0, w1):
-        L.svmc_free(p)
+            assert np.all(np.isfinite(host)), f"{key}: the output holds non-finite values -- the measurement ran on NaN data"
+            res[key + "_finite"] = True
+    L.svmc_free(out)
+    del bt
 print(json.dumps(res))
