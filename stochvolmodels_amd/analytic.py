@@ -30,6 +30,7 @@ ODE_RTOL, ODE_ATOL = 1e-10, 1e-12
 # release() returns it.  One pooled grid per key: a second acquire() before the release() builds a private one.
 _POOL = {}
 _POOL_LOCK = threading.Lock()
+MAX_POOLED_GRIDS = 8                        # resident pooled grids per process (a 1000-point, 5-coefficient grid is ~130 KB of HBM)
 
 
 class _Pooled:
@@ -42,6 +43,8 @@ class _Pooled:
                 alive = {t.ident for t in threading.enumerate()}
                 for k in [k for k in _POOL if k[0] not in alive]:
                     _POOL.pop(k).close()
+            while len(_POOL) > MAX_POOLED_GRIDS:                # ... and the least recently released ones beyond the cap: a
+                _POOL.pop(next(iter(_POOL))).close()            # live thread that prices many grid shapes does not keep them all
         if obj is None:
             obj = cls(*args)
         else:
@@ -66,8 +69,10 @@ class AnalyticGrid(_Pooled):
         return (int(np.asarray(phi).size), int(n_coef))
 
     def _reset(self, phi, psi, n_coef) -> None:
-        phi = np.ascontiguousarray(phi, dtype=np.complex128)
-        psi = np.ascontiguousarray(psi, dtype=np.complex128)
+        # private copies: the pooled object compares the NEXT caller's grid with these -- a caller that reuses and mutates its
+        # own array in place must not end up comparing the array with itself (and keeping a stale grid on the device)
+        phi = np.array(phi, dtype=np.complex128, copy=True, order="C")
+        psi = np.array(psi, dtype=np.complex128, copy=True, order="C")
         if not np.array_equal(phi, self.phi_host):
             _lib.check(self.lib.svmc_memcpy_h2d(self.phi.ptr, phi.ctypes.data, phi.nbytes, None))
             self.phi_host = phi
@@ -86,10 +91,11 @@ class AnalyticGrid(_Pooled):
             raise _lib.SvmcError("no HIP device visible: the analytic pricers run on the GPU only")
         self.n = int(phi.size)
         self.n_coef = int(n_coef)
-        self.phi_host = np.ascontiguousarray(phi, dtype=np.complex128)
+        self.phi_host = np.array(phi, dtype=np.complex128, copy=True, order="C")
         self.phi = self._up(self.phi_host)
-        self.psi_host = np.ascontiguousarray(psi, dtype=np.complex128)
+        self.psi_host = np.array(psi, dtype=np.complex128, copy=True, order="C")
         self.psi = self._up(self.psi_host)
+        self.last_given_up = 0
         self.a = DeviceBuffer(2 * self.n * self.n_coef)
         self.b = DeviceBuffer(2 * self.n)
         self.log_mgf = DeviceBuffer(2 * self.n)
@@ -168,9 +174,16 @@ class AnalyticGrid(_Pooled):
                                                 self._capped.offset(offset), None))
 
     def download_results(self, n_doubles: int) -> np.ndarray:
+        """the queued sums of the chain -- and, in the same wait, the last expiry's log-MGF: a grid point the ODE integrator
+        GAVE UP on (step floor / try cap of csrc/svmc_analytic.hip) is NaN there and stays NaN for every later expiry, and the
+        inversion drops it like the reference's nansum -- silently.  self.last_given_up counts them (0 for every sane set):
+        the chain pricers warn and a calibrator can penalise the evaluation."""
         out = np.empty(int(n_doubles))
+        lm = np.empty(self.n, dtype=np.complex128)
         _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, 8 * int(n_doubles), None))
+        _lib.check(self.lib.svmc_memcpy_d2h(lm.ctypes.data, self.log_mgf.ptr, lm.nbytes, None))
         _lib.check(self.lib.svmc_stream_synchronize(None))
+        self.last_given_up = int(np.count_nonzero(np.isnan(lm.real) | np.isnan(lm.imag)))
         return out
 
     def qvar_sums(self, ttm: float, strikes: np.ndarray) -> np.ndarray:
@@ -216,9 +229,10 @@ class AnalyticGridBatch(_Pooled):
         self.n_sets = len(phis)
         self.n = int(np.asarray(phis[0]).size)
         self.n_coef = int(n_coef)
-        phi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in phis]))
+        phi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in phis]))       # np.stack copies: private
         psi = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.complex128) for p in psis]))
         assert phi.shape == psi.shape == (self.n_sets, self.n)
+        self.last_given_up = np.zeros(self.n_sets, dtype=int)
         self.phi_host, self.psi_host = phi, psi
         self.phi, self.psi = DeviceBuffer(2 * phi.size), DeviceBuffer(2 * psi.size)
         for buf, z in ((self.phi, phi), (self.psi, psi)):
@@ -268,9 +282,13 @@ class AnalyticGridBatch(_Pooled):
                                                          self._capped.offset(offset), None))
 
     def download_results(self, n_doubles: int) -> np.ndarray:
+        """as AnalyticGrid.download_results; self.last_given_up is an array, one count per parameter set"""
         out = np.empty(int(n_doubles))
+        lm = np.empty((self.n_sets, self.n), dtype=np.complex128)
         _lib.check(self.lib.svmc_memcpy_d2h(out.ctypes.data, self._capped.ptr, 8 * int(n_doubles), None))
+        _lib.check(self.lib.svmc_memcpy_d2h(lm.ctypes.data, self.log_mgf.ptr, lm.nbytes, None))
         _lib.check(self.lib.svmc_stream_synchronize(None))
+        self.last_given_up = np.count_nonzero(np.isnan(lm.real) | np.isnan(lm.imag), axis=1).astype(int)
         return out
 
     def close(self) -> None:

@@ -223,7 +223,11 @@ __device__ void dop853(const OdeConsts &c, cd phi, cd psi, double ttm, cd (&y)[5
             e5 += fma(err5.re, err5.re, err5.im * err5.im) * inv;
             e3 += fma(err3.re, err3.re, err3.im * err3.im) * inv;
         }
-        // error^2 = h^2 e5^2 / ((e5 + 0.01 e3) n)
+        // error^2 = h^2 e5^2 / ((e5 + 0.01 e3) n), n = 5 ALWAYS: a first-order chain (three live components, the other two
+        // identically zero) is normed over five where SciPy's DOP853 would take len(scale) = 3 -- its effective tolerance is
+        // sqrt(5/3) looser than "SciPy's controller at rtol".  Deliberate: one norm for both orders keeps the lane-per-component
+        // kernels' row reduction uniform, and the difference is a factor 1.3 in a tolerance that sits six orders below the
+        // reference's own (rtol 1e-3); the first-order goldens hold at the same 1e-8.
         const double denom = fma(0.01, e3, e5);
         // a trial step that left the finite range (a quadratic system: a step too long for a far grid point overflows inside its
         // stages and the estimators come back inf or NaN) is a rejection with the smallest factor, not a number to take a power of

@@ -121,6 +121,25 @@ ROUGH_CHAIN_ONE_LAUNCH = True
 LOGSV_BTC_PARAMS = LogSvParams(sigma0=0.8376, theta=1.0413, kappa1=3.1844, kappa2=3.058, beta=0.1514, volvol=1.8458)
 
 
+# Grid points the coefficient-ODE integrator gave up on in the LAST analytic chain pricing of this process (step floor / try
+# cap, csrc/svmc_analytic.hip): an int for logsv_chain_pricer, one count per parameter set for the batched pricer.  Zero for
+# every sane parameter vector; non-zero means the inversion dropped those terms (as the reference's np.nansum drops NaN terms)
+# and the prices are bounded but NOT the model's -- a RuntimeWarning says so, and a calibrator can test this to penalise the
+# evaluation (the reference's solve_ivp returns whatever state it reached, without a signal).
+LAST_ANALYTIC_GIVEN_UP = 0
+
+
+def _note_given_up(count, n_grid: int) -> None:
+    global LAST_ANALYTIC_GIVEN_UP
+    LAST_ANALYTIC_GIVEN_UP = count
+    if np.any(np.asarray(count) > 0):
+        import warnings
+        warnings.warn(f"analytic LogSV pricer: the coefficient ODEs were given up on {np.asarray(count).tolist()} of {n_grid} "
+                      f"transform-grid points (stiff beyond the try cap, or blowing up before the expiry): those terms are dropped "
+                      f"from the inversion and the prices are not the model's -- pricers.logsv_pricer.LAST_ANALYTIC_GIVEN_UP",
+                      RuntimeWarning, stacklevel=3)
+
+
 def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarray, forwards: np.ndarray,
                              discfactors: np.ndarray, strikes_ttms: Sequence[np.ndarray],
                              optiontypes_ttms: Sequence[np.ndarray], is_spot_measure: bool = True,
@@ -153,6 +172,7 @@ def logsv_chain_pricer_batch(params_list: Sequence[LogSvParams], ttms: np.ndarra
             batch.queue_capped_sums(float(forward), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             ttm0 = ttm
         sums = batch.download_results(int(offs[-1]))
+        _note_given_up(batch.last_given_up, len(grids[0][0]))
         out = [[] for _ in params_list]
         for i, (forward, strikes, types, discfactor) in enumerate(zip(forwards, strikes_ttms, optiontypes_ttms, discfactors)):
             capped = sums[offs[i]:offs[i + 1]].reshape(n_sets, ks[i])
@@ -413,6 +433,7 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
                 grid.queue_qvar_sums(float(ttm), np.asarray(strikes, dtype=np.float64), int(offs[i]))
             ttm0 = ttm
         sums = grid.download_results(int(offs[-1]))
+        _note_given_up(grid.last_given_up, grid.n)
         prices = []
         for i, (ttm, forward, strikes, types, discfactor) in enumerate(zip(ttms, forwards, strikes_ttms, optiontypes_ttms,
                                                                            discfactors)):

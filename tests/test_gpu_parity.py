@@ -1006,12 +1006,18 @@ def test_analytic_gives_up_on_unreasonably_stiff_coefficients(sv):
     sane = np.stack(pricer.price_chain(chain, sv.LOGSV_BTC_PARAMS))
     assert np.all(np.isfinite(sane)) and np.all(sane > 0.0)
     wild = sv.LogSvParams(sigma0=1.0, theta=1.0, kappa1=0.1, kappa2=0.1, beta=50.0, volvol=50.0)
+    from stochvolmodels_amd.pricers import logsv_pricer as lp
+    assert lp.LAST_ANALYTIC_GIVEN_UP == 0                              # the sane set: no grid point was given up
     t0 = time.perf_counter()
-    out = np.stack(pricer.price_chain(chain, wild))
+    with pytest.warns(RuntimeWarning, match="given up"):               # ... and the caller is TOLD when some were
+        out = np.stack(pricer.price_chain(chain, wild))
     seconds = time.perf_counter() - t0
+    assert 0 < lp.LAST_ANALYTIC_GIVEN_UP <= 1000
     assert seconds < 3.0, seconds                # (4.5 - 12 s before the give-up rule; ~0.1 s with it)
     assert np.all((out >= 0.0) & (out <= np.maximum(1.0, kk)[None, :])), out[-1][:3]
-    batch = pricer.price_chain_batch(chain, [sv.LOGSV_BTC_PARAMS, wild])
+    with pytest.warns(RuntimeWarning, match="given up"):
+        batch = pricer.price_chain_batch(chain, [sv.LOGSV_BTC_PARAMS, wild])
+    assert lp.LAST_ANALYTIC_GIVEN_UP[0] == 0 and lp.LAST_ANALYTIC_GIVEN_UP[1] > 0      # per set: the sane neighbour is clean
     np.testing.assert_array_equal(np.stack(batch[0]), sane)          # a set's neighbours in the launch do not feel it
     np.testing.assert_array_equal(np.stack(batch[1]), out)
     np.testing.assert_array_equal(np.stack(pricer.price_chain(chain, sv.LOGSV_BTC_PARAMS)), sane)
