@@ -119,6 +119,12 @@ __device__ __forceinline__ RngTables stage_tables(RngTablesLds &lds, double (&ld
     return RngTables{lds.icdf, nullptr};
 }
 
+#ifndef SVMC_TRIP_BARRIER
+#define SVMC_TRIP_BARRIER 0
+#endif
+#ifndef SVMC_PHILOX_FENCE
+#define SVMC_PHILOX_FENCE 0
+#endif
 #ifndef SVMC_PHILOX_ROUNDS
 #define SVMC_PHILOX_ROUNDS 7
 #endif
@@ -255,8 +261,14 @@ __device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t s
     const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
     for (uint32_t c = first >> 1; c <= (last >> 1); ++c) {
         tick(static_cast<int>(2u * c - first));
+#if SVMC_TRIP_BARRIER          // A/B hook (tools/r05/ab_pairing.sh): the waves of a block re-align every SVMC_TRIP_BARRIER-th trip
+        if ((c % SVMC_TRIP_BARRIER) == 0u) __builtin_amdgcn_s_barrier();
+#endif
         uint32_t r[4];
         philox_draw(lane, c, r);
+#if SVMC_PHILOX_FENCE          // A/B hook: nothing is scheduled across the end of the Philox rounds
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         double z0, z1;
         if (2u * c >= first) {
             normals_from_words(r[0], r[1], tab, z0, z1);
