@@ -372,9 +372,14 @@ def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_time
     world = int(os.environ.get("WORLD_SIZE", "1"))
     report = {"rung": "single", "comm": "SingleComm", "backend": None, "control_plane": None, "comm_fallback_reason": None,
               "probes": [], "ranks_share_a_device": False}
-    if world <= 1:
+    if world <= 1 and os.environ.get("SVMC_DIST_SINGLE_RANK_GROUP") != "1":
         set_default_comm(None)
         return get_default_comm(), report
+    # SVMC_DIST_SINGLE_RANK_GROUP=1: a lone rank walks the ladder too -- probe children, the nccl group / the RCCL communicator,
+    # the collectives of a chain -- so that a 1-GPU box exercises the code of the N > 1 start (tests/test_gpu_parity.py)
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("RANK", "0")
+    world = max(world, 1)
     if os.environ.get("SVMC_DIST_RUNGS"):
         rungs = tuple(r.strip() for r in os.environ["SVMC_DIST_RUNGS"].split(",") if r.strip())
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -2308,3 +2308,39 @@ def test_bench_default_line_ends_with_the_secondary_block():
     assert sec["c2_at_2e21_paths"]["psps"] > 0.9 * line["value"]
     assert sec["seconds"] < 30.0
     assert len(__import__("json").dumps(sec)) < 2600
+
+
+@pytest.mark.parametrize("rungs,want", [("nccl,rccl,gloo", "nccl"), ("rccl,gloo", "rccl"), ("gloo", "gloo")])
+def test_fallback_ladder_rungs_on_hardware_with_one_rank(tmp_path, rungs, want):
+    """every rung of dist.init_with_fallback brought up for real on this box with ONE rank (two ranks cannot share a device under
+    RCCL): the probe child of the rung (its own rendezvous, an RCCL communicator, one all-reduce), then the rung in the process
+    itself -- torch's nccl group beside the gloo control plane, or libsvmc's ncclCommInitRank -- and a chain priced through it
+    equals the ungrouped result bit for bit"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import json, os, sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})\n"
+        "import stochvolmodels_amd as sv\n"
+        "from stochvolmodels_amd import dist\n"
+        "from cases import LOGSV_CASE\n"
+        "base, _ = sv.logsv_mc_chain_pricer(**LOGSV_CASE)\n"
+        "comm, rep = dist.init_with_fallback(probe_timeout=150)\n"
+        "got, _ = sv.logsv_mc_chain_pricer(**LOGSV_CASE)\n"
+        "seen = comm.ranks_seen() if hasattr(comm, 'ranks_seen') else None\n"
+        "print(json.dumps({'rep': rep, 'equal': bool(all(np.array_equal(a, b) for a, b in zip(got, base))), 'seen': seen}))\n"
+        "import torch.distributed as td\n"
+        "td.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("SVMC_DIST_BACKEND",)}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29731 + len(rungs)),
+               SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_DIST_RUNGS=rungs, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-3000:]
+    out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    rep = out["rep"]
+    assert rep["rung"] == want and rep["comm_fallback_reason"] is None and rep["control_plane"] == "gloo", rep
+    assert rep["comm"] == ("RcclComm" if want == "rccl" else "TorchComm") and rep["probes"][0]["ok"] is True
+    assert out["equal"] is True and (out["seen"] == 1 if want == "rccl" else True)
