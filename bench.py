@@ -615,8 +615,8 @@ def secondary_block(sv, P) -> dict:
     oracle.build()
     oracle.set_threads(oracle.effective_cores())
     t_start = time.perf_counter()
-    out = {"note": "ms = median wall time of one product call; psps = path-steps/s; dev = max |gpu - oracle| / (|oracle| + 1e-3 F) "
-                   "of the prices at n_dev paths, same stream"}
+    out = {"note": "ms: median wall of one product call; psps: path-steps/s; dev: max rel price deviation from the oracle, same "
+                   "stream, n_dev paths"}
     n_dev = 1 << 14
     kk = np.linspace(0.5, 1.5, 21)
     types = np.where(kk >= 1.0, "C", "P")

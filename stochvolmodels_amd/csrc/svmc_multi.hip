@@ -14,6 +14,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -107,6 +109,10 @@ struct Multi {
     // host all-reduce: slots[parity][rank][cap] written by their rank, summed in rank order by everybody; result[rank][cap]
     double *slots = nullptr, *result = nullptr;
     size_t cap = 0;
+    // test hook (SVMC_MULTI_FAULT="shard,k" at creation): that shard's k-th host all-reduce fails once -- a failure BETWEEN the
+    // two meeting points of a chain, which no argument check can produce (tests/test_gpu_multi.py)
+    int fault_shard = -1;
+    long fault_countdown = -1;
     // job dispatch
     std::mutex m;
     std::condition_variable cv_job, cv_done;
@@ -126,6 +132,8 @@ static int host_all_reduce(void *user, double *device_buf, size_t n, svmc_stream
     Shard &s = *static_cast<Shard *>(user);
     Multi &mu = *s.owner;
     if (n > mu.cap) return fail(SVMC_ERR_WORKSPACE, "multi-session host all-reduce: buffer exceeds the exchange slots");
+    if (s.rank == mu.fault_shard && mu.fault_countdown >= 0 && mu.fault_countdown-- == 0)
+        return fail(SVMC_ERR_HIP, "fault injection (SVMC_MULTI_FAULT): this shard's all-reduce fails");
     const size_t parity = s.reduce_calls++ & 1u;
     double *mine = mu.slots + (parity * mu.R + s.rank) * mu.cap;
     SVMC_HIP_TRY(hipMemcpyAsync(mine, device_buf, n * sizeof(double), hipMemcpyDeviceToHost, as_stream(stream)));
@@ -181,6 +189,9 @@ static int run_on_shards(Multi &mu, std::function<int(Shard &)> job)
         for (Shard &s : mu.shards) {
             s.rc = SVMC_OK;
             s.error.clear();
+            // every job starts its exchanges at slot parity 0 on EVERY shard: a job that failed half-way may have left the
+            // shards' counters apart, and shards on different parities would read each other's stale slots -- silently
+            s.reduce_calls = 0;
         }
         mu.job = std::move(job);
         mu.pending = mu.R;
@@ -266,6 +277,14 @@ int svmc_multi_create(svmc_multi_t *multi, int n_shards, const int *devices_host
     mu->max_strikes = max_strikes_total;
     mu->barrier = new AbortableBarrier(n_shards);
     mu->shards.resize(n_shards);
+    if (const char *f = std::getenv("SVMC_MULTI_FAULT")) {
+        int sh = -1;
+        long k = -1;
+        if (std::sscanf(f, "%d,%ld", &sh, &k) == 2) {
+            mu->fault_shard = sh;
+            mu->fault_countdown = k;
+        }
+    }
     bool distinct = true;
     for (int r = 0; r < n_shards; ++r) {
         Shard &s = mu->shards[r];

@@ -154,6 +154,38 @@ def test_multi_session_errors_and_rccl_refusal(sv):
         ms.close()
 
 
+def test_a_shard_failing_between_the_meeting_points_releases_the_others(sv, monkeypatch):
+    """a shard whose all-reduce fails AFTER the first meeting point of a chain (fault injection: no argument check can produce
+    that) -- the others are released from the second one instead of waiting for ever, the call raises naming the shard, and
+    the NEXT call on the same multi-session is right: every job restarts the exchange slots at parity 0 on every shard (a
+    failed job leaves the shards' counters apart; shards on different parities would read each other's stale slots)"""
+    from stochvolmodels_amd._lib import SvmcError
+    from stochvolmodels_amd.multi import MultiDeviceSession
+    p = sv.LOGSV_BTC_PARAMS
+    ttms, fw, df, strikes, types = _small_chain()
+    args = (ttms, fw, df, strikes, types, p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol, np.ones(3), True, 200, 1, 99, 0)
+    ref, ref_sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=strikes, optiontypes_ttms=types,
+                                           v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                           vol_backbone_etas=np.ones(3), nb_path=50_000, nb_steps_per_year=200, seed=99)
+    for shard, k in ((1, 1), (2, 0), (0, 3)):              # second all-reduce of the first chain; first of the first; of the second chain
+        monkeypatch.setenv("SVMC_MULTI_FAULT", f"{shard},{k}")
+        ms = MultiDeviceSession([0, 0, 0], 50_000, 3, 21, reduce="host")
+        monkeypatch.delenv("SVMC_MULTI_FAULT")
+        try:
+            seen_failure = False
+            for call in range(4):
+                try:
+                    pr, sd = ms.price_logsv_chain(*args)
+                except SvmcError as exc:
+                    assert not seen_failure and f"shard {shard} " in str(exc) and "fault injection" in str(exc), str(exc)
+                    seen_failure = True
+                    continue
+                assert _rel(pr, ref) <= 1e-12 and _rel(sd, ref_sd) <= 1e-12 and ms.info()["shards_agree"] is True, (shard, k, call)
+            assert seen_failure
+        finally:
+            ms.close()
+
+
 def test_c4_eight_shards_of_full_size_on_one_device(sv):
     """C4 as the driver's 8-GPU run shards it -- 2^24 paths, 8 expiries x 128 steps, 8 x 21 strikes, EIGHT shards of 2^21 --
     through the multi-session on the one device there is (the shards run back to back on it), against the one-session job

@@ -2307,7 +2307,7 @@ def test_bench_default_line_ends_with_the_secondary_block():
     assert f3["bit_equal_to_mc_chain_pricer"] is True and f3["hbm_bytes_for_randoms"] == 0 and f3["one_set_with_ivols_ms"] < 1.0
     assert sec["c2_at_2e21_paths"]["psps"] > 0.9 * line["value"]
     assert sec["seconds"] < 30.0
-    assert len(__import__("json").dumps(sec)) < 2600
+    assert len(__import__("json").dumps(sec)) < 2000                 # the block fits the part of the line a truncating log keeps
 
 
 @pytest.mark.parametrize("rungs,want", [("nccl,rccl,gloo", "nccl"), ("rccl,gloo", "rccl"), ("gloo", "gloo")])

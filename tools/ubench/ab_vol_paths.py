@@ -11,6 +11,8 @@ import os
 import sys
 
 import numpy as np
+import torch  # BEFORE the library: one HIP runtime per process (torch links its bundled copy under the un-versioned name; loaded
+              # after libsvmc's libamdhip64.so.7 it would map a second one and see no device) -- stochvolmodels_amd/_lib.py does the same
 
 L = C.CDLL(os.path.abspath(sys.argv[1]))
 tag = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
@@ -40,7 +42,6 @@ for nb in (1024, 360):
     # svmc_fill_normals' UNSCALED N(0,1) here: sigma overflowed within tens of steps, the whole output was NaN (the committed
     # supplied_360_digest of profiles/r04_vol_paths.json) and NaN operands toggle less, draw less power and clock higher than
     # real data -- the "supplied" figures of round 4 were measured on that.  Now: scaled, and the digest must be finite.
-    import torch
     bt = torch.randn(nb, n, dtype=torch.float64, device="cuda") * (1.0 / 360) ** 0.5
     torch.cuda.synchronize()
     for mode, b in (("rng", None), ("supplied", vp(bt.data_ptr()))):
