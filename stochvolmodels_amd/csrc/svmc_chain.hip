@@ -187,8 +187,11 @@ static int all_reduce(Session *s, double *buf, size_t n)
 {
     if (!s->sharded() || n == 0) return SVMC_OK;
     if (s->reduce_fn != nullptr) {
+        last_error_ref().clear();
         const int rc = s->reduce_fn(s->reduce_user, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
-        return rc == SVMC_OK ? SVMC_OK : fail(rc, "the session's all-reduce callback failed");
+        if (rc == SVMC_OK) return SVMC_OK;
+        const std::string why = last_error_ref();          // what the callback itself said, if it went through this library
+        return fail(rc, "the session's all-reduce callback failed" + (why.empty() ? std::string() : ": " + why));
     }
     return svmc_rccl_all_reduce_sum(s->comm, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
 }
