@@ -341,7 +341,12 @@ def _run_probe(rung: str, port: int, timeout: float):
     """-> (ok, reason) of this rank's probe child for `rung`"""
     import subprocess
     import sys
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # the children rendezvous among THEMSELVES on `port`: under torch.distributed.run the ranks carry TORCHELASTIC_USE_AGENT_STORE
+    # (= "connect to the launcher's store at MASTER_PORT as a client"), which on a port of our own nobody serves -- every probe
+    # would wait for a store that never comes and the ladder would fall to gloo on a perfectly healthy RCCL.  Rank 0's child
+    # must host the store: the launcher's variables stay with the ranks.
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     try:
@@ -357,8 +362,10 @@ def _run_probe(rung: str, port: int, timeout: float):
         return False, f"probe did not finish within {timeout:.0f} s (killed)"
     if proc.returncode == 0:
         return True, ""
-    tail = [ln for ln in (out or "").strip().splitlines() if ln.strip()]
-    return False, (tail[-1] if tail else f"probe exited with status {proc.returncode}")[:240]
+    tail = [ln.strip() for ln in (out or "").strip().splitlines() if ln.strip()]
+    # the child's own last words: the last line that names an error, else its last line
+    said = [ln for ln in tail if any(w in ln for w in ("Error", "error:", "invalid", "failed", "fault injection")) and "Warning" not in ln]
+    return False, (said[-1] if said else (tail[-1] if tail else f"probe exited with status {proc.returncode}"))[:240]
 
 
 def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_timeout: Optional[float] = None):

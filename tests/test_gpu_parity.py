@@ -2310,12 +2310,16 @@ def test_bench_default_line_ends_with_the_secondary_block():
     assert len(__import__("json").dumps(sec)) < 2000                 # the block fits the part of the line a truncating log keeps
 
 
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
 @pytest.mark.parametrize("rungs,want", [("nccl,rccl,gloo", "nccl"), ("rccl,gloo", "rccl"), ("gloo", "gloo")])
-def test_fallback_ladder_rungs_on_hardware_with_one_rank(tmp_path, rungs, want):
+def test_fallback_ladder_rungs_on_hardware_with_one_rank(tmp_path, rungs, want, launcher):
     """every rung of dist.init_with_fallback brought up for real on this box with ONE rank (two ranks cannot share a device under
     RCCL): the probe child of the rung (its own rendezvous, an RCCL communicator, one all-reduce), then the rung in the process
     itself -- torch's nccl group beside the gloo control plane, or libsvmc's ncclCommInitRank -- and a chain priced through it
-    equals the ungrouped result bit for bit"""
+    equals the ungrouped result bit for bit.  launcher = "torchrun": the same under `python -m torch.distributed.run` -- the
+    driver's form -- whose environment (TORCHELASTIC_USE_AGENT_STORE: "the launcher serves the rendezvous store") must not leak into
+    the probe children, which rendezvous on a port of their own (they would wait for a store nobody serves, and a healthy RCCL
+    would be reported as hanging)"""
     import json
     import os
     import subprocess
@@ -2334,10 +2338,19 @@ def test_fallback_ladder_rungs_on_hardware_with_one_rank(tmp_path, rungs, want):
         "print(json.dumps({'rep': rep, 'equal': bool(all(np.array_equal(a, b) for a, b in zip(got, base))), 'seen': seen}))\n"
         "import torch.distributed as td\n"
         "td.destroy_process_group()\n")
-    env = {k: v for k, v in os.environ.items() if k not in ("SVMC_DIST_BACKEND",)}
-    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29731 + len(rungs)),
-               SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_DIST_RUNGS=rungs, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("SVMC_DIST_BACKEND", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT")}
+    env.update(SVMC_DIST_SINGLE_RANK_GROUP="1", SVMC_DIST_RUNGS=rungs, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29731 + len(rungs) + (40 if launcher == "torchrun" else 0))
+    if launcher == "torchrun":
+        script = tmp_path / "ladder_one_rank.py"
+        script.write_text(code)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", port, str(script)]
+    else:
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        cmd = [sys.executable, "-c", code]
+    run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-3000:]
     out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     rep = out["rep"]
