@@ -151,9 +151,11 @@ class DeviceArray:
     __cuda_array_interface__, `torch.from_dlpack(a)` through __dlpack__); `row_moments` / `expanding_mean_of_squares` do on
     the device what the reference's callers do with the host array; `numpy()` fetches it through the pinned pipeline."""
 
-    def __init__(self, buf: DeviceBuffer, shape: Tuple[int, int], stream=None, device: int = 0):
+    def __init__(self, buf: DeviceBuffer, shape: Tuple[int, int], stream=None, device: int = 0, owns: bool = True, scratch=None):
         self._buf, self.shape, self.stream, self.device = buf, (int(shape[0]), int(shape[1])), stream, int(device)
         self.dtype = np.dtype(np.float64)
+        self._owns = bool(owns)                    # False: a view of an engine's cached bulk buffer (free() leaves the buffer alone)
+        self._scratch = scratch                    # callable(n_doubles, slot) -> DeviceBuffer for temporaries (the engine's cache)
 
     @property
     def ptr(self) -> int:
@@ -194,6 +196,8 @@ class DeviceArray:
         lib = _lib.load()
         rows, cols = self.shape
         k2 = 2 * int(n_moments)
+        if not 1 <= int(n_moments) <= 4:
+            raise ValueError("n_moments must be 1 .. 4")
         sums, ws = DeviceBuffer(rows * k2), DeviceBuffer(rows * 4 * k2)
         try:
             _lib.check(lib.svmc_row_power_sums(self.ptr, cols, rows, cols, float(center), int(n_moments), sums.ptr, ws.ptr,
@@ -212,14 +216,18 @@ class DeviceArray:
     def expanding_mean_of_squares(self) -> "DeviceArray":
         """a new resident array q[t][p] = mean of a[u][p]^2 over u <= t (moments_vol_qvar.py:102: the realised variance so far)"""
         rows, cols = self.shape
-        out = DeviceBuffer(rows * cols)
+        if self._scratch is not None:              # a view of an engine's cache: the result lives in the engine's second bulk slot
+            out, owns = self._scratch(rows * cols, 1), False
+        else:
+            out, owns = DeviceBuffer(rows * cols), True
         _lib.check(_lib.load().svmc_expanding_mean_squares(self.ptr, cols, rows, cols, out.ptr, cols, self.stream))
-        return DeviceArray(out, self.shape, self.stream, self.device)
+        return DeviceArray(out, self.shape, self.stream, self.device, owns=owns)
 
     def free(self) -> None:
         if self._buf is not None:
             self.synchronize()
-            self._buf.free()
+            if self._owns:
+                self._buf.free()
             self._buf = None
 
 
@@ -287,6 +295,7 @@ class HipEngine:
         self._factors: Optional[DeviceBuffer] = None   # rough LogSV: [n_factors][n_path]
         self._sums = {}
         self._pinned, self._pinned_doubles = None, 0    # page-locked staging of the small result downloads
+        self._bulk = {}                                 # slot -> DeviceBuffer: multi-GB results kept between calls (_bulk_buffer)
         self._prof = None   # list of (name, start_event, stop_event) while kernel timing is on
         self.closed = False
         if n_snapshots:
@@ -389,6 +398,26 @@ class HipEngine:
     def snapshot(self, row: int, which: str = "x") -> None:
         src = self.x.ptr if which == "x" else self.qvar.ptr
         _lib.check(self.lib.svmc_memcpy_d2d(self.snapshot_ptr(row), src, 8 * self.n_path, self.stream))
+
+    def _bulk_buffer(self, n_doubles: int, slot: int = 0) -> DeviceBuffer:
+        """the engine's cached buffer for a bulk result that does not leave the call (the path array behind a NumPy return, the
+        arrays vol_path_moments reduces): grown when needed, kept until close() / release_bulk().  Allocating and freeing 8.6 GB
+        per call costs the runtime 0.25-0.7 s every other call (the VRAM is mapped and unmapped; profiles/r05_moments_timing
+        .jsonl) -- two hundred times the kernel that fills it."""
+        buf = self._bulk.get(slot)
+        if buf is None or buf.n < n_doubles:
+            if buf is not None:
+                buf.free()
+            buf = DeviceBuffer(int(n_doubles))
+            self._bulk[slot] = buf
+        return buf
+
+    def release_bulk(self) -> None:
+        """give the cached bulk buffers back (they otherwise stay with the engine: up to two path arrays of the largest size seen)"""
+        self.synchronize()
+        for b in self._bulk.values():
+            b.free()
+        self._bulk = {}
 
     # ---- randoms --------------------------------------------------------------------------------
     def _rand_buffer(self, n_doubles: int) -> DeviceBuffer:
@@ -563,10 +592,13 @@ class HipEngine:
             self.stream)))
 
     def logsv_vol_paths(self, nb_steps, dt, v0, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
-                        brownians: Optional[np.ndarray] = None, return_device: bool = False, out_host: Optional[np.ndarray] = None):
+                        brownians: Optional[np.ndarray] = None, return_device=False, out_host: Optional[np.ndarray] = None):
         """full-grid sigma paths [(nb_steps+1), n_path] (svmc_logsv_vol_paths): the host array (fetched through the pinned
-        pipeline, into out_host when given), or with return_device the resident DeviceArray (the caller frees it)"""
-        out = DeviceBuffer((nb_steps + 1) * self.n_path)
+        pipeline, into out_host when given); with return_device=True the resident DeviceArray (a fresh allocation the caller
+        owns and frees); with return_device="view" a DeviceArray over the engine's cached bulk buffer (valid until the engine's
+        next bulk call; what vol_path_moments reduces)"""
+        n_out = (nb_steps + 1) * self.n_path
+        out = DeviceBuffer(n_out) if return_device is True else self._bulk_buffer(n_out, 0)
         b_ptr = None
         if brownians is not None:
             (b_ptr,) = self.upload_randoms((brownians,))
@@ -574,7 +606,8 @@ class HipEngine:
                                                  float(theta), float(kappa1), float(kappa2), float(beta), float(volvol),
                                                  int(bool(is_spot_measure)), b_ptr, self.n_path, int(seed),
                                                  int(call_id), self.path_offset, self.stream))
-        arr = DeviceArray(out, (nb_steps + 1, self.n_path), self.stream, self.device)
+        arr = DeviceArray(out, (nb_steps + 1, self.n_path), self.stream, self.device, owns=return_device is True,
+                          scratch=None if return_device is True else self._bulk_buffer)
         if return_device:
             return arr
         host = arr.numpy(out_host)
@@ -641,7 +674,8 @@ class HipEngine:
         checks (SvmcError), it never touches freed memory"""
         self.closed = True
         self.__dict__.pop("_comm_bufs", None)       # a communicator's reduction tensors that lived on this engine (dist.TorchComm)
-        for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values()):
+        for b in (self.x, self.vol, self.qvar, self.ws, self._snap, self._rand, self._factors, *self._sums.values(),
+                  *self._bulk.values()):
             if b is not None:
                 b.free()
         if self._pinned is not None:

@@ -525,7 +525,7 @@ def vol_path_moments(ttm: float, v0: float, theta: float, kappa1: float, kappa2:
     [nb_steps + 1][n_terms], "std" (same shape; divide by sqrt(nb_path) for the standard error), "qvar_mean", "qvar_std"}."""
     sigma_t, grid_t = simulate_vol_paths(ttm=ttm, v0=v0, theta=theta, kappa1=kappa1, kappa2=kappa2, beta=beta, volvol=volvol,
                                          is_spot_measure=is_spot_measure, nb_path=nb_path, nb_steps_per_year=nb_steps_per_year,
-                                         seed=seed, return_device=True)
+                                         seed=seed, return_device="view")      # the engine's cached buffer: no 8.6 GB allocation per call
     try:
         mean, std = sigma_t.row_moments(center=theta if center is None else center, n_moments=n_terms)
         out = {"grid_t": grid_t, "mean": mean, "std": std}

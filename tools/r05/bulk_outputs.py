@@ -87,9 +87,10 @@ def main():
         res["return_device_s"] = time.perf_counter() - t0
         res["round4_pageable_copy_s"] = pageable_copy_s(dev.ptr, rows * n)
         dev.free()
-        t0 = time.perf_counter()
-        mom = pricer.vol_path_moments(p, ttm=ttm, nb_path=n, nb_steps=spy, seed=5, with_qvar=True)
-        res["vol_path_moments_with_qvar_s"] = time.perf_counter() - t0
+        for rep in range(3):               # rep 0 grows the engine's cached bulk buffers (an 8.6 GB hipMalloc maps VRAM: 0.2-0.7 s)
+            t0 = time.perf_counter()
+            mom = pricer.vol_path_moments(p, ttm=ttm, nb_path=n, nb_steps=spy, seed=5, with_qvar=True)
+            res[f"vol_path_moments_with_qvar_s_rep{rep}"] = time.perf_counter() - t0
         res["moment_rows"] = int(mom["mean"].shape[0])
         print(json.dumps(res), flush=True)
     for n in (1 << 20, 1 << 24):
