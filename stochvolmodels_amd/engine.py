@@ -80,9 +80,10 @@ class DeviceBuffer:
 # download here is a pipeline: the device-to-host copies run back to back, asynchronously, into a ring of page-locked
 # buffers the process keeps, and a few host threads move each finished chunk into the destination array while the next
 # chunks are in flight (NumPy releases the GIL while it copies) -- the GPU link and the host's memory system both stay busy.
-PIPELINE_CHUNK_BYTES = 32 << 20
-PIPELINE_SLOTS = 6
-PIPELINE_THREADS = 4
+import os as _os
+PIPELINE_CHUNK_BYTES = int(_os.environ.get("SVMC_PIPELINE_CHUNK_MIB", "32")) << 20
+PIPELINE_SLOTS = int(_os.environ.get("SVMC_PIPELINE_SLOTS", "8"))
+PIPELINE_THREADS = int(_os.environ.get("SVMC_PIPELINE_THREADS", "6"))        # swept in profiles/r05_pipeline_sweep.jsonl
 PIPELINE_MIN_BYTES = 8 << 20                   # below this a plain copy is as fast
 _pinned_ring = {"ptr": None, "slots": 0, "chunk": 0, "lock": threading.Lock()}
 _copy_pool = None
