@@ -411,6 +411,14 @@ def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_time
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     phase("rendezvous")
+    if dist.is_initialized() and "gloo" not in str(dist.get_backend()):
+        # the caller brought its own process group (nccl): it IS the collective layer; there is no control plane to vote on
+        chosen = TorchComm()
+        report.update(rung=str(dist.get_backend()), comm="TorchComm", backend=str(dist.get_backend()), control_plane=None)
+        _share_rng_seed(chosen)
+        set_default_comm(chosen)
+        phase("ready")
+        return chosen, report
     if not dist.is_initialized():
         dist.init_process_group(backend="gloo")
     control = TorchComm()                                # the gloo world group

@@ -260,11 +260,27 @@ def _dlpack_capsule(arr: "DeviceArray"):
     m.deleter = deleter
     _DLPACK_ALIVE[key] = (m, shape, deleter, arr)          # owner of everything the consumer may touch
     C.pythonapi.PyCapsule_New.restype = C.py_object
-    C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
-    return C.pythonapi.PyCapsule_New(C.addressof(m), b"dltensor", None)
+    C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, _CAPSULE_DESTRUCTOR]
+    return C.pythonapi.PyCapsule_New(C.addressof(m), b"dltensor", _drop_unconsumed_capsule)
 
 
 _DLPACK_ALIVE = {}
+_CAPSULE_DESTRUCTOR = C.CFUNCTYPE(None, C.c_void_p)
+
+
+@_CAPSULE_DESTRUCTOR
+def _drop_unconsumed_capsule(capsule):
+    """a capsule nobody consumed (still named "dltensor" when it dies) releases what it kept alive; a consumed one was renamed
+    "used_dltensor" and its consumer calls the tensor's deleter"""
+    C.pythonapi.PyCapsule_IsValid.restype = C.c_int
+    C.pythonapi.PyCapsule_IsValid.argtypes = [C.c_void_p, C.c_char_p]
+    if C.pythonapi.PyCapsule_IsValid(capsule, b"dltensor"):
+        C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+        C.pythonapi.PyCapsule_GetPointer.argtypes = [C.c_void_p, C.c_char_p]
+        addr = C.pythonapi.PyCapsule_GetPointer(capsule, b"dltensor")
+        for key, kept in list(_DLPACK_ALIVE.items()):
+            if C.addressof(kept[0]) == addr:
+                _DLPACK_ALIVE.pop(key, None)
 
 
 class HipEngine:

@@ -479,3 +479,34 @@ def test_bench_watchdog_ends_a_stuck_phase():
     assert stuck.returncode == 1 and "finished" not in stuck.stdout
     assert "rank 7" in stuck.stderr and "a collective that never returns" in stuck.stderr and "did not finish within 2 s" in stuck.stderr
     assert "time.sleep" in stuck.stderr or "Timeout" in stuck.stderr or "line" in stuck.stderr          # the traceback
+
+
+def test_dlpack_capsule_keeps_and_releases_its_owner():
+    """engine.DeviceArray.__dlpack__ (no GPU needed for the plumbing): the capsule is a "dltensor" of a kDLROCM float64 2-d tensor
+    that keeps the array alive; a capsule nobody consumed releases it when it dies, a consumed one when the consumer calls the
+    tensor's deleter"""
+    import ctypes as C
+    import gc
+
+    from stochvolmodels_amd import engine
+
+    class FakeArray:
+        shape, device, ptr = (3, 4), 2, 0x7000
+
+    before = len(engine._DLPACK_ALIVE)
+    cap = engine._dlpack_capsule(FakeArray())
+    assert len(engine._DLPACK_ALIVE) == before + 1
+    C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+    C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+    assert C.pythonapi.PyCapsule_GetName(cap) == b"dltensor"
+    m = next(v[0] for v in engine._DLPACK_ALIVE.values() if v[3].__class__ is FakeArray)
+    t = m.dl_tensor
+    assert (t.data, t.device.device_type, t.device.device_id, t.ndim, t.dtype.code, t.dtype.bits, t.dtype.lanes) == \
+        (0x7000, 10, 2, 2, 2, 64, 1) and [t.shape[0], t.shape[1]] == [3, 4] and not t.strides
+    del cap, m, t
+    gc.collect()
+    assert len(engine._DLPACK_ALIVE) == before                       # unconsumed: released with the capsule
+    cap = engine._dlpack_capsule(FakeArray())
+    m = next(v[0] for v in engine._DLPACK_ALIVE.values() if v[3].__class__ is FakeArray)
+    m.deleter(C.pointer(m))                                          # what a consumer does when it is done with the tensor
+    assert len(engine._DLPACK_ALIVE) == before
