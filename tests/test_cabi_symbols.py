@@ -67,14 +67,15 @@ def test_no_cpu_fallback():
                                   strikes_ttm=np.array([1.0]), optiontypes_ttm=np.array(["C"]))
 
 
-def test_c_example_compiles_and_links(tmp_path):
-    """examples/price_chain.c is a plain-C host of the library: it must compile with gcc against include/svmc.h and link
-    against libsvmc.so (it is RUN by the gpu suite)"""
+@pytest.mark.parametrize("name", ["price_chain", "price_chain_rccl", "price_chain_multi"])
+def test_c_example_compiles_and_links(tmp_path, name):
+    """the examples are plain-C hosts of the library -- one GPU, a process per GPU over RCCL, several GPUs from one process: each
+    must compile with gcc -Wall -Werror against include/svmc.h and link against libsvmc.so (they are RUN by the gpu suite)"""
     from stochvolmodels_amd import build
     lib = build.build()
-    exe = str(tmp_path / "price_chain")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(lib)
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "price_chain.c"), "-o", exe, "-L" + libdir, "-lsvmc",
+                    os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + libdir, "-lsvmc",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"], check=True)
     assert os.path.exists(exe)
