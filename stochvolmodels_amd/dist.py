@@ -364,7 +364,9 @@ def _run_probe(rung: str, port: int, timeout: float):
         return True, ""
     tail = [ln.strip() for ln in (out or "").strip().splitlines() if ln.strip()]
     # the child's own last words: the last line that names an error, else its last line
-    said = [ln for ln in tail if any(w in ln for w in ("Error", "error:", "invalid", "failed", "fault injection")) and "Warning" not in ln]
+    import re
+    exc = [ln for ln in tail if re.search(r"\b\w*(Error|Exception)\b: \S", ln)]          # "RuntimeError: ...", "DistBackendError: ..."
+    said = exc or [ln for ln in tail if any(w in ln for w in ("invalid", "failed", "fault injection")) and "Warning" not in ln]
     return False, (said[-1] if said else (tail[-1] if tail else f"probe exited with status {proc.returncode}"))[:240]
 
 
