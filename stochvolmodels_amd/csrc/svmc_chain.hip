@@ -165,6 +165,27 @@ static int enqueue_payoff_sums_of_set(Session *s, const ChainView &c, int variab
                                   variable_type, s->sums + 3 * K * static_cast<size_t>(set), s->ws, s->ws_bytes, s->stream);
 }
 
+// the payoff sums of all n_sets sets: one launch and one column reduce where the chain allows it (the bits of the per-set loop)
+static int enqueue_payoff_sums_of_sets(Session *s, const ChainView &c, int variable_type, const std::vector<double> &shifts,
+                                       int n_sets)
+{
+    if (n_sets > 1 && payoff_sets_fit(s->n_path, c.m, c.offsets, c.types, n_sets, s->ws_bytes)) {
+        const size_t n = s->n_path;
+        std::vector<const double *> xs(c.m), qs(c.m);
+        for (int i = 0; i < c.m; ++i) {
+            xs[i] = s->snap + static_cast<size_t>(i) * n;
+            qs[i] = s->snap + static_cast<size_t>(n_sets * c.m + i) * n;
+        }
+        return payoff_sums_chain_sets(xs.data(), variable_type == SVMC_Q_VAR ? qs.data() : nullptr, n, c.forwards, c.ttms, s->spot,
+                                      c.m, c.strikes, c.types, shifts.data(), c.offsets, variable_type, s->sums, s->ws, s->ws_bytes,
+                                      s->stream, n_sets, static_cast<size_t>(c.m) * n, static_cast<size_t>(c.m) * n,
+                                      2 * static_cast<size_t>(c.m));
+    }
+    for (int q = 0; q < n_sets; ++q)
+        if (int rc = enqueue_payoff_sums_of_set(s, c, variable_type, shifts, q, n_sets)) return rc;
+    return SVMC_OK;
+}
+
 // phase 4: host finalisation of the downloaded sums (utils/mc_payoffs.py:85-88); the standard error divides by the
 // path count of the WHOLE job
 static int finalize_prices(const Session *s, const ChainView &c, const double *sums, const std::vector<double> &shifts,
@@ -454,14 +475,13 @@ int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_h
             }
             std::vector<double> unused;
             if (e == hipSuccess && rc == SVMC_OK) rc = enqueue_payoff_sums(s, c, variable_type, unused);
-            if (e == hipSuccess && rc == SVMC_OK && n_sums)
-                e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-            if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr) {
+            // results home: with implied vols the last kernel writes both the sums and the vols into the pinned host buffers
+            // (two copy nodes fewer per replay); without, the sums' copy
+            if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr)
                 rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, static_cast<double>(s->n_path), IV_VOL_LO, IV_VOL_HI,
-                                        g.ivols_dev, s->stream);
-                if (rc == SVMC_OK)
-                    e = hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-            }
+                                        g.ivols_host, g.sums_host, s->stream);
+            else if (e == hipSuccess && rc == SVMC_OK && n_sums)
+                e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
             const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
             if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
             if (e != hipSuccess || e_end != hipSuccess) {
@@ -597,16 +617,12 @@ int svmc_logsv_chain_price_fixed_sets(svmc_session_t session, const double *ttms
             rc = logsv_chain_w_sets(n, P, c.m, nb_steps_host, g.params_dev + P, g.params_dev, W0s, W1s, ldw, c.forwards, s->snap,
                                     qsnaps, s->spot, s->ws, s->ws_bytes, s->stream);
         }
-        for (int q = 0; q < P && e == hipSuccess && rc == SVMC_OK; ++q)
-            rc = enqueue_payoff_sums_of_set(s, c, variable_type, shifts, q, P);
-        if (e == hipSuccess && rc == SVMC_OK && n_sums)
-            e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-        if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr) {
+        if (e == hipSuccess && rc == SVMC_OK) rc = enqueue_payoff_sums_of_sets(s, c, variable_type, shifts, P);
+        if (e == hipSuccess && rc == SVMC_OK && g.ivols_dev != nullptr)       // (the last kernel writes the pinned host buffers)
             rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, static_cast<double>(s->n_path), IV_VOL_LO, IV_VOL_HI,
-                                    g.ivols_dev, s->stream);
-            if (rc == SVMC_OK)
-                e = hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream);
-        }
+                                    g.ivols_host, g.sums_host, s->stream);
+        else if (e == hipSuccess && rc == SVMC_OK && n_sums)
+            e = hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream);
         const hipError_t e_end = hipStreamEndCapture(s->stream, &g.graph);      // always leave capture mode
         if (rc != SVMC_OK) { fixed_graph_release(g); return rc; }
         if (e != hipSuccess || e_end != hipSuccess) {
@@ -719,14 +735,14 @@ int svmc_logsv_chain_price_frozen_sets(svmc_session_t session, const double *ttm
                                           s->path_offset, s->snap, qsnaps, s->spot, s->ws, s->ws_bytes, s->stream, !graph))
             return rc;
         if (int rc = all_reduce(s, s->spot, 2 * static_cast<size_t>(c.m) * P)) return rc;
-        for (int q = 0; q < P; ++q)
-            if (int rc = enqueue_payoff_sums_of_set(s, c, variable_type, shifts, q, P)) return rc;
+        if (int rc = enqueue_payoff_sums_of_sets(s, c, variable_type, shifts, P)) return rc;
         if (int rc = all_reduce(s, s->sums, n_sums)) return rc;
-        if (n_sums) SVMC_HIP_TRY(hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        if (g.ivols_dev != nullptr) {
-            if (int rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, n_all, IV_VOL_LO, IV_VOL_HI, g.ivols_dev, s->stream))
+        if (g.ivols_dev != nullptr) {               // (the last kernel writes the pinned host buffers: no copy nodes)
+            if (int rc = chain_implied_vols(s->sums, g.quotes_dev, n_quotes, n_all, IV_VOL_LO, IV_VOL_HI, g.ivols_host, g.sums_host,
+                                            s->stream))
                 return rc;
-            SVMC_HIP_TRY(hipMemcpyAsync(g.ivols_host, g.ivols_dev, n_quotes * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        } else if (n_sums) {
+            SVMC_HIP_TRY(hipMemcpyAsync(g.sums_host, s->sums, n_sums * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         }
         return SVMC_OK;
     };

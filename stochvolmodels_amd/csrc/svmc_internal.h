@@ -55,9 +55,20 @@ int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_
                          size_t workspace_bytes, hipStream_t stream, bool allow_probe);
 void logsv_fast_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,
                            int is_spot_measure, double *out);
+// payoff sums of n_sets parameter sets' snapshots in ONE launch and ONE column reduce (bit-equal to n_sets calls of
+// svmc_payoff_sums_chain); payoff_sets_fit says whether the chain's strike groups fit one launch and the workspace
+bool payoff_sets_fit(size_t n_path, int n_expiries, const size_t *offsets, const int8_t *types, int n_sets, size_t workspace_bytes);
+int payoff_sums_chain_sets(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
+                           const double *forwards_host, const double *ttms_host, const double *spot_sums, int n_expiries,
+                           const double *strikes_host, const int8_t *types_host, const double *shifts_host,
+                           const size_t *strike_offsets_host, int variable_type, double *sums, void *workspace,
+                           size_t workspace_bytes, hipStream_t stream, int n_sets, size_t x_set_stride, size_t q_set_stride,
+                           size_t spot_set_stride);
 constexpr int IV_QUOTE_DOUBLES_HOST = 6;   // = IV_QUOTE_DOUBLES of svmc_kernels.hip: {strike, code, shift, forward, ttm, df}
+// ivols_out and sums_copy (nullable: the kernel also stores the 3 x n_quotes sums it read) may be device-visible pinned host
+// memory: the results of a graph then reach the host without copy nodes
 int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,
-                       double vol_hi, double *ivols_dev, hipStream_t stream);
+                       double vol_hi, double *ivols_out, double *sums_copy, hipStream_t stream);
 // svmc_comm.hip: ncclCommInitAll -- comms_out[n] communicators for the devices[n] of this process (svmc_multi.hip)
 int rccl_comm_init_all(int n, const int *devices, void **comms_out);
 void logsv_consts_to_doubles(double dt, double theta, double kappa1, double kappa2, double beta, double volvol, double eta,

@@ -1366,7 +1366,12 @@ struct PayoffGroup {
 struct PayoffGroupPack {
     PayoffGroup g[PAYOFF_GROUPS];
 };
-static_assert(sizeof(PayoffGroupPack) + 64 <= 4096, "the payoff descriptors travel in the kernel arguments");
+// parameter sets of one chain (the calibration's bumped evaluations) share every descriptor; their snapshots, spot sums and
+// output rows lie at fixed distances, and blockIdx.z picks the set: doubles between consecutive sets (zeros for one set)
+struct PayoffSetStrides {
+    size_t x, q, spot;
+};
+static_assert(sizeof(PayoffGroupPack) + sizeof(PayoffSetStrides) + 64 <= 4096, "the payoff descriptors travel in the kernel arguments");
 
 // number of indices i < n visited by block b of a grid-stride loop (stride = grid * BLOCK, BLOCK consecutive per block)
 __device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigned grid)
@@ -1385,15 +1390,17 @@ __device__ __forceinline__ double block_path_count(size_t n, unsigned b, unsigne
 constexpr int payoff_min_waves(int kt, bool has_inv) { return kt <= (has_inv ? 5 : 12) ? 3 : 2; }
 
 template <int KT, bool HAS_INV, bool NEED_Q>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV), payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_min_waves(KT, HAS_INV), payoff_min_waves(KT, HAS_INV)))) void payoff_group_kernel(PayoffGroupPack pack, size_t n, double *__restrict__ partials, int ld, PayoffSetStrides sets)
 {
     constexpr int NACC = HAS_INV ? 3 : 2;
     __shared__ double lds[4 * block_sum_padded(NACC * KT)];
     const PayoffGroup &d = pack.g[blockIdx.y];
-    const double *__restrict__ x = d.x;
-    const double *__restrict__ qvar = d.qvar;
+    const size_t set = blockIdx.z;                          // parameter set (one launch prices gridDim.z of them)
+    const double *__restrict__ x = d.x + set * sets.x;
+    const double *__restrict__ qvar = NEED_Q ? d.qvar + set * sets.q : nullptr;
+    const double *__restrict__ spot_sums = d.spot_sums + set * sets.spot;
     const double forward = d.forward, inv_ttm_arg = d.ttm;
-    const double corr = d.spot_sums[0] / d.spot_sums[1] - forward;                              // :62
+    const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
     const int nk = d.k;
     const uint32_t inv_mask = d.inv_mask;
@@ -1461,7 +1468,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
     }
     for (size_t i = i0 + static_cast<size_t>(full_trips) * stride; i < n; i += stride) add_path(x[i], need_q ? qvar[i] : 0.0);
     // output row layout: [sum d, sum d^2, count] per strike, interleaved, at column 3 (col + k)
-    double *row = partials + static_cast<size_t>(blockIdx.x) * ld + 3 * d.col;
+    // (sets interleave within a block row: partials[path block][set][column], so that one column reduce serves them all)
+    double *row = partials + (static_cast<size_t>(blockIdx.x) * gridDim.z + set) * ld + 3 * d.col;
     const double cnt = block_path_count(n, blockIdx.x, gridDim.x);
     block_sum_apply<NSUM>(acc, lds, NACC * KT, [&](int j, double t) {
         const int which = j / KT, k = j - which * KT;
@@ -1958,13 +1966,20 @@ void logsv_fast_to_doubles(double dt, double theta, double kappa1, double kappa2
 constexpr int IV_QUOTE_DOUBLES = 6;
 __global__ __launch_bounds__(64) void chain_implied_vols_kernel(const double *__restrict__ sums, const double *__restrict__ quotes,
                                                                size_t n_quotes, double n_path_total, double vol_lo,
-                                                               double vol_hi, double *__restrict__ ivols)
+                                                               double vol_hi, double *__restrict__ ivols,
+                                                               double *__restrict__ sums_copy)
 {
     const size_t k = static_cast<size_t>(blockIdx.x) * 64 + threadIdx.x;
     if (k >= n_quotes) return;
     const double *qd = quotes + IV_QUOTE_DOUBLES * k;
     double price, se;
-    payoff_finalize_one(sums[3 * k], sums[3 * k + 1], sums[3 * k + 2], qd[2], qd[5], n_path_total, &price, &se);
+    const double s0 = sums[3 * k], s1 = sums[3 * k + 1], s2 = sums[3 * k + 2];
+    if (sums_copy != nullptr) {         // the caller's pinned host buffer: the sums go home from here, not by a copy node
+        sums_copy[3 * k] = s0;
+        sums_copy[3 * k + 1] = s1;
+        sums_copy[3 * k + 2] = s2;
+    }
+    payoff_finalize_one(s0, s1, s2, qd[2], qd[5], n_path_total, &price, &se);
     const int code = static_cast<int>(qd[1]);
     // inverse quotes (IC / IP): the Black-76 value of (S - K)^+ / S is the vanilla value over the forward
     const bool call = code == SVMC_CALL || code == SVMC_INV_CALL;
@@ -1972,11 +1987,11 @@ __global__ __launch_bounds__(64) void chain_implied_vols_kernel(const double *__
 }
 
 int chain_implied_vols(const double *sums_dev, const double *quotes_dev, size_t n_quotes, double n_path_total, double vol_lo,
-                       double vol_hi, double *ivols_dev, hipStream_t stream)
+                       double vol_hi, double *ivols_out, double *sums_copy, hipStream_t stream)
 {
     if (n_quotes == 0) return SVMC_OK;
     hipLaunchKernelGGL(chain_implied_vols_kernel, dim3(static_cast<unsigned>((n_quotes + 63) / 64)), dim3(64), 0, stream, sums_dev,
-                       quotes_dev, n_quotes, n_path_total, vol_lo, vol_hi, ivols_dev);
+                       quotes_dev, n_quotes, n_path_total, vol_lo, vol_hi, ivols_out, sums_copy);
     return check_launch("chain_implied_vols");
 }
 
@@ -2443,7 +2458,7 @@ int svmc_spot_sums(const double *x, size_t n_path, double forward, double *spot_
 // the launches of svmc_payoff_sums / svmc_payoff_sums_chain: groups of <= PAYOFF_KT strikes of one expiry, <= PAYOFF_GROUPS
 // groups per launch, every launch followed by its column reduce
 // one kernel per group width: a chain's 21 (or 13) strikes per expiry are worked on as 21, not as the next multiple of 8
-using PayoffKernel = void (*)(PayoffGroupPack, size_t, double *, int);
+using PayoffKernel = void (*)(PayoffGroupPack, size_t, double *, int, PayoffSetStrides);
 template <bool HAS_INV, bool NEED_Q, int... KS>
 static PayoffKernel payoff_kernel_for(int kt, std::integer_sequence<int, KS...>)
 {
@@ -2452,21 +2467,45 @@ static PayoffKernel payoff_kernel_for(int kt, std::integer_sequence<int, KS...>)
 }
 constexpr int PAYOFF_KT_INV = 16;      // inverse chains: three accumulators per strike, 24 would leave one wave per SIMD
 
+// path blocks per strike group of a payoff launch: about a thousand blocks per launch in all (512 are resident at the kernel's
+// two waves per SIMD) -- more groups, fewer and longer-running blocks each, so that a block's set-up (its constants) and
+// wind-down (the 48-value block reduction) are amortised over more paths (C3's 4 groups: 118 -> 108 us) -- and no block with
+// fewer than PAYOFF_MIN_TRIPS paths per lane: at a calibration's 10^5 paths 256 blocks per group made 1.5 trips each and the
+// launch was set-up and wind-down only (4 groups 9.1 us; x 7 parameter sets 39 us).  A function of the path count and the
+// group count alone -- never of the number of parameter sets -- so that every route adds the same partial sums.
+#ifndef SVMC_PAYOFF_MIN_TRIPS
+#define SVMC_PAYOFF_MIN_TRIPS 4
+#endif
+static inline unsigned payoff_path_blocks(size_t n_path, int n_groups)
+{
+    const unsigned g = reduce_grid(n_path);
+    unsigned gx = (PAYOFF_BLOCKS + static_cast<unsigned>(n_groups) - 1u) / static_cast<unsigned>(n_groups);
+    gx = (gx < 128u) ? 128u : gx;
+    gx = (gx > g) ? g : gx;
+    const size_t cap = (n_path + static_cast<size_t>(BLOCK) * SVMC_PAYOFF_MIN_TRIPS - 1) / (static_cast<size_t>(BLOCK) * SVMC_PAYOFF_MIN_TRIPS);
+    if (cap < gx) gx = static_cast<unsigned>(cap < 1 ? 1 : cap);
+    return gx;
+}
+
 template <bool HAS_INV>
 static void launch_payoff_groups(int kt, dim3 grid, hipStream_t st, const PayoffGroupPack &pack, size_t n, int variable_type,
-                                 double *partials, int ld)
+                                 double *partials, int ld, const PayoffSetStrides &sets)
 {
     constexpr auto widths = std::make_integer_sequence<int, HAS_INV ? PAYOFF_KT_INV : PAYOFF_KT>();
     const PayoffKernel kern = (variable_type == SVMC_Q_VAR) ? payoff_kernel_for<HAS_INV, true>(kt, widths)
                                                             : payoff_kernel_for<HAS_INV, false>(kt, widths);
-    hipLaunchKernelGGL(kern, grid, dim3(BLOCK), 0, st, pack, n, partials, ld);
+    hipLaunchKernelGGL(kern, grid, dim3(BLOCK), 0, st, pack, n, partials, ld, sets);
 }
 
 static int payoff_sums_impl(const char *fn, const double *const *xs, const double *const *qs, size_t n_path,
                             const double *forwards, const double *ttms, const double *spot_sums, int n_expiries,
                             const double *strikes, const int8_t *types, const double *shifts, const size_t *offsets,
-                            int variable_type, double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
+                            int variable_type, double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream,
+                            int n_sets = 1, const PayoffSetStrides &sets = PayoffSetStrides{0, 0, 0})
 {
+    // n_sets > 1: xs / qs / spot_sums / sums are those of set 0 and the others lie `sets` (and 3 x total sums) further on; the
+    // chain must then fit ONE launch (payoff_sets_fit), whose path blocks are those of a one-set launch -- the same partial
+    // sums added in the same order, hence the bits of n_sets calls
     const size_t total = offsets[n_expiries];
     bool any_inv = false;
     for (size_t k = 0; k < total; ++k) {
@@ -2489,19 +2528,17 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
     bool has_inv = false;
     auto flush = [&]() -> int {
         if (n_groups == 0) return SVMC_OK;
-        // path blocks per group: about a thousand blocks per launch in all (512 are resident at the kernel's two waves
-        // per SIMD) -- more groups, fewer and longer-running blocks each, so that a block's set-up (its constants) and
-        // wind-down (the 48-value block reduction) are amortised over more paths (C3's 4 groups: 118 -> 108 us)
-        unsigned gx = (PAYOFF_BLOCKS + static_cast<unsigned>(n_groups) - 1u) / static_cast<unsigned>(n_groups);
-        gx = (gx < 128u) ? 128u : gx;
-        gx = (gx > g) ? g : gx;
-        const dim3 grid(gx, static_cast<unsigned>(n_groups));
+        const unsigned gx = payoff_path_blocks(n_path, n_groups);
+        const dim3 grid(gx, static_cast<unsigned>(n_groups), static_cast<unsigned>(n_sets));
+        if (n_sets > 1 && (first_strike != 0 || static_cast<size_t>(cols) != total ||
+                           static_cast<size_t>(gx) * n_sets * 3 * cols * sizeof(double) > workspace_bytes))
+            return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": the parameter sets do not fit one payoff launch");
         if (has_inv)
-            launch_payoff_groups<true>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
+            launch_payoff_groups<true>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols, sets);
         else
-            launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<unsigned>(gx), static_cast<size_t>(3 * cols), size_t(1), sums + 3 * first_strike);
+            launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols, sets);
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols * n_sets), dim3(BLOCK), 0, as_stream(stream), partials,
+                           static_cast<unsigned>(gx), static_cast<size_t>(3 * cols) * n_sets, size_t(1), sums + 3 * first_strike);
         first_strike += static_cast<size_t>(cols);
         n_groups = cols = kt = 0;
         has_inv = false;
@@ -2539,6 +2576,41 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
     }
     return flush();
 }
+
+namespace svmc {
+
+// whether payoff_sums_chain_sets can take this chain: all its strike groups in one launch, the sets' partials in the workspace
+bool payoff_sets_fit(size_t n_path, int n_expiries, const size_t *offsets, const int8_t *types, int n_sets, size_t workspace_bytes)
+{
+    const size_t total = offsets[n_expiries];
+    if (n_path == 0 || total == 0 || n_sets < 1 || n_sets > 65535) return false;
+    bool any_inv = false;
+    for (size_t k = 0; k < total; ++k) any_inv = any_inv || types[k] >= SVMC_INV_CALL;
+    const size_t KG = any_inv ? PAYOFF_KT_INV : PAYOFF_KT;
+    size_t n_groups = 0;
+    for (int i = 0; i < n_expiries; ++i) n_groups += (offsets[i + 1] - offsets[i] + KG - 1) / KG;
+    if (n_groups == 0 || n_groups > static_cast<size_t>(PAYOFF_GROUPS)) return false;
+    const unsigned g = reduce_grid(n_path), gx = payoff_path_blocks(n_path, static_cast<int>(n_groups));
+    return static_cast<size_t>(gx) * n_sets * 3 * total * sizeof(double) <= workspace_bytes &&
+           static_cast<size_t>(g) * 3 * PAYOFF_KT * PAYOFF_GROUPS * sizeof(double) <= workspace_bytes;
+}
+
+// svmc_payoff_sums_chain for n_sets parameter sets at once: ONE payoff launch (blockIdx.z = set) and ONE column reduce
+// instead of n_sets of each; sums[set][3 x total].  Bit-equal to n_sets calls of svmc_payoff_sums_chain.
+int payoff_sums_chain_sets(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
+                           const double *forwards_host, const double *ttms_host, const double *spot_sums, int n_expiries,
+                           const double *strikes_host, const int8_t *types_host, const double *shifts_host,
+                           const size_t *strike_offsets_host, int variable_type, double *sums, void *workspace,
+                           size_t workspace_bytes, hipStream_t stream, int n_sets, size_t x_set_stride, size_t q_set_stride,
+                           size_t spot_set_stride)
+{
+    return payoff_sums_impl("payoff_sums_chain_sets", x_snapshots_host, qvar_snapshots_host, n_path, forwards_host, ttms_host,
+                            spot_sums, n_expiries, strikes_host, types_host, shifts_host, strike_offsets_host, variable_type, sums,
+                            workspace, workspace_bytes, reinterpret_cast<svmc_stream_t>(stream), n_sets,
+                            PayoffSetStrides{x_set_stride, q_set_stride, spot_set_stride});
+}
+
+}  // namespace svmc
 
 extern "C" {
 

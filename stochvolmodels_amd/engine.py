@@ -27,14 +27,34 @@ HESTON_EULER_FLOOR, HESTON_QE = 0, 1
 _TYPE_CODES = {"C": 0, "P": 1, "IC": 2, "IP": 3}
 
 
+_CODES_CACHE = {}           # (dtype, bytes) of a NumPy array of option types -> its int8 codes (read-only)
+
+
 def option_type_codes(optiontypes: Sequence) -> np.ndarray:
-    """'C','P','IC','IP' -> int8; anything else raises like utils/mc_payoffs.py:84."""
+    """'C','P','IC','IP' -> int8; anything else raises like utils/mc_payoffs.py:84.  The codes of a NumPy array are kept
+    (a calibration asks for the same few arrays at every objective evaluation) and come back read-only."""
+    key = None
+    if isinstance(optiontypes, np.ndarray) and optiontypes.dtype.kind == "U" and optiontypes.size <= 4096:
+        key = (optiontypes.dtype.str, optiontypes.shape, optiontypes.tobytes())
+        hit = _CODES_CACHE.get(key)
+        if hit is not None:
+            return hit
+        if optiontypes.ndim != 1:
+            out = option_type_codes(optiontypes.ravel()).reshape(optiontypes.shape)
+            out.flags.writeable = False
+            _CODES_CACHE[key] = out
+            return out
     out = np.empty(len(optiontypes), dtype=np.int8)
     for i, t in enumerate(optiontypes):
         code = _TYPE_CODES.get(str(t))
         if code is None:
             raise ValueError("unknown option payoff code")
         out[i] = code
+    if key is not None:
+        if len(_CODES_CACHE) > 256:
+            _CODES_CACHE.clear()
+        out.flags.writeable = False
+        _CODES_CACHE[key] = out
     return out
 
 
@@ -842,6 +862,38 @@ class DeviceRandoms:
         return (split(prices), split(stderrs), split(ivols)) if want_ivols else (split(prices), split(stderrs))
 
 
+    def _marshalled_chain(self, ttms, forwards, discfactors, strikes, codes):
+        """the chain's arrays as the C ABI takes them (contiguous copies, their ctypes pointers, the strike offsets and the
+        slices that cut a result row into expiries), kept per chain CONTENT: the objective of a calibration prices the same
+        chain hundreds of times and the marshalling was a quarter of an evaluation's wall time."""
+        arrs = [np.asarray(ttms), np.asarray(forwards), np.asarray(discfactors)] + list(strikes) + list(codes)
+        key = tuple((a.dtype.str, a.shape, a.tobytes()) for a in arrs)
+        cache = self.__dict__.setdefault("_chain_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        m = len(self)
+        dp = C.POINTER(C.c_double)
+        f64 = lambda a: np.array(a, dtype=np.float64, order="C", copy=True).ravel()      # noqa: E731  (private copies)
+        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
+        total = int(offs[-1])
+        t, f, d = f64(ttms), f64(forwards), f64(discfactors)
+        k_all = f64(np.concatenate(strikes)) if total else np.zeros(1)
+        c_all = np.array(np.concatenate(codes), dtype=np.int8) if total else np.zeros(1, dtype=np.int8)
+        dts = f64(self.dts)
+        hit = {
+            "keep": (t, f, d, k_all, c_all, offs, dts), "total": total, "offs": offs,
+            "slices": [slice(int(offs[i]), int(offs[i + 1])) for i in range(m)],
+            "ttms": t.ctypes.data_as(dp), "forwards": f.ctypes.data_as(dp), "discfactors": d.ctypes.data_as(dp),
+            "strikes": k_all.ctypes.data_as(dp), "codes": c_all.ctypes.data_as(C.POINTER(C.c_int8)),
+            "offsets": offs.ctypes.data_as(C.POINTER(C.c_size_t)), "nbs": (C.c_int * m)(*self.nb_steps),
+            "dts": dts.ctypes.data_as(dp),
+        }
+        if len(cache) >= 8:
+            cache.clear()
+        cache[key] = hit
+        return hit
+
     def price_logsv_chain_sets(self, ttms, forwards, discfactors, strikes: Sequence[np.ndarray], codes: Sequence[np.ndarray],
                                params_rows: np.ndarray, is_spot_measure: bool, variable_type: int, want_ivols: bool = False,
                                use_graph: bool = True, comm_handle=None, rank: int = 0, world: int = 1):
@@ -855,8 +907,8 @@ class DeviceRandoms:
         n_sets = params_rows.shape[0]
         if params_rows.ndim != 2 or params_rows.shape[1] != 6 + m or n_sets < 1:
             raise ValueError("params_rows must have shape [n_sets, 6 + n_expiries]")
-        offs = np.concatenate([[0], np.cumsum([len(k) for k in strikes])]).astype(np.uintp)
-        total = int(offs[-1])
+        ch = self._marshalled_chain(ttms, forwards, discfactors, strikes, codes)
+        offs, total = ch["offs"], ch["total"]
         per_launch = min(n_sets, 8)
         need = (m * per_launch, max(total * per_launch, 1))
         if self.is_frozen:
@@ -867,44 +919,33 @@ class DeviceRandoms:
             sess = C.c_void_p()
             _lib.check(lib.svmc_session_create(C.byref(sess), self.n_local, need[0], need[1]))
             self._session_sets, self._session_sets_size = sess, need
+            self._graphs_on = None
             if comm_handle is not None:
                 _lib.check(lib.svmc_session_set_comm(sess, comm_handle, int(rank), int(world), self.nb_path, self.col0))
         dp = C.POINTER(C.c_double)
-        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)      # noqa: E731
-        ttms, forwards, discfactors = f64(ttms), f64(forwards), f64(discfactors)
-        k_all = f64(np.concatenate(strikes)) if total else np.zeros(1)
-        c_all = np.ascontiguousarray(np.concatenate(codes), dtype=np.int8) if total else np.zeros(1, dtype=np.int8)
-        w0 = (C.c_void_p * m)(*[b.ptr for b in self.w0])
-        w1 = (C.c_void_p * m)(*[b.ptr for b in self.w1])
-        nbs = (C.c_int * m)(*self.nb_steps)
-        dts = f64(self.dts)
-        shape = (n_sets, max(total, 1))
-        prices, stderrs = np.empty(shape), np.empty(shape)
-        ivols = np.empty(shape) if want_ivols else None
-        split = lambda a, q: [a[q, offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
+        # one result block per call, cut into per-set, per-expiry VIEWS (nothing else refers to the block)
+        res = np.empty((3 if want_ivols else 2, n_sets, max(total, 1)))
+        p_res = res.ctypes.data
+        row_bytes = res.strides[0]
+        ptr = lambda j: C.cast(p_res + j * row_bytes, dp)      # noqa: E731
+        slices = ch["slices"]
         if self.is_frozen:
-            _lib.check(lib.svmc_session_use_graphs(self._session_sets, int(bool(use_graph))))
+            if self.__dict__.get("_graphs_on") != bool(use_graph):
+                _lib.check(lib.svmc_session_use_graphs(self._session_sets, int(bool(use_graph))))
+                self._graphs_on = bool(use_graph)
             seed, call_id = self.frozen_stream
             _lib.check(lib.svmc_logsv_chain_price_frozen_sets(
-                self._session_sets, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp), m,
-                k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
-                n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), nbs,
-                dts.ctypes.data_as(dp), seed, call_id, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp),
-                ivols.ctypes.data_as(dp) if want_ivols else None))
-            return [(split(prices, q), split(stderrs, q), split(ivols, q)) if want_ivols else (split(prices, q), split(stderrs, q))
-                    for q in range(n_sets)]
-        _lib.check(lib.svmc_logsv_chain_price_fixed_sets(
-            self._session_sets, ttms.ctypes.data_as(dp), forwards.ctypes.data_as(dp), discfactors.ctypes.data_as(dp), m,
-            k_all.ctypes.data_as(dp), c_all.ctypes.data_as(C.POINTER(C.c_int8)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
-            n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), w0, w1, nbs,
-            dts.ctypes.data_as(dp), self.n_local, prices.ctypes.data_as(dp), stderrs.ctypes.data_as(dp),
-            ivols.ctypes.data_as(dp) if want_ivols else None))
-        split = lambda a, q: [a[q, offs[i]:offs[i + 1]].copy() for i in range(m)]      # noqa: E731
-        out = []
-        for q in range(n_sets):
-            out.append((split(prices, q), split(stderrs, q), split(ivols, q)) if want_ivols
-                       else (split(prices, q), split(stderrs, q)))
-        return out
+                self._session_sets, ch["ttms"], ch["forwards"], ch["discfactors"], m, ch["strikes"], ch["codes"], ch["offsets"],
+                n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), ch["nbs"], ch["dts"],
+                seed, call_id, ptr(0), ptr(1), ptr(2) if want_ivols else None))
+        else:
+            w0 = (C.c_void_p * m)(*[b.ptr for b in self.w0])
+            w1 = (C.c_void_p * m)(*[b.ptr for b in self.w1])
+            _lib.check(lib.svmc_logsv_chain_price_fixed_sets(
+                self._session_sets, ch["ttms"], ch["forwards"], ch["discfactors"], m, ch["strikes"], ch["codes"], ch["offsets"],
+                n_sets, params_rows.ctypes.data_as(dp), int(bool(is_spot_measure)), int(variable_type), w0, w1, ch["nbs"],
+                ch["dts"], self.n_local, ptr(0), ptr(1), ptr(2) if want_ivols else None))
+        return [tuple([part[q, sl] for sl in slices] for part in res) for q in range(n_sets)]
 
 
 def payoff_finalize(sums: np.ndarray, shifts: np.ndarray, discfactor: float, n_path_total: float

@@ -673,7 +673,7 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
                                          [c.ravel() for c in codes], v0, theta, kappa1, kappa2, beta, volvol,
                                          vol_backbone_etas, is_spot_measure, variable_type_code(variable_type),
                                          want_ivols=return_ivols)
-        return tuple([a.reshape(np.shape(k)) for a, k in zip(part, strikes_ttms)] for part in out)
+        return tuple([_shaped_like(a, k) for a, k in zip(part, strikes_ttms)] for part in out)
     if resident and resident.is_frozen:
         # frozen randoms, sharded over ranks (or the fused driver switched off): the on-device-RNG chain on the stream the
         # object names -- the same numbers the fused route gives on one GPU
@@ -708,6 +708,12 @@ def logsv_mc_chain_pricer_fixed_randoms(ttms: np.ndarray, forwards: np.ndarray, 
     return prices, stderrs, _host_ivols(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors)
 
 
+def _shaped_like(a: np.ndarray, k) -> np.ndarray:
+    """a result row in the shape of the strikes it belongs to (the reference returns arrays shaped like strikes_ttms[i])"""
+    shape = k.shape if isinstance(k, np.ndarray) else np.shape(k)
+    return a if a.shape == shape else a.reshape(shape)
+
+
 def _host_ivols(prices, ttms, forwards, strikes_ttms, optiontypes_ttms, discfactors) -> List[np.ndarray]:
     from ..data.option_chain import black_ivols_native           # the host twin of the graph's implied-vol kernel
     return [black_ivols_native(np.asarray(p, dtype=float).ravel(), float(t), float(f), np.asarray(k, dtype=float).ravel(),
@@ -733,14 +739,19 @@ def logsv_mc_chain_pricer_fixed_randoms_batch(params_list: Sequence[LogSvParams]
     codes = [option_type_codes(t) for t in optiontypes_ttms]
     if comm.world == 1 and FUSED_FIXED_RANDOMS_DRIVER and len(W0s) == len(ttms):
         strikes = [np.ascontiguousarray(np.asarray(k, dtype=np.float64)) for k in strikes_ttms]
-        rows = np.array([[p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol] + list(p.get_vol_backbone_etas(ttms=ttms))
-                         for p in params_list], dtype=np.float64)
+        rows = np.ones((len(params_list), 6 + len(ttms)))
+        for row, p in zip(rows, params_list):
+            row[:6] = (p.sigma0, p.theta, p.kappa1, p.kappa2, p.beta, p.volvol)
+            if p.vol_backbone is not None:
+                row[6:] = p.get_vol_backbone_etas(ttms=ttms)
         out = []
         for q0 in range(0, len(params_list), 8):                      # a launch takes up to 8 sets
             out += W0s.price_logsv_chain_sets(ttms, forwards, discfactors, [k.ravel() for k in strikes],
                                               [c.ravel() for c in codes], rows[q0:q0 + 8], is_spot_measure, vt,
                                               want_ivols=return_ivols)
-        return [tuple([a.reshape(np.shape(k)) for a, k in zip(part, strikes_ttms)] for part in res) for res in out]
+        if all(np.ndim(k) == 1 for k in strikes_ttms):
+            return out
+        return [tuple([_shaped_like(a, k) for a, k in zip(part, strikes_ttms)] for part in res) for res in out]
     return [logsv_mc_chain_pricer_fixed_randoms(ttms=ttms, forwards=forwards, discfactors=discfactors,
                                                 strikes_ttms=strikes_ttms, optiontypes_ttms=optiontypes_ttms, W0s=W0s,
                                                 W1s=None, dts=None, v0=p.sigma0, theta=p.theta, kappa1=p.kappa1,
