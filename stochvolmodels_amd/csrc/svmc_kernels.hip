@@ -684,6 +684,9 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
     clock_probe_stamp(probe, 0);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     const bool active = p < n;
+    // (spreading the sets over groups of blocks instead -- more waves of fewer states each -- was measured and is slower at
+    // every set count: two sets 0.221 -> 0.289 ms, four 0.302 -> 0.363, six 0.386 -> 0.439; an extra state in a lane costs
+    // 40 us, an extra wave of one state 107)
     double xv[P], sg[P], q[P];
 #pragma unroll
     for (int s = 0; s < P; ++s) {
@@ -734,14 +737,59 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
                 step(b0, b1);
                 ++c;
             }
-            // (drawing call c + 1's normals while call c's steps run -- the draw does not depend on the state -- was measured
-            // and is SLOWER, 100 -> 115 us at one set: the scheduler does not interleave the two, the registers cost)
-            for (const uint32_t c_end = (last + 1u) >> 1; c < c_end; ++c) {
+            // How the draw's table reads are scheduled against the steps decides a launch of one or two waves per SIMD, where no
+            // other wave hides an LDS round trip (10^5 paths x 364 steps, wall time of an evaluation, one / seven sets):
+            //   0  word by word, as the full-occupancy generators do -- the compiler reads, waits, evaluates four times over:
+            //      0.180 / 0.427 ms;
+            //   1  all eight reads of a call in flight, then the cubics (draw_issue / draw_finish): 0.172 / 0.419;
+            //   3  call c + 1's words, indices and READS issued before call c's two steps, its cubics after them -- the draw's
+            //      round trip hides behind the steps (it does not depend on the state); the last trip draws a call nobody
+            //      uses rather than branch inside the trip (with the branch, form 2, the trip is 8 us slower than form 0):
+            //      0.175 / 0.410.
+            // One set runs form 1, several run form 3 (SVMC_FROZEN_DRAW forces one form: tools/ubench A/B builds).
+#ifdef SVMC_FROZEN_DRAW
+            constexpr int DRAW = SVMC_FROZEN_DRAW;
+#else
+            constexpr int DRAW = (P == 1) ? 1 : 3;
+#endif
+            const uint32_t c_end = (last + 1u) >> 1;
+            if constexpr (DRAW == 0) {
+                for (; c < c_end; ++c) {
+                    philox_draw(lane, c, r);
+                    normals_from_words(r[0], r[1], tab, a0, a1);
+                    normals_from_words(r[2], r[3], tab, b0, b1);
+                    step(a0, a1);
+                    step(b0, b1);
+                }
+            } else if constexpr (DRAW == 1) {
+                for (; c < c_end; ++c) {
+                    DrawInFlight d;
+                    double z[4];
+                    philox_draw(lane, c, r);
+                    draw_issue(r, tab, d);
+                    draw_finish(d, z);
+                    step(z[0], z[1]);
+                    step(z[2], z[3]);
+                }
+            } else if (c < c_end) {
+                DrawInFlight d;
                 philox_draw(lane, c, r);
-                normals_from_words(r[0], r[1], tab, a0, a1);
-                normals_from_words(r[2], r[3], tab, b0, b1);
-                step(a0, a1);
-                step(b0, b1);
+                draw_issue(r, tab, d);
+                for (; c < c_end; ++c) {
+                    double z[4];
+                    draw_finish(d, z);
+                    if constexpr (DRAW == 2) {
+                        if (c + 1u < c_end) {
+                            philox_draw(lane, c + 1u, r);
+                            draw_issue(r, tab, d);
+                        }
+                    } else {
+                        philox_draw(lane, c + 1u, r);
+                        draw_issue(r, tab, d);
+                    }
+                    step(z[0], z[1]);
+                    step(z[2], z[3]);
+                }
             }
             if (!(last & 1u)) {
                 philox_draw(lane, last >> 1, r);

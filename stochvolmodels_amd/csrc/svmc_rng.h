@@ -247,6 +247,38 @@ __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, con
     w1 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(rb, t.icdf);
 }
 
+// The four normals of one Philox call in two halves, for launches of one or two waves per SIMD where an LDS round trip is not
+// hidden by other waves: draw_issue() converts the words and puts all eight table reads in flight (nothing is scheduled
+// across its end), draw_finish() runs the four cubics.  normal_icdf32's operations on the same operands: the same bits.
+struct DrawInFlight {
+    double t[4];
+    IcdfPiece e0[4], e1[4];
+};
+__device__ __forceinline__ void draw_issue(const uint32_t (&r)[4], const RngTables &tab, DrawInFlight &d)
+{
+    static_assert(SVMC_ICDF_RAW != 0, "the split draw is written for the raw form of the table");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d.t[k] = static_cast<double>(static_cast<int32_t>(r[k])) + 0.5;
+        const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
+        const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
+        d.e0[k] = *reinterpret_cast<const IcdfPiece *>(base);
+        d.e1[k] = *reinterpret_cast<const IcdfPiece *>(base + 16 * SVMC_ICDF_SEGMENTS);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void draw_finish(const DrawInFlight &d, double (&z)[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double a = fabs(d.t[k]);
+        double p = fma(d.e1[k].b, a, d.e1[k].a);
+        p = fma(p, a, d.e0[k].b);
+        p = fma(p, a, d.e0[k].a);
+        z[k] = copysign(p, d.t[k]);
+    }
+}
+
 // The time loop of every on-device-RNG generator: time steps [0, nb) of a lane whose first step has the chain-global
 // index step0.  One Philox call serves the two steps 2c, 2c + 1, so the loop runs over CALLS and each half is guarded by
 // a wave-uniform (scalar) test -- a slice that starts or ends on an odd step simply uses one half of its edge call,
