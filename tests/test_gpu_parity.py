@@ -1242,6 +1242,46 @@ def test_frozen_randoms_regenerated_in_registers(sv):
     hbm.free()
 
 
+@pytest.mark.parametrize("n", [777, 20011, 300_001])
+def test_payoff_sums_of_all_sets_in_one_launch(sv, n):
+    """the payoff pass of a multi-set evaluation is ONE launch (blockIdx.z = parameter set) and ONE column reduce where the
+    chain's strike groups fit a launch, the per-set loop where they do not: either way set q's prices and standard errors are
+    logsv_mc_chain_pricer's bits -- ragged chains, inverse options (their third accumulator, groups of 16), an expiry wider
+    than a group, nine expiries (more groups than a launch takes), path counts either side of the four-trips rule"""
+    rng = np.random.default_rng(n)
+    sets = [sv.LogSvParams(sigma0=0.8 + 0.03 * j, theta=1.0, kappa1=3.0 + 0.2 * j, kappa2=3.0, beta=0.15 - 0.05 * j, volvol=1.8 - 0.1 * j)
+            for j in range(5)]
+
+    def chain_of(counts, inverse):
+        m = len(counts)
+        ttms = np.linspace(0.05, 0.4, m)
+        fw = 1.0 + 0.01 * np.arange(m)
+        ks = tuple(np.sort(f * rng.uniform(0.6, 1.5, c)) for f, c in zip(fw, counts))
+        if inverse:
+            tys = tuple(np.where(k >= f, np.where(np.arange(k.size) % 2 == 0, "IC", "C"), np.where(np.arange(k.size) % 3 == 0, "IP", "P"))
+                        for k, f in zip(ks, fw))
+        else:
+            tys = tuple(np.where(k >= f, "C", "P") for k, f in zip(ks, fw))
+        return dict(ttms=ttms, forwards=fw, discfactors=np.exp(-0.03 * ttms), strikes_ttms=ks, optiontypes_ttms=tys)
+
+    cases = [("ragged", chain_of((5, 17, 1), False), sv.VariableType.LOG_RETURN),
+             ("inverse, an expiry of 30", chain_of((4, 30, 9), True), sv.VariableType.LOG_RETURN),
+             ("nine expiries", chain_of((3,) * 9, False), sv.VariableType.LOG_RETURN),
+             ("wide, realised variance", chain_of((23, 2), False), sv.VariableType.Q_VAR)]
+    for tag, chain, vt in cases:
+        if vt == sv.VariableType.Q_VAR:
+            chain = dict(chain, strikes_ttms=tuple(np.abs(k - 0.9) + 0.05 for k in chain["strikes_ttms"]))
+        res = sv.draw_fixed_randoms_on_device(chain["ttms"], nb_path=n, nb_steps_per_year=120, seed=5)
+        out = sv.logsv_mc_chain_pricer_fixed_randoms_batch(params_list=sets, W0s=res, variable_type=vt, **chain)
+        for p, got in zip(sets, out):
+            want = sv.logsv_mc_chain_pricer(v0=p.sigma0, theta=p.theta, kappa1=p.kappa1, kappa2=p.kappa2, beta=p.beta, volvol=p.volvol,
+                                            vol_backbone_etas=np.ones(len(chain["ttms"])), nb_path=n, nb_steps_per_year=120, seed=5,
+                                            variable_type=vt, **chain)
+            for a, b in zip(got[0] + got[1], want[0] + want[1]):
+                np.testing.assert_array_equal(a, b, err_msg=f"{tag}, {n} paths")
+        res.free()
+
+
 def test_implied_vols_from_the_graph(sv, oracle):
     """the price -> implied-vol step of the calibration objective done by the last kernel of the replayed graph
     (svmc_logsv_chain_price_fixed_iv): same numbers as the host routine on the returned prices (the same solver, device
