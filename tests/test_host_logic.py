@@ -510,3 +510,32 @@ def test_dlpack_capsule_keeps_and_releases_its_owner():
     m = next(v[0] for v in engine._DLPACK_ALIVE.values() if v[3].__class__ is FakeArray)
     m.deleter(C.pointer(m))                                          # what a consumer does when it is done with the tensor
     assert len(engine._DLPACK_ALIVE) == before
+
+
+def test_chain_marshalling_is_keyed_by_content():
+    """the objective of a calibration prices one chain hundreds of times: its arrays are marshalled for the C ABI once per
+    CONTENT (engine.DeviceRandoms._marshalled_chain) and the option-type codes are kept per array content
+    (engine.option_type_codes) -- a caller that changes an array in place gets a new entry, never stale pointers"""
+    from stochvolmodels_amd.engine import DeviceRandoms, option_type_codes
+    ty = np.array(["C", "P", "IC", "IP"])
+    c1, c2 = option_type_codes(ty), option_type_codes(ty.copy())
+    assert c1 is c2 and c1.tolist() == [0, 1, 2, 3] and not c1.flags.writeable
+    ty[1] = "C"
+    assert option_type_codes(ty).tolist() == [0, 0, 2, 3]
+    assert option_type_codes(np.array([["C", "P"], ["IP", "IC"]])).tolist() == [[0, 1], [3, 2]]
+    for _ in range(2):                                                   # a bad code raises every time, cached or not
+        with pytest.raises(ValueError):
+            option_type_codes(np.array(["C", "X"]))
+    assert option_type_codes(["P", "C"]).tolist() == [1, 0]              # plain sequences still work
+
+    res = DeviceRandoms.frozen([10, 20], [0.01, 0.01], nb_path=100, n_local=100, col0=0, seed=1)
+    ttms, fw, df = np.array([0.1, 0.3]), np.array([1.0, 1.01]), np.array([0.99, 0.98])
+    ks = [np.array([0.9, 1.0, 1.1]), np.array([0.8, 1.2])]
+    cs = [option_type_codes(np.array(["P", "C", "C"])), option_type_codes(np.array(["P", "C"]))]
+    a = res._marshalled_chain(ttms, fw, df, ks, cs)
+    assert res._marshalled_chain(ttms.copy(), fw, df, [k.copy() for k in ks], cs) is a
+    assert a["total"] == 5 and a["offs"].tolist() == [0, 3, 5] and a["slices"] == [slice(0, 3), slice(3, 5)]
+    assert a["keep"][3].tolist() == [0.9, 1.0, 1.1, 0.8, 1.2] and a["keep"][4].tolist() == [1, 0, 0, 1, 0]
+    ks[0][1] = 1.05                                                      # in place: another chain, the kept copy untouched
+    b = res._marshalled_chain(ttms, fw, df, ks, cs)
+    assert b is not a and b["keep"][3][1] == 1.05 and a["keep"][3][1] == 1.0
