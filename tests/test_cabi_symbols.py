@@ -67,9 +67,9 @@ def test_no_cpu_fallback():
                                   strikes_ttm=np.array([1.0]), optiontypes_ttm=np.array(["C"]))
 
 
-@pytest.mark.parametrize("name", ["price_chain", "price_chain_rccl", "price_chain_multi"])
+@pytest.mark.parametrize("name", ["price_chain", "price_chain_rccl", "price_chain_multi", "calibration_objective"])
 def test_c_example_compiles_and_links(tmp_path, name):
-    """the examples are plain-C hosts of the library -- one GPU, a process per GPU over RCCL, several GPUs from one process: each
+    """the examples are plain-C hosts of the library -- one GPU, a process per GPU over RCCL, several GPUs from one process, a calibration's objective: each
     must compile with gcc -Wall -Werror against include/svmc.h and link against libsvmc.so (they are RUN by the gpu suite)"""
     from stochvolmodels_amd import build
     lib = build.build()

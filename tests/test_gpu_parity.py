@@ -1458,6 +1458,44 @@ def test_config_c4_btc_style_chain(sv, oracle):
     assert np.all(s > 0) and np.all(q >= 0)
 
 
+def test_c_host_calibration_objective(sv, tmp_path):
+    """examples/calibration_objective.c: the objective and the gradient evaluation of an MC calibration from plain C on FROZEN
+    randoms (svmc_logsv_chain_price_frozen_sets, nothing resident) -- per set the Python host's logsv_mc_chain_pricer(seed) bit
+    for bit, the implied vols those of the host inversion; the program itself checks its base point against the chain driver"""
+    import json
+    import os
+    import subprocess
+    from stochvolmodels_amd.data.option_chain import black_ivols_native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "calibration_objective")
+    libdir = os.path.join(root, "stochvolmodels_amd")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "calibration_objective.c"),
+                    "-o", exe, "-L" + libdir, "-lsvmc", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"], check=True)
+    n = 30011
+    run = subprocess.run([exe, str(n), "77", "20"], check=True, capture_output=True, text=True)
+    out = json.loads(run.stdout.replace("NaN", "null"))
+    assert out["base_equals_chain_driver"] is True and out["steps"] == 364 and out["one_set_ms"] > 0 and out["seven_sets_ms"] > 0
+    ttms = np.array([1 / 12, 0.25, 0.5, 1.0])
+    k = 0.7 + 0.05 * np.arange(13)
+    ty = np.where(np.arange(13) >= 6, "C", "P")
+    chain = dict(ttms=ttms, forwards=np.ones(4), discfactors=np.ones(4), strikes_ttms=(k,) * 4, optiontypes_ttms=(ty,) * 4)
+    base = np.array([0.8376, 1.0413, 3.1844, 3.058, 0.1514, 1.8458])
+    prices = np.array(out["prices"], dtype=float).reshape(7, 4, 13)
+    stderrs = np.array(out["stderrs"], dtype=float).reshape(7, 4, 13)
+    ivols = np.array([np.nan if v is None else v for v in out["ivols"]], dtype=float).reshape(7, 4, 13)
+    for q in (0, 1, 4, 6):
+        p = base.copy()
+        if q:
+            p[q - 1] *= 1.0 + 1e-4
+        pr, sd = sv.logsv_mc_chain_pricer(v0=p[0], theta=p[1], kappa1=p[2], kappa2=p[3], beta=p[4], volvol=p[5],
+                                          vol_backbone_etas=np.ones(4), nb_path=n, nb_steps_per_year=360, seed=77, **chain)
+        np.testing.assert_array_equal(np.array(pr), prices[q])
+        np.testing.assert_array_equal(np.array(sd), stderrs[q])
+        for i in range(4):
+            np.testing.assert_allclose(ivols[q, i], black_ivols_native(prices[q, i], float(ttms[i]), 1.0, k, ty, 1.0), rtol=1e-9,
+                                       equal_nan=True)
+
+
 def test_c_host_example(sv, tmp_path):
     """the drop-in boundary is a C ABI: examples/price_chain.c (plain C, gcc, no Python, no torch) prices a chain through
     the fused drivers svmc_logsv_chain_price / svmc_heston_chain_price; the Python host with the same seed must give
