@@ -306,6 +306,61 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     slice_epilogue(so, p, active, xv, q);
 }
 
+// logsv_rng_kernel for a launch of a few waves per SIMD (n_path <= few_waves_max_paths(): the reference's default 10^5 paths
+// are 1.5 waves per SIMD).  Statement for statement the kernel above -- the same bits -- but compiled for latency instead
+// of residency: 256-thread blocks (every CU gets work), the register budget of two waves per SIMD, and the draw's table
+// reads of a call in flight together (rng_time_loop_few_waves).
+constexpr int FEW_BLOCK = 256;
+__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void logsv_rng_few_kernel(
+    double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, int nb_steps, LogsvFast c,
+    uint64_t seed, uint32_t c3, uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init, uint64_t *probe)
+{
+    __shared__ RngTablesLds s_tab;
+    __shared__ double s_exp[256];
+    const RngTables tab = stage_tables(s_tab, s_exp);
+    clock_probe_stamp(probe, 0);
+    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };
+    const size_t p = static_cast<size_t>(blockIdx.x) * FEW_BLOCK + threadIdx.x;
+    const bool active = p < n;
+    double xv = 0.0, s = 1.0, q = 0.0;
+    if (active) {
+        if (init.uniform) {
+            xv = init.x0;
+            s = init.vol0;
+            q = init.qvar0;
+        } else {
+            xv = x[p];
+            s = sigma[p];
+            q = qvar[p];
+        }
+        double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
+        double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
+        const double s2_start = s2;
+        const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
+        rng_time_loop_few_waves(lane, step_offset, nb_steps, tab,
+                                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); });
+        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
+    }
+    clock_probe_stamp(probe, 1);
+    slice_epilogue(so, p, active, xv, q);
+}
+
+// path counts up to this run the few-waves kernels: two waves per SIMD.  Measured (tools/r05/few_waves_sweep.py, wall time of
+// logsv_mc_chain_pricer for a 4 x 13 chain x 364 steps, few / full kernels): 2^14-2^16 paths 0.135 / 0.208 ms, 10^5-2^17
+// 0.163 / 0.210, 2 x 10^5 0.263 / 0.217 -- from three waves per SIMD on the full-launch kernels win.
+// SVMC_FEW_WAVES_MAX_PATHS overrides (0: never).
+static size_t few_waves_max_paths()
+{
+    static const size_t v = [] {
+        const char *e = getenv("SVMC_FEW_WAVES_MAX_PATHS");
+        return e ? static_cast<size_t>(strtoull(e, nullptr, 10)) : static_cast<size_t>(2) * 64 * 1024;
+    }();
+    return v;
+}
+
 // All expiries of a chain in ONE stepping launch: the slice loop runs inside the kernel, each slice with its own
 // constants (dt, vol backbone) and its own epilogue (snapshot row i, spot partials column pair i).  Eight 128-step
 // launches each pay their own ramp-up and ramp-down (C4: 8 x 1.03 ms against 7.44 ms for one 1024-step launch);
@@ -408,6 +463,53 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
         x[p] = s_park[threadIdx.x];
         sigma[p] = s;
         qvar[p] = s_park[CHAIN_BLOCK + threadIdx.x];
+    }
+    clock_probe_stamp(probe, 1);
+}
+
+// logsv_chain_rng_kernel for a launch of a few waves per SIMD (see logsv_rng_few_kernel): the same statements, the same bits
+__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void logsv_chain_rng_few_kernel(
+    double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
+    uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
+    double *__restrict__ partials, StateInit init, uint64_t *probe)
+{
+    __shared__ RngTablesLds s_tab;
+    __shared__ double s_exp[256];
+    const RngTables tab = stage_tables(s_tab, s_exp);
+    clock_probe_stamp(probe, 0);
+    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };
+    const size_t p = static_cast<size_t>(blockIdx.x) * FEW_BLOCK + threadIdx.x;
+    const bool active = p < n;
+    double xv = 0.0, s = 1.0, q = 0.0;                     // (two waves per SIMD: x and qvar stay in registers)
+    if (init.uniform) {
+        xv = init.x0;
+        s = init.vol0;
+        q = init.qvar0;
+    } else if (active) {
+        xv = x[p];
+        s = sigma[p];
+        q = qvar[p];
+    }
+    const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
+    int tg = 0;
+    for (int i = 0; i < cs.m; ++i) {
+        const int nb = cs.nb_steps[i];
+        const LogsvFast c = cs.c[i];
+        double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
+        double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
+        const double s2_start = s2;
+        rng_time_loop_few_waves(lane, step_offset + static_cast<uint32_t>(tg), nb, tab,
+                                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); });
+        logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
+        tg += nb;
+        const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
+                             partials + 2 * static_cast<size_t>(i) * ((n + 63) >> 6), cs.forward[i], (n + 63) >> 6};
+        slice_epilogue(so, p, active, xv, q);
+    }
+    if (active) {
+        x[p] = xv;
+        sigma[p] = s;
+        qvar[p] = q;
     }
     clock_probe_stamp(probe, 1);
 }
@@ -1640,8 +1742,13 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (n_path == 0) return SVMC_OK;
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
-    hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
-                       n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, armed_probe());
+    if (n_path <= few_waves_max_paths())
+        hipLaunchKernelGGL(logsv_rng_few_kernel, dim3(static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK)), dim3(FEW_BLOCK), 0,
+                           as_stream(stream), x, sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset,
+                           so, init, armed_probe());
+    else
+        hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
+                           n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, armed_probe());
     return check_launch(fn);
 }
 
@@ -1749,9 +1856,14 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
         }
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
-        hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
-                           cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
-                           (i0 == 0) ? init : StateInit(), armed_probe());
+        if (n_path <= few_waves_max_paths())
+            hipLaunchKernelGGL(logsv_chain_rng_few_kernel, dim3(static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK)),
+                               dim3(FEW_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path, cs, seed, make_c3(call_id), path_offset,
+                               step_offset, xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit(), armed_probe());
+        else
+            hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
+                               cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
+                               (i0 == 0) ? init : StateInit(), armed_probe());
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;

@@ -320,6 +320,28 @@ __device__ __forceinline__ void rng_time_loop(const PhiloxLane &lane, uint32_t s
     rng_time_loop(lane, step0, nb, tab, step, [](int) {});
 }
 
+// rng_time_loop for launches of a few waves per SIMD (a calibration- or default-sized path set: 10^5 paths are 1.5 waves per
+// SIMD on this chip), where no other wave hides an LDS round trip: all eight table reads of a call are in flight before the
+// first cubic (draw_issue / draw_finish) instead of four read-wait-evaluate rounds.  The same words for the same (path,
+// step), the same operations on them: the same bits.  Costs 24 more live registers, which a full launch does not have.
+template <class Step>
+__device__ __forceinline__ void rng_time_loop_few_waves(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                                        Step &&step)
+{
+    if (nb <= 0) return;
+    const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
+    for (uint32_t c = first >> 1; c <= (last >> 1); ++c) {
+        uint32_t r[4];
+        philox_draw(lane, c, r);
+        DrawInFlight d;
+        double z[4];
+        draw_issue(r, tab, d);
+        draw_finish(d, z);
+        if (2u * c >= first) step(z[0], z[1]);
+        if (2u * c + 1u <= last) step(z[2], z[3]);
+    }
+}
+
 // stream 0 for a single (path, step), from scratch: the step's two UNSCALED N(0,1)  (svmc_fill_normals)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
                                              const RngTables &t, double &w0, double &w1)

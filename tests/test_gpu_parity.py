@@ -1458,6 +1458,40 @@ def test_config_c4_btc_style_chain(sv, oracle):
     assert np.all(s > 0) and np.all(q >= 0)
 
 
+@pytest.mark.parametrize("n", [131072, 131073])
+def test_few_waves_kernels_either_side_of_their_path_count(sv, oracle, n):
+    """up to two waves per SIMD (131072 paths) the on-device-RNG LogSV generators run as logsv_rng_few_kernel /
+    logsv_chain_rng_few_kernel (256-thread blocks, the draw's table reads of a call in flight together), above as the
+    full-launch kernels: the same statements -- path by path the CPU twin's numbers on the same stream either side of the
+    switch, for a chain (both kernels' slice loops, odd slice boundaries) and for one expiry, prices, standard errors and the
+    state the launch leaves behind"""
+    from stochvolmodels_amd.engine import get_engine
+    P_ = sv.LOGSV_BTC_PARAMS
+    seed, spy = 31, 60
+    k = np.array([0.8, 1.0, 1.25])
+    ty = np.array(["P", "C", "IC"])
+    for ttms in (np.array([0.12, 0.3, 0.55]), np.array([0.3])):
+        m = len(ttms)
+        fw, df = 1.0 + 0.02 * np.arange(m), np.exp(-0.04 * ttms)
+        pr, sd = sv.logsv_mc_chain_pricer(ttms=ttms, forwards=fw, discfactors=df, strikes_ttms=(k,) * m, optiontypes_ttms=(ty,) * m,
+                                          v0=P_.sigma0, theta=P_.theta, kappa1=P_.kappa1, kappa2=P_.kappa2, beta=P_.beta,
+                                          volvol=P_.volvol, vol_backbone_etas=np.ones(m), nb_path=n, nb_steps_per_year=spy, seed=seed)
+        x, s, q = np.zeros(n), P_.sigma0 * np.ones(n), np.zeros(n)
+        t0, step0 = 0.0, 0
+        for i, ttm in enumerate(ttms):
+            nb, dt, _ = sv.set_time_grid(ttm - t0, spy)
+            x, s, q = oracle.logsv_terminal_rng(x, s, q, nb, dt, P_.theta, P_.kappa1, P_.kappa2, P_.beta, P_.volvol, seed,
+                                                step_offset=step0)
+            step0, t0 = step0 + nb, ttm
+            opr, osd = oracle.payoff(x, q, float(ttm), float(fw[i]), k, ty, float(df[i]))
+            np.testing.assert_allclose(pr[i], opr, rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(sd[i], osd, rtol=1e-11, atol=1e-13)
+        gx, gs, gq = get_engine(n).get_state()
+        np.testing.assert_allclose(gx, x, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gs, s, rtol=1e-10)
+        np.testing.assert_allclose(gq, q, rtol=1e-10)
+
+
 def test_c_host_calibration_objective(sv, tmp_path):
     """examples/calibration_objective.c: the objective and the gradient evaluation of an MC calibration from plain C on FROZEN
     randoms (svmc_logsv_chain_price_frozen_sets, nothing resident) -- per set the Python host's logsv_mc_chain_pricer(seed) bit

@@ -19,6 +19,7 @@ cp $O/frozen.jsonl profiles/${R}_frozen_objective.jsonl
 { echo "# rocprofv3 --kernel-trace --stats of python tools/r05/bench_frozen.py 100000 100 (4 x 13 chain, 10^5 paths x 364 steps): the frozen route's kernels (logsv_chain_rng_sets_kernel<P>) and the round-4 route's (logsv_chain_w_*: 582 MB of resident randoms streamed per evaluation) side by side"; python tools/rocpd_summary.py $(find $O/frozen_prof -name '*.db') | cut -c1-160; } > profiles/${R}_calibration_objective.txt
 cp $O/frozen_breakdown.jsonl profiles/${R}_frozen_breakdown.jsonl
 cp $O/frozen_scaling.jsonl profiles/${R}_frozen_scaling.jsonl
+cp $O/few_waves_sweep.json profiles/${R}_few_waves_sweep.json
 cp $O/bulk_outputs.jsonl profiles/${R}_bulk_outputs.jsonl
 cp $O/moments_timing.jsonl profiles/${R}_moments_timing.jsonl
 cp $O/vol_paths.json profiles/${R}_vol_paths.json

@@ -23,6 +23,7 @@ timeout 600 python tools/r05/bench_frozen.py 100000 300 > $O/frozen.jsonl 2> $O/
 find $O/frozen_prof -type f ! -name '*.db' -delete 2>/dev/null
 timeout 300 python tools/r05/frozen_breakdown.py 100000 300 2>/dev/null | grep '^{' > $O/frozen_breakdown.jsonl; cat $O/frozen_breakdown.jsonl
 timeout 300 python tools/r05/frozen_scaling.py 100 2>/dev/null | grep '^{' > $O/frozen_scaling.jsonl; cat $O/frozen_scaling.jsonl
+timeout 600 python tools/r05/few_waves_sweep.py 100 2>/dev/null | grep '^{' > $O/few_waves_sweep.json; cat $O/few_waves_sweep.json | cut -c1-400
 timeout 600 python tools/r05/bulk_outputs.py > $O/bulk_outputs.jsonl 2> $O/bulk.err; cat $O/bulk_outputs.jsonl | cut -c1-300
 timeout 300 python tools/r05/moments_timing.py 2>/dev/null | grep '^{' > $O/moments_timing.jsonl; cat $O/moments_timing.jsonl
 timeout 600 python tools/ubench/ab_vol_paths.py stochvolmodels_amd/libsvmc.so round5 2>$O/vol_paths.err | tail -1 > $O/vol_paths.json; cat $O/vol_paths.json | cut -c1-600
