@@ -1290,12 +1290,18 @@ __global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_expiries_
 #ifndef SVMC_HESTON_ATTR
 #define SVMC_HESTON_ATTR               // A/B hook (tools/ubench/build_variants.sh): e.g. __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-template <int SCHEME>
-__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
-                                                           double *__restrict__ qvar, size_t n, int nb_steps,
-                                                           HestonConsts c, QeConsts qc, uint64_t seed,
-                                                           uint32_t c3, uint64_t path_offset,
-                                                           uint32_t step_offset, SliceOut so, StateInit init)
+// FEW: the launch runs a few waves per SIMD (see logsv_rng_few_kernel): the draw's table reads of a call in flight together
+template <bool FEW, class Step>
+__device__ __forceinline__ void heston_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab, Step &&step)
+{
+    if constexpr (FEW) rng_time_loop_few_waves(lane, step0, nb, tab, step);
+    else rng_time_loop(lane, step0, nb, tab, step);
+}
+
+template <int SCHEME, bool FEW>
+__device__ __forceinline__ void heston_rng_body(double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n,
+                                                int nb_steps, HestonConsts c, QeConsts qc, uint64_t seed, uint32_t c3,
+                                                uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
@@ -1325,15 +1331,15 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
             double vsum = 0.0;
             const double v_first = v;
             const QeVec qv = make_qe_vec(qc);
-            rng_time_loop(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
+            heston_time_loop<FEW>(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
                 heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
                 ++step;
             });
             heston_qe_fold(qc, q, vsum, v_first, v);
         } else {
             v = heston_euler_guard_zero(v);
-            rng_time_loop(lane, step_offset, nb_steps, tab,
-                          [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
+            heston_time_loop<FEW>(lane, step_offset, nb_steps, tab,
+                                  [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
             heston_fold_acc(ef, xv, q, v, xacc, vacc);
         }
         x[p] = xv;
@@ -1341,6 +1347,26 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
         qvar[p] = q;
     }
     slice_epilogue(so, p, active, xv, q);
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                           double *__restrict__ qvar, size_t n, int nb_steps,
+                                                           HestonConsts c, QeConsts qc, uint64_t seed,
+                                                           uint32_t c3, uint64_t path_offset,
+                                                           uint32_t step_offset, SliceOut so, StateInit init)
+{
+    heston_rng_body<SCHEME, false>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
+}
+
+// the same generator for a launch of a few waves per SIMD (n_path <= few_waves_max_paths(); the reference's default is 10^5
+// paths): the statements -- and the bits -- of heston_rng_kernel, compiled for latency (see logsv_rng_few_kernel)
+template <int SCHEME>
+__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void heston_rng_few_kernel(
+    double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n, int nb_steps, HestonConsts c, QeConsts qc,
+    uint64_t seed, uint32_t c3, uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init)
+{
+    heston_rng_body<SCHEME, true>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
 }
 
 // whole-chain variant, as logsv_chain_rng_kernel: the slice loop inside the kernel, one launch tail per chain
@@ -1352,13 +1378,12 @@ struct HestonChainSlices {
     int m;
 };
 
-template <int SCHEME>
-__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
-                                                                 double *__restrict__ qvar, size_t n,
-                                                                 HestonChainSlices cs, uint64_t seed, uint32_t c3,
-                                                                 uint64_t path_offset, uint32_t step_offset,
-                                                                 double *__restrict__ x_snap, double *__restrict__ q_snap,
-                                                                 double *__restrict__ partials, StateInit init)
+template <int SCHEME, bool FEW>
+__device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar,
+                                                      size_t n, const HestonChainSlices &cs, uint64_t seed, uint32_t c3,
+                                                      uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap,
+                                                      double *__restrict__ q_snap, double *__restrict__ partials,
+                                                      const StateInit &init)
 {
     __shared__ RngTablesLds s_tab;
     __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
@@ -1395,15 +1420,15 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
                 const double v_first = v;
                 uint32_t st = step;
                 const QeVec qv = make_qe_vec(qc);
-                rng_time_loop(lane, step, nb, tab, [&](double w0, double w1) {
+                heston_time_loop<FEW>(lane, step, nb, tab, [&](double w0, double w1) {
                     heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
                     ++st;
                 });
                 heston_qe_fold(qc, q, vsum, v_first, v);
             } else {
                 v = heston_euler_guard_zero(v);
-                rng_time_loop(lane, step, nb, tab,
-                              [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
+                heston_time_loop<FEW>(lane, step, nb, tab,
+                                      [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
                 heston_fold_acc(ef, xv, q, v, xacc, vacc);
             }
         }
@@ -1417,6 +1442,26 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
         var[p] = v;
         qvar[p] = q;
     }
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_kernel(double *__restrict__ x, double *__restrict__ var,
+                                                                 double *__restrict__ qvar, size_t n,
+                                                                 HestonChainSlices cs, uint64_t seed, uint32_t c3,
+                                                                 uint64_t path_offset, uint32_t step_offset,
+                                                                 double *__restrict__ x_snap, double *__restrict__ q_snap,
+                                                                 double *__restrict__ partials, StateInit init)
+{
+    heston_chain_rng_body<SCHEME, false>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
+}
+
+template <int SCHEME>
+__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void heston_chain_rng_few_kernel(
+    double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n, HestonChainSlices cs, uint64_t seed,
+    uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
+    double *__restrict__ partials, StateInit init)
+{
+    heston_chain_rng_body<SCHEME, true>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
 }
 
 __global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x, double *__restrict__ var,
@@ -2248,13 +2293,19 @@ static int heston_rng_launch(const char *fn, double *x, double *var, double *qva
     if (n_path == 0) return SVMC_OK;
     const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
     const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
-    if (scheme == SVMC_HESTON_QE)
-        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream),
-                           x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
-    else
-        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(rng_grid(n_path)), dim3(rng_block()), 0,
-                           as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id),
-                           path_offset, step_offset, so, init);
+    const bool few = n_path <= few_waves_max_paths();
+    const dim3 grid(few ? static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK) : rng_grid(n_path)), block(few ? FEW_BLOCK : rng_block());
+#define SVMC_HESTON_LAUNCH(KERNEL)                                                                                              \
+    hipLaunchKernelGGL(KERNEL, grid, block, 0, as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), \
+                       path_offset, step_offset, so, init)
+    if (scheme == SVMC_HESTON_QE) {
+        if (few) SVMC_HESTON_LAUNCH(heston_rng_few_kernel<SVMC_HESTON_QE>);
+        else SVMC_HESTON_LAUNCH(heston_rng_kernel<SVMC_HESTON_QE>);
+    } else {
+        if (few) SVMC_HESTON_LAUNCH(heston_rng_few_kernel<SVMC_HESTON_EULER_FLOOR>);
+        else SVMC_HESTON_LAUNCH(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>);
+    }
+#undef SVMC_HESTON_LAUNCH
     return check_launch(fn);
 }
 
@@ -2342,14 +2393,19 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
         }
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
-        if (scheme == SVMC_HESTON_QE)
-            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_QE>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x,
-                               var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs,
-                               static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
-        else
-            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(g), dim3(rng_block()), 0,
-                               as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset,
-                               xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit());
+        const bool few = n_path <= few_waves_max_paths();
+        const dim3 grid(few ? static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK) : g), block(few ? FEW_BLOCK : rng_block());
+#define SVMC_HESTON_LAUNCH(KERNEL)                                                                                              \
+    hipLaunchKernelGGL(KERNEL, grid, block, 0, as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, \
+                       step_offset, xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit())
+        if (scheme == SVMC_HESTON_QE) {
+            if (few) SVMC_HESTON_LAUNCH(heston_chain_rng_few_kernel<SVMC_HESTON_QE>);
+            else SVMC_HESTON_LAUNCH(heston_chain_rng_kernel<SVMC_HESTON_QE>);
+        } else {
+            if (few) SVMC_HESTON_LAUNCH(heston_chain_rng_few_kernel<SVMC_HESTON_EULER_FLOOR>);
+            else SVMC_HESTON_LAUNCH(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>);
+        }
+#undef SVMC_HESTON_LAUNCH
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """
-The on-device-RNG LogSV pricers at default- and calibration-sized path counts: the few-waves kernels (logsv_rng_few_kernel,
-logsv_chain_rng_few_kernel) against the full-launch kernels (SVMC_FEW_WAVES_MAX_PATHS=0), wall time of the public pricer for a
-4 x 13 chain (364 steps) and a one-expiry chain (360 steps), and whether the prices are the same bits.  One JSON line.
+The on-device-RNG pricers at default- and calibration-sized path counts: the few-waves kernels (logsv_rng_few_kernel,
+logsv_chain_rng_few_kernel, heston_*_few_kernel) against the full-launch kernels (SVMC_FEW_WAVES_MAX_PATHS=0), wall time of the
+public pricer for a LogSV 4 x 13 chain (364 steps), a one-expiry chain (360 steps) and a Heston 4 x 13 chain (Euler, QE), and
+whether the prices are the same bits.  One JSON line.
 
     python tools/r05/few_waves_sweep.py [calls]
 """
@@ -41,6 +42,22 @@ def child(calls):
                 ts.append(time.perf_counter() - t0)
             row[str(n)] = [round(1e3 * float(np.median(ts)), 4), float(sum(float(np.sum(a)) for a in got[0] + got[1])).hex()]
         out[tag] = row
+    h0 = dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)
+    ttms = np.array([0.25, 0.5, 0.75, 1.0])
+    chain = dict(ttms=ttms, forwards=np.ones(4), discfactors=np.ones(4), strikes_ttms=(k,) * 4, optiontypes_ttms=(ty,) * 4)
+    for scheme in ("euler", "qe"):
+        row = {}
+        for n in SIZES:
+            fn = lambda: sv.heston_mc_chain_pricer(nb_path=n, scheme=scheme, nb_steps_per_year=360, seed=10, **chain, **h0)  # noqa: E731
+            got = fn()
+            fn()
+            ts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            row[str(n)] = [round(1e3 * float(np.median(ts)), 4), float(sum(float(np.sum(a)) for a in got[0] + got[1])).hex()]
+        out["heston_" + scheme] = row
     print(json.dumps(out), flush=True)
 
 
@@ -61,7 +78,7 @@ def main():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         res[tag] = json.loads(line[-1]) if line else {"error": r.stderr[-400:]}
     out = {"calls": calls}
-    for case in ("chain4", "one"):
+    for case in ("chain4", "one", "heston_euler", "heston_qe"):
         a, b = res["few_waves"].get(case, {}), res["full_launch_kernels"].get(case, {})
         out[case] = {n: {"few_ms": a[n][0], "full_ms": b[n][0], "same_bits": a[n][1] == b[n][1]} for n in a if n in b}
     print(json.dumps(out))
