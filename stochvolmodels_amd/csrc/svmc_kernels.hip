@@ -1328,14 +1328,14 @@ __device__ __forceinline__ void heston_rng_body(double *__restrict__ x, double *
             const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);
             QeUniforms uc;
             uint32_t step = step_offset;
-            double vsum = 0.0;
+            double vsum = 0.0, ksum = 0.0;
             const double v_first = v;
             const QeVec qv = make_qe_vec(qc);
             heston_time_loop<FEW>(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
-                heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
+                heston_qe_step(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
                 ++step;
             });
-            heston_qe_fold(qc, q, vsum, v_first, v);
+            heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
         } else {
             v = heston_euler_guard_zero(v);
             heston_time_loop<FEW>(lane, step_offset, nb_steps, tab,
@@ -1416,15 +1416,15 @@ __device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, do
             const HestonEulerFast ef = make_heston_euler_fast(c);
             double xacc = 0.0, vacc = 0.0;
             if (SCHEME == SVMC_HESTON_QE) {
-                double vsum = 0.0;
+                double vsum = 0.0, ksum = 0.0;
                 const double v_first = v;
                 uint32_t st = step;
                 const QeVec qv = make_qe_vec(qc);
                 heston_time_loop<FEW>(lane, step, nb, tab, [&](double w0, double w1) {
-                    heston_qe_step(qc, qv, tab.log, xv, v, vsum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
+                    heston_qe_step(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
                     ++st;
                 });
-                heston_qe_fold(qc, q, vsum, v_first, v);
+                heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
             } else {
                 v = heston_euler_guard_zero(v);
                 heston_time_loop<FEW>(lane, step, nb, tab,
@@ -1491,14 +1491,14 @@ __global__ __launch_bounds__(BLOCK) void heston_qe_w_kernel(double *__restrict__
     const LogTabEntry *tab = stage_log_table(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
     if (p >= n) return;
-    double xv = x[p], v = var[p], q = qvar[p], vsum = 0.0;
+    double xv = x[p], v = var[p], q = qvar[p], vsum = 0.0, ksum = 0.0;
     const double v_first = v;
     const double *const w[3] = {Z0 + p, Z1 + p, U + p};
     const QeVec qv = make_qe_vec(qc);
     streamed_time_loop<3>(w, ldw, nb_steps, [&](const double(&z)[3]) {
-        heston_qe_step(qc, qv, tab, xv, v, vsum, z[0], z[1], [&]() { return z[2]; });
+        heston_qe_step(qc, qv, tab, xv, v, vsum, ksum, z[0], z[1], [&]() { return z[2]; });
     });
-    heston_qe_fold(qc, q, vsum, v_first, v);
+    heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
     x[p] = xv;
     var[p] = v;
     qvar[p] = q;

@@ -144,6 +144,17 @@ SVMC_HD double sqrt_pos_1g(double t)
     return fma(g, r, g);
 }
 
+// the same, handing out h = (rsq seed) / 2 ~ 1 / (2 sqrt(t)) as well: a low-accuracy reciprocal for residual corrections
+SVMC_HD double sqrt_pos_1g_h(double t, double &half_rsq)
+{
+    const double y = rsq_seed(t);
+    const double g = t * y;
+    const double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    half_rsq = h;
+    return fma(g, r, g);
+}
+
 // sqrt(t) for t >= 0 including exact zero (the rsq seed of 0 is +inf): Heston's variance before its first floor.
 SVMC_HD double sqrt_pos0(double t)
 {

@@ -304,17 +304,18 @@ __device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double
 // ---- Andersen QE-M (J. Comp. Fin. 11(3), 2008); CPU twin: oracle/svmc_oracle.c heston_qe_step -------
 struct QeConsts {
     double dt, theta, E, c1, c2, K1m, K2, K3, K4, A, twoA, K0_plain2, K13_2, m0;     // ..2: twice the constant
+    double c1h, c2h;                                                                 // c1 / 2, c2 / 2: s2 / 2 = v0 c1h + c2h
 };
 
 // The two constants that multiply the variance, held in VECTOR registers: an instruction takes one scalar-register operand
 // on this chip, so fma(v0, E, m0) and fma(v0, c1, c2) with all four in scalar registers each cost a v_mov on top
 struct QeVec {
-    double E, c1;
+    double E, c1h;
 };
 __device__ __forceinline__ QeVec make_qe_vec(const QeConsts &c)
 {
-    QeVec v = {c.E, c.c1};
-    asm volatile("" : "+v"(v.E), "+v"(v.c1));
+    QeVec v = {c.E, c.c1h};
+    asm volatile("" : "+v"(v.E), "+v"(v.c1h));
     return v;
 }
 
@@ -340,6 +341,8 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     c.K13_2 = 2.0 * K13;
     c.m0 = theta * (1.0 - E);                             // E[v1 | v0] = v0 E + theta (1 - E)
     c.K1m = K1 - K13;                                     // the martingale correction's -K13 v0 rides on the K1 v0 term
+    c.c1h = 0.5 * c.c1;
+    c.c2h = 0.5 * c.c2;
     return c;
 }
 
@@ -348,7 +351,10 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
 // switch); larger |e| take the table logarithm.  The choice is made PER LANE (a wave whose lanes all take one branch skips
 // the others): a path's rounding must not depend on which other paths share its wave -- results are bit-independent of how
 // a job is sharded and where a path sits in a launch.
-__device__ __forceinline__ double log_one_minus(double e, double one_minus_e, const LogTabEntry *tab)
+// inv_out = 1 / (1 - e), which the correction needs beside the logarithm: below 2^-10 the geometric series to e^5 (next:
+// e^6 <= 8.7e-19) -- five FMAs where the hardware reciprocal and its Newton step cost the issue slots of seven -- above,
+// rcp_1n
+__device__ __forceinline__ double log_one_minus(double e, const LogTabEntry *tab, double &inv_out)
 {
     const double ae = fabs(e);
     if (ae < 0x1.0p-10) {
@@ -357,8 +363,15 @@ __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, co
         p = fma_k(p, e, 0x1.5555555555555p-2);            // 1/3
         p = fma_k(p, e, 0x1.0000000000000p-1);            // 1/2
         p = fma_k(p, e, 1.0);
+        double q = e + 1.0;
+        q = fma_k(q, e, 1.0);
+        q = fma_k(q, e, 1.0);
+        q = fma_k(q, e, 1.0);
+        inv_out = fma_k(q, e, 1.0);
         return -e * p;
     }
+    const double one_minus_e = 1.0 - e;
+    inv_out = rcp_1n(one_minus_e);
     if (ae < 0x1.0p-6) {
         double p = 0x1.0000000000000p-3;                  // 1/8
         p = fma_k(p, e, 0x1.2492492492492p-3);            // 1/7
@@ -375,58 +388,63 @@ __device__ __forceinline__ double log_one_minus(double e, double one_minus_e, co
 
 // One QE-M step.  z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential
 // branch -- called by the whole wave as soon as one lane is there (the streamed kernel loads it; the on-device draw is a
-// lazily evaluated Philox call shared by four steps, svmc_rng.h qe_uniform).  The scheme's quotients are regrouped so that each branch takes ONE hardware reciprocal (two with a
-// martingale correction in the exponential branch) where the textbook form -- the CPU twin's -- takes three to five:
-//   quadratic (psi = s2/m^2 <= 3/2), with w = 2 m^2 - s2, Q = sqrt(2 m^2 w), N = w + Q = s2 b^2, T = 2 m^2 + Q = s2 (1 + b^2):
-//     a = m s2 / T,   v1 = a (b + z1)^2 = (m / T) (N + 2 sqrt(N s2) z1 + s2 z1^2),
-//     1 - 2 A a = dn / T with dn = T - 2 A m s2,   A b^2 a / (1 - 2 A a) = A m N / dn;   1/T and 1/dn from rcp(T dn)
+// lazily evaluated Philox call shared by four steps, svmc_rng.h qe_uniform).
+//   quadratic (psi = s2/m^2 <= 3/2).  With alpha = sqrt(m^2 - s2/2) (in [m/2, m]) the textbook quantities are
+//     b^2 = 2 alpha (alpha + m) / s2,   1 + b^2 = 2 m (alpha + m) / s2,   a = m / (1 + b^2) = m - alpha,   b^2 a = alpha,
+//     v1 = a (b + z1)^2 = (sqrt(alpha) + sqrt(m - alpha) z1)^2 = alpha + 2 sqrt(alpha (m - alpha)) z1 + (m - alpha) z1^2:
+//     two square roots and NO quotient for the new variance; the martingale correction
+//     2 K0* = ln(1 - e) - 2 A alpha / (1 - e),  e = 2 A a = 2 A (m - alpha),  takes 1 / (1 - e) -- a five-term series
+//     wherever the logarithm's is (|e| < 2^-10: every sane grid), the hardware reciprocal elsewhere.  (Round 4 formed
+//     N = s2 b^2, T = s2 (1 + b^2), sqrt(2 m^2 w), sqrt(N s2) and 1/(T dn): ten instructions and a reciprocal more per
+//     step.)  m - alpha cancels for small psi; a residual step on (m - alpha)(m + alpha) = s2/2 repairs it (below).
 //   exponential, with D = s2 + m^2:  p = (s2 - m^2)/D,  1 - p = 2 m^2/D,  beta = 2 m/D,  u <= p  <=>  u D <= s2 - m^2,
 //     v1 = ln(2 m^2 / (D (1 - u))) D / (2 m);   1/(D (1 - u)) and 1/m from rcp(D (1 - u) m);
 //     p + beta (1 - p)/(beta - A) = ((s2 - m^2) e + 4 m m^2) / (D e),  e = 2 m - A D;   1/(D e) is the second reciprocal.
-// Identical in exact arithmetic to the twin; reciprocals are seed + one Newton step (2^-48), square roots stop after the
-// Goldschmidt step (2^-47: the scheme matches two moments of the variance, not its bits), logs go through the LDS
-// table.  The quadratic variance is dt (sum of the new variances + (v_first - v_last)/2): the caller keeps `vsum` and
-// folds it in (heston_qe_fold); x carries the martingale correction with its -K13 v0 term folded into K1m.
+// Identical in exact arithmetic to the CPU twin (oracle/svmc_oracle.c, the textbook form); reciprocals are seed + one Newton
+// step (2^-48), square roots stop after the Goldschmidt step (2^-47: the scheme matches two moments of the variance, not its
+// bits), logs go through the LDS table.  x advances by sqrt(K3 v0 + K4 v1) z0 alone; the drift terms are SUMS over the
+// steps -- K1m sum v0 + K2 sum v1 + sum K0* -- and are folded in once (heston_qe_fold: `vsum` = sum v1, `ksum` = sum 2 K0*,
+// sum v0 = v_first + vsum - v_last), as is the quadratic variance dt (vsum + (v_first - v_last)/2).
 template <class DrawU>
 __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &cv, const LogTabEntry *tab, double &x,
-                                               double &var, double &vsum, double z0, double z1, DrawU &&draw_u)
+                                               double &var, double &vsum, double &ksum, double z0, double z1, DrawU &&draw_u)
 {
     const double v0 = var;
     const double m = fma(v0, cv.E, c.m0);
-    const double s2 = fma(v0, cv.c1, c.c2);
+    const double s2h = fma(v0, cv.c1h, c.c2h);            // s2 / 2
     const double m2 = m * m;
-    double v1, Kd;                                        // Kd = 2 K0, K0 without its -K13 v0 term (the half rides in x's FMA)
-    const bool quad = s2 <= 1.5 * m2;                     // psi <= psi_c, decided without the divide
+    const double w = m2 - s2h;                            // alpha^2
+    double v1, Kd;                                        // Kd = 2 K0, K0 without its -K13 v0 term (that rides in K1m)
+    const bool quad = w >= 0.25 * m2;                     // psi <= psi_c = 3/2 (s2 <= 3/2 m^2), decided without the divide
     // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
     // on-device draw is a Philox call that serves four steps: every lane must take part in it)
     double u = m;                                         // any defined value: only lanes past the test below read it
     if (!__all(quad)) u = draw_u();
     if (quad) {
-        const double tm2 = m2 + m2;
-        const double w = tm2 - s2;                        // >= m^2 / 2
-        const double Q = sqrt_pos_1g(tm2 * w);
-        const double N = w + Q, T = tm2 + Q;
-        const double g = sqrt_pos_1g(N * s2);
-        const double t = fma(z1, fma(s2, z1, g + g), N);  // (sqrt N + sqrt s2 z1)^2 up to rounding: clamped at 0 below
+        double h;                                         // ~ 1 / (2 alpha)
+        const double al = sqrt_pos_1g_h(w, h);            // alpha to 2^-47
+        // a = m - alpha cancels: alpha's 2^-47 would reach it multiplied by alpha / a = 4 / psi (3e-12 at C3's psi ~ 0.01).
+        // One residual step on a (m + alpha) = s2 / 2 with the crude 1 / (m + alpha) ~ h (off by psi / 8) takes the error
+        // back to eps wherever it mattered.  (volvol = 0: a is 0 up to rounding, of either sign -- |a| + 1e-300 below)
+        const double a0 = m - al;
+        const double a = fma(fma(-a0, m + al, s2h), h, a0);
+        const double ga = sqrt_pos_1g(fma(al, fabs(a), 1e-300));
+        const double t = fma(z1, fma(a, z1, ga + ga), al);        // (sqrt(alpha) + sqrt(a) z1)^2 up to rounding: clamped at 0
+        v1 = fmax(t, 0.0);
         if (c.A == 0.0) {                                 // wave-uniform: rho = 0 makes the martingale factor 1
-            v1 = fmax((m * rcp_1n(T)) * t, 0.0);
             Kd = 0.0;
         } else {
-            const double tam = c.twoA * m;
-            const double ams2 = tam * s2;
-            const double dn = T - ams2;                   // T (1 - 2 A a)
-            if (dn > 0.0) {
-                const double r = rcp_1n(T * dn);
-                const double invT = dn * r, invD = T * r;
-                v1 = fmax((m * invT) * t, 0.0);
-                const double ln_den = log_one_minus(ams2 * invT, dn * invT, tab);
-                Kd = fma(-(tam * N), invD, ln_den);       // 2 K0 = ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)
+            const double e = c.twoA * a;                  // 2 A a
+            if (e < 1.0) {
+                double inv;
+                const double ln_den = log_one_minus(e, tab, inv);
+                Kd = fma(-(c.twoA * al), inv, ln_den);    // ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)
             } else {
-                v1 = fmax((m * rcp_1n(T)) * t, 0.0);
                 Kd = fma(c.K13_2, v0, c.K0_plain2);       // the plain drift: cancels the folded -K13 v0
             }
         }
     } else {
+        const double s2 = s2h + s2h;
         const double D = s2 + m2, dm = s2 - m2;
         const bool zero = (u * D <= dm);                  // u <= p
         const double q1 = D * (1.0 - u);
@@ -448,15 +466,20 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
     }
     // + 1e-300: v0 = v1 = 0 (two exponential-branch zeros in a row) must not reach the rsq seed; sqrt(1e-300) z0 is nothing
     const double sq = sqrt_pos_1g(fma(c.K4, v1, fma(c.K3, v0, 1e-300)));
-    x = fma(sq, z0, fma(c.K2, v1, fma(c.K1m, v0, fma(0.5, Kd, x))));
+    x = fma(sq, z0, x);
+    ksum = ksum + Kd;
     vsum = vsum + v1;
     var = v1;
 }
 
 // qvar += dt * sum_t (v_{t-1} + v_t)/2 over the steps since vsum was zero (v_first = the variance they started from)
-__device__ __forceinline__ void heston_qe_fold(const QeConsts &c, double &qvar, double vsum, double v_first, double v_last)
+// and x += K1m sum v0 + K2 sum v1 + sum K0* (see heston_qe_step)
+__device__ __forceinline__ void heston_qe_fold(const QeConsts &c, double &x, double &qvar, double vsum, double ksum, double v_first,
+                                               double v_last)
 {
-    qvar = fma(c.dt, fma(0.5, v_first - v_last, vsum), qvar);
+    const double dv = v_first - v_last;
+    x = fma(c.K1m, vsum + dv, fma(c.K2, vsum, fma(0.5, ksum, x)));
+    qvar = fma(c.dt, fma(0.5, dv, vsum), qvar);
 }
 
 }  // namespace svmc
