@@ -305,6 +305,10 @@ __device__ __forceinline__ void heston_fold_acc(const HestonEulerFast &f, double
 struct QeConsts {
     double dt, theta, E, c1, c2, K1m, K2, K3, K4, A, twoA, K0_plain2, K13_2, m0;     // ..2: twice the constant
     double c1h, c2h;                                                                 // c1 / 2, c2 / 2: s2 / 2 = v0 c1h + c2h
+    // what the parameters alone decide (wave-uniform, scalar branches in the step):
+    int quad_only;        // psi = s2/m^2 is largest at v0 = 0, where it is volvol^2 / (2 kappa theta): at most 3/2 (less a margin) ->
+                          // no path ever takes the exponential branch and the step does not test for it
+    int e_below_one;      // A <= 0 (rho <= 0 on any sane grid): 1 - 2 A a >= 1, the martingale correction always exists
 };
 
 // The two constants that multiply the variance, held in VECTOR registers: an instruction takes one scalar-register operand
@@ -343,6 +347,9 @@ inline QeConsts make_qe_consts(double dt, double theta, double kappa, double rho
     c.K1m = K1 - K13;                                     // the martingale correction's -K13 v0 rides on the K1 v0 term
     c.c1h = 0.5 * c.c1;
     c.c2h = 0.5 * c.c2;
+    // d psi / d v0 = [c1 m0 - 2 E c2 - E c1 v0] / m^3 and c1 m0 = 2 E c2: psi falls from psi(0) = c2 / m0^2 = volvol^2 / (2 kappa theta)
+    c.quad_only = (kappa > 0.0 && theta > 0.0 && volvol * volvol <= 3.0 * kappa * theta * (1.0 - 1e-6)) ? 1 : 0;
+    c.e_below_one = (c.A <= 0.0) ? 1 : 0;
     return c;
 }
 
@@ -415,11 +422,14 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
     const double m2 = m * m;
     const double w = m2 - s2h;                            // alpha^2
     double v1, Kd;                                        // Kd = 2 K0, K0 without its -K13 v0 term (that rides in K1m)
-    const bool quad = w >= 0.25 * m2;                     // psi <= psi_c = 3/2 (s2 <= 3/2 m^2), decided without the divide
-    // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
-    // on-device draw is a Philox call that serves four steps: every lane must take part in it)
+    bool quad = true;
     double u = m;                                         // any defined value: only lanes past the test below read it
-    if (!__all(quad)) u = draw_u();
+    if (!c.quad_only) {                                   // (wave-uniform)
+        quad = w >= 0.25 * m2;                            // psi <= psi_c = 3/2 (s2 <= 3/2 m^2), decided without the divide
+        // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
+        // on-device draw is a Philox call that serves four steps: every lane must take part in it)
+        if (!__all(quad)) u = draw_u();
+    }
     if (quad) {
         double h;                                         // ~ 1 / (2 alpha)
         const double al = sqrt_pos_1g_h(w, h);            // alpha to 2^-47
@@ -435,7 +445,7 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
             Kd = 0.0;
         } else {
             const double e = c.twoA * a;                  // 2 A a
-            if (e < 1.0) {
+            if (c.e_below_one || e < 1.0) {
                 double inv;
                 const double ln_den = log_one_minus(e, tab, inv);
                 Kd = fma(-(c.twoA * al), inv, ln_den);    // ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)

@@ -428,6 +428,54 @@ def test_heston_qe(sv, oracle, golden):
         eng.close()
 
 
+@pytest.mark.parametrize("tag,par", [
+    ("exponential branch (volvol^2 = 17 x 3 kappa theta), rho < 0", dict(v0=0.02, theta=0.02, kappa=1.0, rho=-0.7, volvol=1.0)),
+    ("mixed branches, rho > 0 (A > 0: the correction's existence is tested per path)", dict(v0=0.09, theta=0.09, kappa=2.0, rho=0.6, volvol=0.9)),
+    ("quadratic only, rho > 0", dict(v0=0.09, theta=0.09, kappa=2.0, rho=0.6, volvol=0.5)),
+    ("quadratic only, rho = 0", dict(v0=0.5, theta=0.6, kappa=3.0, rho=0.0, volvol=1.2)),
+    # (smaller still and the scheme itself is ill-conditioned: K2 v1 ~ rho / volvol cancels against K0* to O(1), in the twin too)
+    ("almost no vol of vol (psi ~ 1e-7: m - alpha is all cancellation)", dict(v0=0.04, theta=0.05, kappa=2.0, rho=-0.3, volvol=1e-5)),
+])
+def test_heston_qe_branches_the_parameters_decide(sv, oracle, tag, par):
+    """the QE step skips what the parameters alone decide (svmc_models.h make_qe_consts: quad_only when volvol^2 <= 3 kappa theta,
+    e_below_one when A <= 0): every combination -- never / sometimes / mostly exponential, rho of either sign and zero, vanishing
+    vol of vol -- path by path against the CPU twin's textbook form on the same stream, one-slice kernel and chain kernel (few-waves
+    and full-launch forms), states and prices"""
+    seed = 17
+    for n in (8192, 140_000):
+        nb = 48
+        eng = _engine(n)
+        eng.fill_state(0.0, par["v0"], 0.0)
+        eng.heston_rng(nb, 0.5 / nb, par["theta"], par["kappa"], par["rho"], par["volvol"], 1, seed, 0, 0)
+        x, v, q = eng.get_state()
+        ox, ov, oq = oracle.heston_terminal_rng(np.zeros(n), par["v0"] * np.ones(n), np.zeros(n), nb, 0.5 / nb, par["theta"],
+                                                par["kappa"], par["rho"], par["volvol"], seed, scheme=oracle.HESTON_QE)
+        if "exponential" in tag or "mixed" in tag:
+            assert np.mean(ov == 0.0) > 0 or np.min(ov) < 1e-3 * par["theta"]        # the exponential branch does run here
+        np.testing.assert_allclose(x, ox, rtol=1e-9, atol=1e-10, err_msg=tag)
+        np.testing.assert_allclose(v, ov, rtol=1e-9, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(q, oq, rtol=1e-10, atol=1e-13, err_msg=tag)
+        assert np.array_equal(v == 0.0, ov == 0.0)                                    # the same paths sit at exactly zero
+        eng.close()
+    # the chain kernel through the pricer
+    ttms = np.array([0.2, 0.5])
+    k = np.array([0.85, 1.0, 1.15])
+    ty = np.array(["P", "C", "C"])
+    n = 20_000
+    pr, sd = sv.heston_mc_chain_pricer(ttms=ttms, forwards=np.ones(2), discfactors=np.ones(2), strikes_ttms=(k, k), optiontypes_ttms=(ty, ty),
+                                       nb_path=n, scheme="qe", nb_steps_per_year=100, seed=seed, **par)
+    x, v, q = np.zeros(n), par["v0"] * np.ones(n), np.zeros(n)
+    t0, step0 = 0.0, 0
+    for i, ttm in enumerate(ttms):
+        nb, dt, _ = sv.set_time_grid(ttm - t0, 100)
+        x, v, q = oracle.heston_terminal_rng(x, v, q, nb, dt, par["theta"], par["kappa"], par["rho"], par["volvol"], seed,
+                                             scheme=oracle.HESTON_QE, step_offset=step0)
+        step0, t0 = step0 + nb, ttm
+        opr, osd = oracle.payoff(x, q, float(ttm), 1.0, k, ty, 1.0)
+        np.testing.assert_allclose(pr[i], opr, rtol=1e-9, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(sd[i], osd, rtol=1e-9, atol=1e-12, err_msg=tag)
+
+
 def test_config_c1_heston_10k_100(sv, oracle):
     """BASELINE config 1: Heston Euler, 10k paths x 100 steps (ttm=1, spy=99), 5 quickstart strikes"""
     n, seed = 10_000, 20240601
