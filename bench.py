@@ -710,7 +710,7 @@ def secondary_block(sv, P) -> dict:
     wl = dict(ttms=np.array([1.0]), forwards=np.ones(1), discfactors=np.ones(1), strikes_ttms=(kk,), optiontypes_ttms=(types,))
     ms, _ = _median_ms(lambda: sv.logsv_mc_chain_pricer(v0=P.sigma0, theta=P.theta, kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta,
                                                         volvol=P.volvol, vol_backbone_etas=np.ones(1), nb_path=1 << 21,
-                                                        nb_steps_per_year=1023, seed=20240602, **wl), 5, 2)
+                                                        nb_steps_per_year=1023, seed=20240602, **wl), 15, 10)   # (warm: the block's small launches before it leave the clocks low)
     out["c2_at_2e21_paths"] = {"ms": _sig(ms), "psps": _sig((1 << 21) * 1024 / (ms * 1e-3))}
     for n in (1 << 22, 1 << 23, 1 << 21, 100_000, n_dev, 10_000):            # give the legs' HBM back
         try:
