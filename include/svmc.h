@@ -347,7 +347,19 @@ SVMC_API int svmc_payoff_finalize_chain(const double *sums_host, const double *s
  * (svmc_session_set_comm, below) and the same calls shard the job; the Python host mirror
  * (stochvolmodels_amd/mc_chain.py) places the same two all-reduces between the same kernels. */
 SVMC_API int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total);
+/* A session over state arrays and a stream the CALLER owns (device pointers x, vol, qvar of n_path doubles each; stream may be
+ * NULL, the null stream): the session allocates its snapshots / sums / workspace only, every chain it prices leaves the terminal
+ * state in the caller's arrays, and svmc_session_destroy frees neither them nor the stream.  path_offset = the global id of the
+ * arrays' first path (a lone shard of a bigger job; 0 otherwise).  This is how the Python host prices a chain on ONE GPU: its
+ * engine's resident state, one C-ABI call per chain instead of a dozen (logsv_mc_chain_pricer, pricers/logsv_pricer.py:806-867). */
+SVMC_API int svmc_session_create_on(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total,
+                                    double *x, double *vol, double *qvar, uint64_t path_offset, svmc_stream_t stream);
 SVMC_API int svmc_session_destroy(svmc_session_t session);
+/* Measurement: with timing enabled, svmc_logsv_chain_price / svmc_heston_chain_price bracket their stepping launch (and its
+ * spot-sum reduce) with HIP events on the session's stream; svmc_session_last_stepping_ms returns the elapsed time of the last
+ * such call (-1 if none was timed).  This is how bench.py times the dominant kernel inside its timed region without a profiler. */
+SVMC_API int svmc_session_time_stepping(svmc_session_t session, int enable);
+SVMC_API int svmc_session_last_stepping_ms(svmc_session_t session, float *ms);
 SVMC_API int svmc_session_state(svmc_session_t session, double *x_host, double *vol_host, double *qvar_host);
 SVMC_API int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, const double *forwards_host,
                                     const double *discfactors_host, const double *vol_backbone_etas_host,

@@ -106,7 +106,10 @@ def _declare(L: C.CDLL) -> None:
         "svmc_mgf_qvar_slice": ([vp, vp, sz, f64, pf64, sz, vp, vp], i32),
         "svmc_mgf_vanilla_slice": ([vp, vp, sz, f64, pf64, sz, vp, vp], i32),
         "svmc_session_create": ([pvp, sz, i32, sz], i32),
+        "svmc_session_create_on": ([pvp, sz, i32, sz, vp, vp, vp, u64, vp], i32),
         "svmc_session_destroy": ([vp], i32),
+        "svmc_session_time_stepping": ([vp, i32], i32),
+        "svmc_session_last_stepping_ms": ([vp, C.POINTER(C.c_float)], i32),
         "svmc_session_state": ([vp, vp, vp, vp], i32),
         "svmc_logsv_chain_price": ([vp, pf64, pf64, pf64, pf64, i32, pf64, pi8, psz, f64, f64, f64, f64, f64, f64, i32,
                                     i32, i32, u64, u32, pf64, pf64], i32),

@@ -59,7 +59,32 @@ struct Session {
     void *ws = nullptr;
     size_t ws_bytes = 0;
     hipStream_t stream = nullptr;
+    bool owns_state = true, owns_stream = true;   // false: svmc_session_create_on -- the caller's state arrays / stream
+    // svmc_session_time_stepping: HIP events around the stepping launch (+ its spot-sum reduce) of the on-device-RNG chain
+    // drivers, on the session's stream -- what a host that times the dominant kernel (bench.py) reads back after the call
+    bool time_stepping = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_stepping_ms = -1.0f;
 };
+
+// events around a stepping call of a timed session (no-ops otherwise)
+static void stepping_begin(Session *s)
+{
+    if (s->time_stepping && s->ev0 != nullptr) (void)hipEventRecord(s->ev0, s->stream);
+}
+static void stepping_end(Session *s)
+{
+    if (s->time_stepping && s->ev1 != nullptr) (void)hipEventRecord(s->ev1, s->stream);
+}
+// after the chain's synchronisation
+static void stepping_read(Session *s)
+{
+    s->last_stepping_ms = -1.0f;
+    if (s->time_stepping && s->ev0 != nullptr && s->ev1 != nullptr) {
+        float ms = -1.0f;
+        if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) s->last_stepping_ms = ms;
+    }
+}
 
 static void fixed_graph_release(FixedGraph &g)
 {
@@ -80,11 +105,15 @@ static void session_release(Session *s)
     fixed_graph_release(s->fixed);
     fixed_graph_release(s->fixed_sets);
     for (FixedGraph &g : s->frozen) fixed_graph_release(g);
-    for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar),
-                    static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
+    if (s->owns_state)
+        for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar)})
+            if (p != nullptr) (void)hipFree(p);
+    for (void *p : {static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
         if (p != nullptr) (void)hipFree(p);
     if (s->sums_pinned != nullptr) (void)hipHostFree(s->sums_pinned);
-    if (s->stream != nullptr) (void)hipStreamDestroy(s->stream);
+    if (s->ev0 != nullptr) (void)hipEventDestroy(s->ev0);
+    if (s->ev1 != nullptr) (void)hipEventDestroy(s->ev1);
+    if (s->owns_stream && s->stream != nullptr) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
@@ -225,6 +254,7 @@ static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type
     if (int rc = all_reduce(s, s->sums, 3 * c.offsets[c.m])) return rc;
     SVMC_HIP_TRY(hipMemcpyAsync(s->sums_pinned, s->sums, 3 * c.offsets[c.m] * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+    stepping_read(s);
     return finalize_prices(s, c, s->sums_pinned, shifts, prices, stderrs);
 }
 
@@ -241,14 +271,41 @@ using namespace svmc;
 
 extern "C" {
 
+static int session_create(const char *fn, svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total,
+                          double *x, double *vol, double *qvar, bool borrow_stream, hipStream_t stream_in);
+
 int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total)
 {
-    SVMC_REQUIRE(session != nullptr, "svmc_session_create: null output");
-    SVMC_REQUIRE(n_path > 0 && max_expiries > 0 && max_strikes_total > 0, "svmc_session_create: sizes must be positive");
+    return session_create("svmc_session_create", session, n_path, max_expiries, max_strikes_total, nullptr, nullptr, nullptr, false,
+                          nullptr);
+}
+
+int svmc_session_create_on(svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total, double *x,
+                           double *vol, double *qvar, uint64_t path_offset, svmc_stream_t stream)
+{
+    SVMC_REQUIRE(x != nullptr && vol != nullptr && qvar != nullptr, "svmc_session_create_on: null state array");
+    if (int rc = session_create("svmc_session_create_on", session, n_path, max_expiries, max_strikes_total, x, vol, qvar, true,
+                                as_stream(stream)))
+        return rc;
+    reinterpret_cast<Session *>(*session)->path_offset = path_offset;
+    return SVMC_OK;
+}
+
+static int session_create(const char *fn, svmc_session_t *session, size_t n_path, int max_expiries, size_t max_strikes_total,
+                          double *x, double *vol, double *qvar, bool borrow_stream, hipStream_t stream_in)
+{
+    SVMC_REQUIRE(session != nullptr, std::string(fn) + ": null output");
+    SVMC_REQUIRE(n_path > 0 && max_expiries > 0 && max_strikes_total > 0, std::string(fn) + ": sizes must be positive");
     Session *s = new Session;
     s->n_path = n_path;
     s->max_expiries = max_expiries;
     s->max_strikes = max_strikes_total;
+    s->owns_state = x == nullptr;
+    s->owns_stream = !borrow_stream;
+    s->x = x;
+    s->vol = vol;
+    s->qvar = qvar;
+    s->stream = stream_in;
     size_t ws = 0;
     int rc = svmc_slice_workspace_bytes(n_path, &ws);
     // the multi-set replay (svmc_logsv_chain_price_fixed_sets) writes two partial columns per (expiry, set): a session created
@@ -258,10 +315,10 @@ int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries
     s->ws_bytes = ws;
     const size_t nb = n_path * sizeof(double);
     hipError_t e = hipSuccess;
-    if (rc == SVMC_OK) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->x), nb);
-    if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->vol), nb);
-    if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->qvar), nb);
+    if (rc == SVMC_OK && s->owns_stream) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (rc == SVMC_OK && e == hipSuccess && s->owns_state) e = hipMalloc(reinterpret_cast<void **>(&s->x), nb);
+    if (rc == SVMC_OK && e == hipSuccess && s->owns_state) e = hipMalloc(reinterpret_cast<void **>(&s->vol), nb);
+    if (rc == SVMC_OK && e == hipSuccess && s->owns_state) e = hipMalloc(reinterpret_cast<void **>(&s->qvar), nb);
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->snap), 2 * static_cast<size_t>(max_expiries) * nb);
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->spot), 2 * static_cast<size_t>(max_expiries) * sizeof(double));
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->sums), 3 * max_strikes_total * sizeof(double));
@@ -270,7 +327,7 @@ int svmc_session_create(svmc_session_t *session, size_t n_path, int max_expiries
         e = hipHostMalloc(reinterpret_cast<void **>(&s->sums_pinned), 3 * max_strikes_total * sizeof(double), hipHostMallocDefault);
     if (rc != SVMC_OK || e != hipSuccess) {
         session_release(s);
-        return rc != SVMC_OK ? rc : fail(SVMC_ERR_HIP, std::string("svmc_session_create: ") + hipGetErrorString(e));
+        return rc != SVMC_OK ? rc : fail(SVMC_ERR_HIP, std::string(fn) + ": " + hipGetErrorString(e));
     }
     *session = reinterpret_cast<svmc_session_t>(s);
     return SVMC_OK;
@@ -319,6 +376,27 @@ int svmc_session_set_reducer(svmc_session_t session, svmc_all_reduce_fn fn, void
     return SVMC_OK;
 }
 
+int svmc_session_time_stepping(svmc_session_t session, int enable)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr, "svmc_session_time_stepping: null session");
+    if (enable && s->ev0 == nullptr) {
+        SVMC_HIP_TRY(hipEventCreate(&s->ev0));
+        SVMC_HIP_TRY(hipEventCreate(&s->ev1));
+    }
+    s->time_stepping = enable != 0;
+    s->last_stepping_ms = -1.0f;
+    return SVMC_OK;
+}
+
+int svmc_session_last_stepping_ms(svmc_session_t session, float *ms)
+{
+    Session *s = reinterpret_cast<Session *>(session);
+    SVMC_REQUIRE(s != nullptr && ms != nullptr, "svmc_session_last_stepping_ms: null argument");
+    *ms = s->last_stepping_ms;
+    return SVMC_OK;
+}
+
 int svmc_session_destroy(svmc_session_t session)
 {
     session_release(reinterpret_cast<Session *>(session));
@@ -346,6 +424,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
         time_grid(c.ttms[i] - t0, nb_steps_per_year, nbs[i], dts[i]);
         t0 = c.ttms[i];
     }
+    stepping_begin(s);
     if (c.m == 1) {       // a single expiry: the plain slice kernel (same bits, and the one bench.py profiles)
         if (int rc = svmc_logsv_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
                                           vol_backbone_etas_host ? vol_backbone_etas_host[0] : 1.0, is_spot_measure, seed,
@@ -353,6 +432,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
                                           (variable_type == SVMC_Q_VAR) ? s->snap + n : nullptr, s->spot, s->ws, s->ws_bytes,
                                           s->stream))
             return rc;
+        stepping_end(s);
         return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
     }
     if (int rc = svmc_logsv_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
@@ -360,6 +440,7 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
                                       s->path_offset, 0, s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
                                       s->spot, s->ws, s->ws_bytes, s->stream))
         return rc;
+    stepping_end(s);
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
 }
 
@@ -853,6 +934,7 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
         t0 = c.ttms[i];
     }
     double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
+    stepping_begin(s);
     if (c.m == 1) {
         if (int rc = svmc_heston_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
                                            call_id, s->path_offset, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
@@ -863,6 +945,7 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
                                               s->ws_bytes, s->stream)) {
         return rc;
     }
+    stepping_end(s);
     return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
 }
 

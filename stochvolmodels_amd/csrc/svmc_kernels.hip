@@ -7,8 +7,10 @@
 // transcendentals (DESIGN.md "Rooflines").
 #include "svmc_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 #include "svmc_black.h"
 #include "svmc_models.h"
@@ -310,8 +312,32 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
 // are 1.5 waves per SIMD).  Statement for statement the kernel above -- the same bits -- but compiled for latency instead
 // of residency: 256-thread blocks (every CU gets work), the register budget of two waves per SIMD, and the draw's table
 // reads of a call in flight together (rng_time_loop_few_waves).
+//
+// ... and for a launch of THREE TO SEVEN waves per SIMD (LOOP = GEN_LOOP_AHEAD, WAVES = 4: the register budget of four waves per
+// SIMD, which is also what four 256-thread blocks' tables leave room for in a CU's LDS): every wave keeps the next call's table
+// reads in flight under its own two steps (rng_time_loop_ahead) -- the batched draw of the two-wave form makes the waves of a CU
+// alternate, all together, between an LDS phase and a VALU phase.
 constexpr int FEW_BLOCK = 256;
-__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void logsv_rng_few_kernel(
+// the time loop of a LogSV generator in form LOOP: the pipelined form takes the step in its two halves
+template <int LOOP>
+__device__ __forceinline__ void logsv_gen_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab, const LogsvFast &c,
+                                                    double &xacc, double &L, double &s, double &acc, const double *exp_table)
+{
+    if constexpr (LOOP == GEN_LOOP_PIPE) {
+        LogsvStepInFlight h;
+        rng_time_loop_pipelined(
+            lane, step0, nb, tab, [&](double z0, double z1) { logsv_step_acc_front(c, xacc, L, s, z0, z1, exp_table, h); },
+            [&]() { logsv_step_acc_back(s, acc, h); });
+    } else {
+        double s2_unused = 0.0;
+        gen_time_loop<LOOP>(lane, step0, nb, tab, [&](double z0, double z1) {
+            logsv_step_acc(c, xacc, L, s, s2_unused, acc, z0, z1, [&](double v) { return exp2u_tab(v, exp_table); });
+        });
+    }
+}
+
+template <int LOOP, int WAVES, int TB>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void logsv_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, int nb_steps, LogsvFast c,
     uint64_t seed, uint32_t c3, uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init, uint64_t *probe)
 {
@@ -319,8 +345,7 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
     clock_probe_stamp(probe, 0);
-    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };
-    const size_t p = static_cast<size_t>(blockIdx.x) * FEW_BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * TB + threadIdx.x;
     const bool active = p < n;
     double xv = 0.0, s = 1.0, q = 0.0;
     if (active) {
@@ -334,11 +359,10 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
             q = qvar[p];
         }
         double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
-        double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
-        const double s2_start = s2;
+        double acc = 0.0, xacc = 0.0;
+        const double s2_start = square_rn(s);
         const PhiloxLane lane = philox_prepare(seed, c3, path_offset + p);
-        rng_time_loop_few_waves(lane, step_offset, nb_steps, tab,
-                                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); });
+        logsv_gen_time_loop<LOOP>(lane, step_offset, nb_steps, tab, c, xacc, L, s, acc, s_exp);
         logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
         x[p] = xv;
         sigma[p] = s;
@@ -348,17 +372,56 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
     slice_epilogue(so, p, active, xv, q);
 }
 
-// path counts up to this run the few-waves kernels: two waves per SIMD.  Measured (tools/r05/few_waves_sweep.py, wall time of
-// logsv_mc_chain_pricer for a 4 x 13 chain x 364 steps, few / full kernels): 2^14-2^16 paths 0.135 / 0.208 ms, 10^5-2^17
-// 0.163 / 0.210, 2 x 10^5 0.263 / 0.217 -- from three waves per SIMD on the full-launch kernels win.
-// SVMC_FEW_WAVES_MAX_PATHS overrides (0: never).
-static size_t few_waves_max_paths()
+// Which form of a generator a launch runs is decided by how many waves per SIMD it puts on the device, not by a path constant:
+//   up to lat_waves_per_simd() (7: 458752 paths on an MI355X, 256 CUs x 4 SIMDs)   the few-waves form: 256-thread blocks, the
+//                                                                                  pipelined time loop, a 128-register budget
+//   above                                                                          the full-launch kernels (eight waves per SIMD)
+// Round 6 (tools/r06/mid_waves_sweep.py -> profiles/r06_mid_waves_sweep.json; wall time of logsv_mc_chain_pricer, 4 x 13 chain x
+// 364 steps, pipelined form / round 5's batched form / full-launch kernels): 2^16 paths 0.125 / 0.140 / 0.211 ms, 10^5 0.151 /
+// 0.165 / 0.212, 2 x 10^5 0.221 / 0.264 / 0.219, 4 x 10^5 0.331 / 0.411 / 0.344, 2^19 0.371 / 0.459 / 0.362.  From two waves per
+// SIMD on EVERY form runs at 250-275 cycles per wave-step -- C2's rate: the loop is bound by VALU issue and the LDS pipe together,
+// not by latency -- and a launch takes as long as its fullest SIMD: 200 000 paths are 3.05 waves per SIMD on average but four on
+// the fullest, so they cost what 262 144 cost.  What the pipelined form buys is the latency-bound end (one or two waves per SIMD,
+// the reference's default 10^5 paths) and the block shape in between (256-thread blocks spread 6.1 waves per SIMD evenly where
+// 1024-thread blocks leave a third of the CUs with eight).
+// SVMC_FEW_WAVES_MAX_PATHS overrides the limit as a path count (0: the full-launch kernels always); SVMC_GEN_VARIANT = index into
+// LOGSV_LAT_VARIANTS / HESTON_LAT_VARIANTS (-1: full-launch) forces one compiled form for every launch (measurement only).
+static size_t device_simds()
 {
-    static const size_t v = [] {
-        const char *e = getenv("SVMC_FEW_WAVES_MAX_PATHS");
-        return e ? static_cast<size_t>(strtoull(e, nullptr, 10)) : static_cast<size_t>(2) * 64 * 1024;
-    }();
+    // per device of the calling thread's current context; the attribute query costs microseconds, so it is cached per device
+    static std::atomic<size_t> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+    size_t v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        v = static_cast<size_t>(cus) * 4;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
     return v;
+}
+
+constexpr int LAT_WAVES_PER_SIMD = 7;
+
+// true: the launch runs the few-waves form of its generator
+static bool few_waves_launch(size_t n_path)
+{
+    static const long long env_max = [] {
+        const char *e = getenv("SVMC_FEW_WAVES_MAX_PATHS");
+        return e ? static_cast<long long>(strtoull(e, nullptr, 10)) : -1ll;
+    }();
+    const size_t limit = env_max >= 0 ? static_cast<size_t>(env_max) : static_cast<size_t>(LAT_WAVES_PER_SIMD) * 64 * device_simds();
+    return n_path <= limit;
+}
+
+static int forced_gen_variant()
+{
+    static const int forced = [] {
+        const char *e = getenv("SVMC_GEN_VARIANT");
+        return e ? atoi(e) : -2;
+    }();
+    return forced;
 }
 
 // All expiries of a chain in ONE stepping launch: the slice loop runs inside the kernel, each slice with its own
@@ -468,7 +531,8 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
 }
 
 // logsv_chain_rng_kernel for a launch of a few waves per SIMD (see logsv_rng_few_kernel): the same statements, the same bits
-__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void logsv_chain_rng_few_kernel(
+template <int LOOP, int WAVES, int TB>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void logsv_chain_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials, StateInit init, uint64_t *probe)
@@ -477,10 +541,9 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
     __shared__ double s_exp[256];
     const RngTables tab = stage_tables(s_tab, s_exp);
     clock_probe_stamp(probe, 0);
-    const auto exp_of = [&](double v) { return exp2u_tab(v, s_exp); };
-    const size_t p = static_cast<size_t>(blockIdx.x) * FEW_BLOCK + threadIdx.x;
+    const size_t p = static_cast<size_t>(blockIdx.x) * TB + threadIdx.x;
     const bool active = p < n;
-    double xv = 0.0, s = 1.0, q = 0.0;                     // (two waves per SIMD: x and qvar stay in registers)
+    double xv = 0.0, s = 1.0, q = 0.0;                     // (a few waves per SIMD: x and qvar stay in registers)
     if (init.uniform) {
         xv = init.x0;
         s = init.vol0;
@@ -496,10 +559,9 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
         const int nb = cs.nb_steps[i];
         const LogsvFast c = cs.c[i];
         double L = log_state(s) * LOG_UNITS_PER_NAT;                                                  // :1039
-        double s2 = square_rn(s), acc = 0.0, xacc = 0.0;
-        const double s2_start = s2;
-        rng_time_loop_few_waves(lane, step_offset + static_cast<uint32_t>(tg), nb, tab,
-                                [&](double z0, double z1) { logsv_step_acc(c, xacc, L, s, s2, acc, z0, z1, exp_of); });
+        double acc = 0.0, xacc = 0.0;
+        const double s2_start = square_rn(s);
+        logsv_gen_time_loop<LOOP>(lane, step_offset + static_cast<uint32_t>(tg), nb, tab, c, xacc, L, s, acc, s_exp);
         logsv_fold_acc(c, xv, q, xacc, acc, s2_start, square_rn(s));
         tg += nb;
         const SliceOut so = {x_snap + static_cast<size_t>(i) * n, q_snap ? q_snap + static_cast<size_t>(i) * n : nullptr,
@@ -513,6 +575,38 @@ __global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
     clock_probe_stamp(probe, 1);
 }
+
+// The compiled few-waves forms of the LogSV generators.  Entry 0 is the product form; the rest are the alternatives the round-6
+// sweep measured against it (tools/r06/mid_waves_sweep.py selects one for EVERY launch with SVMC_GEN_VARIANT = index).
+using LogsvSliceKernel = void (*)(double *, double *, double *, size_t, int, LogsvFast, uint64_t, uint32_t, uint64_t, uint32_t, SliceOut,
+                                  StateInit, uint64_t *);
+using LogsvChainKernel = void (*)(double *, double *, double *, size_t, ChainSlices, uint64_t, uint32_t, uint64_t, uint32_t, double *,
+                                  double *, double *, StateInit, uint64_t *);
+struct LogsvLatVariant {
+    LogsvSliceKernel slice;
+    LogsvChainKernel chain;
+    int block;
+};
+#define SVMC_LOGSV_LAT(LOOP, WAVES, TB) {logsv_rng_lat_kernel<LOOP, WAVES, TB>, logsv_chain_rng_lat_kernel<LOOP, WAVES, TB>, TB}
+static const LogsvLatVariant LOGSV_LAT_VARIANTS[] = {
+    SVMC_LOGSV_LAT(GEN_LOOP_PIPE, 4, 256),     // 0: the product form
+    SVMC_LOGSV_LAT(GEN_LOOP_FEW, 2, 256),      // 1: round 5's few-waves form (all eight reads of a call, then the cubics)
+    SVMC_LOGSV_LAT(GEN_LOOP_AHEAD, 4, 256),    // 2: the next call's reads under this call's two steps
+    SVMC_LOGSV_LAT(GEN_LOOP_PAIR, 4, 256),     // 3: the next step's reads under this step
+};
+#undef SVMC_LOGSV_LAT
+constexpr int N_LOGSV_LAT_VARIANTS = static_cast<int>(sizeof(LOGSV_LAT_VARIANTS) / sizeof(LOGSV_LAT_VARIANTS[0]));
+
+// -> the entry of LOGSV_LAT_VARIANTS a launch of n_path paths runs, or null: the full-launch kernels
+static const LogsvLatVariant *logsv_lat_variant(size_t n_path)
+{
+    const int forced = forced_gen_variant();
+    if (forced == -1) return nullptr;
+    if (forced >= 0) return &LOGSV_LAT_VARIANTS[forced < N_LOGSV_LAT_VARIANTS ? forced : 0];
+    return few_waves_launch(n_path) ? &LOGSV_LAT_VARIANTS[0] : nullptr;
+}
+
+static inline unsigned lat_grid(size_t n, int block = FEW_BLOCK) { return static_cast<unsigned>((n + block - 1) / block); }
 
 // Streamed-randoms time loop: HBM-bound (8 B per supplied random per path-step).  Software-pipelined by hand:
 // the NARR*U loads of the next U steps are issued before the current U steps are computed, so every wave keeps
@@ -1065,6 +1159,14 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
 constexpr int ROW_MOMENTS_MAX = 4;
 constexpr int ROW_SEGMENTS = 4;        // blocks per row: 1025 rows x 4 fill the chip; their partial sums are added in order
 
+// Round 6: both kernels read 16 bytes per lane and keep eight (row sums) / four (expanding mean) such loads in flight -- 32 KB
+// per block, several blocks per CU -- where round 5's read 8 bytes four deep and stood at 5.0 / 4.5 TB/s (0.63 / 0.56 of the
+// HBM peak; logsv_w_kernel, the same kind of pass, reaches 5.9).  The expanding mean also lost its fp64 DIVIDE per element
+// (about forty instructions: 1.1 ms of issue for 2^30 elements beside 2.9 ms of memory time): the divisor of a row is the
+// same for every path, so each block forms the reciprocals 1 / (t + 1) of a chunk of rows once, in LDS, by the correctly
+// rounded division, and an element costs one multiplication -- within an ulp of the quotient.
+constexpr int ROW_SUM_U = 8;           // 16-byte loads in flight per lane
+
 template <int K>
 __global__ __launch_bounds__(BLOCK) void row_power_sums_kernel(const double *__restrict__ a, size_t ld, size_t n_cols, double center,
                                                                double *__restrict__ partials /* [rows][ROW_SEGMENTS][2K] */)
@@ -1072,7 +1174,8 @@ __global__ __launch_bounds__(BLOCK) void row_power_sums_kernel(const double *__r
     __shared__ double lds[4 * block_sum_padded(2 * K)];
     const size_t row = blockIdx.x, seg = blockIdx.y;
     const double *__restrict__ src = a + row * ld;
-    const size_t lo = n_cols * seg / ROW_SEGMENTS, hi = n_cols * (seg + 1) / ROW_SEGMENTS;
+    size_t lo = n_cols * seg / ROW_SEGMENTS;
+    const size_t hi = n_cols * (seg + 1) / ROW_SEGMENTS;
     double acc[2 * K];
 #pragma unroll
     for (int j = 0; j < 2 * K; ++j) acc[j] = 0.0;
@@ -1085,39 +1188,74 @@ __global__ __launch_bounds__(BLOCK) void row_power_sums_kernel(const double *__r
             pw *= d;
         }
     };
-    size_t i = lo + threadIdx.x;
-    for (; i + 3 * BLOCK < hi; i += 4 * BLOCK) {           // four loads in flight per lane
-        const double v0 = src[i], v1 = src[i + BLOCK], v2 = src[i + 2 * BLOCK], v3 = src[i + 3 * BLOCK];
-        add(v0);
-        add(v1);
-        add(v2);
-        add(v3);
+    // a segment that does not start on a 16-byte boundary gives its first element to thread 0 (block-uniform test)
+    if (lo < hi && (reinterpret_cast<uintptr_t>(src + lo) & 15u) != 0u) {
+        if (threadIdx.x == 0) add(src[lo]);
+        ++lo;
     }
-    for (; i < hi; i += BLOCK) add(src[i]);
+    const size_t pairs = (hi - lo) >> 1;                   // double2 elements of the aligned body
+    const double2 *__restrict__ src2 = reinterpret_cast<const double2 *>(src + lo);
+    size_t i = threadIdx.x;
+    for (; i + (ROW_SUM_U - 1) * BLOCK < pairs; i += ROW_SUM_U * BLOCK) {
+        double2 v[ROW_SUM_U];
+#pragma unroll
+        for (int u = 0; u < ROW_SUM_U; ++u) v[u] = src2[i + u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < ROW_SUM_U; ++u) {
+            add(v[u].x);
+            add(v[u].y);
+        }
+    }
+    for (; i < pairs; i += BLOCK) {
+        const double2 v = src2[i];
+        add(v.x);
+        add(v.y);
+    }
+    if (((hi - lo) & 1u) != 0u && threadIdx.x == 0) add(src[hi - 1]);
     block_sum_store<2 * K>(acc, lds, partials + (row * ROW_SEGMENTS + seg) * (2 * K), 2 * K);
 }
 
+// out[t][p] = mean of a[u][p]^2 over u <= t.  PAIR: a lane owns the two adjacent columns 2 i, 2 i + 1 and moves 16 bytes per
+// access (the caller checks that both arrays and leading dimensions allow it); otherwise one column, 8 bytes.
+constexpr int EXPANDING_CHUNK = 1024;  // rows whose reciprocals a block holds in LDS at a time
+template <bool PAIR>
 __global__ __launch_bounds__(BLOCK) void expanding_mean_sq_kernel(const double *__restrict__ a, size_t ld, size_t n_rows, size_t n_cols,
                                                                   double *__restrict__ out, size_t ldo)
 {
-    const size_t p = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
-    if (p >= n_cols) return;
-    double q = 0.0;
-    size_t t = 0;
-    for (; t + 4 <= n_rows; t += 4) {                      // four rows in flight
-        double v[4];
+    __shared__ double s_inv[EXPANDING_CHUNK];
+    using Vec = typename std::conditional<PAIR, double2, double>::type;
+    constexpr size_t W = PAIR ? 2 : 1;
+    const size_t p = (static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x) * W;
+    const bool active = p < n_cols;                        // (PAIR: n_cols is even)
+    double q0 = 0.0, q1 = 0.0;
+    for (size_t t0 = 0; t0 < n_rows; t0 += EXPANDING_CHUNK) {
+        const size_t nt = (n_rows - t0 < static_cast<size_t>(EXPANDING_CHUNK)) ? n_rows - t0 : EXPANDING_CHUNK;
+        __syncthreads();                                   // everybody is done with the previous chunk's reciprocals
+        for (size_t j = threadIdx.x; j < nt; j += BLOCK) s_inv[j] = 1.0 / static_cast<double>(t0 + j + 1);
+        __syncthreads();
+        if (!active) continue;
+        const auto one = [&](const Vec &v, size_t j) {
+            Vec o;
+            if constexpr (PAIR) {
+                q0 = fma(v.x, v.x, q0);
+                q1 = fma(v.y, v.y, q1);
+                o.x = q0 * s_inv[j];
+                o.y = q1 * s_inv[j];
+            } else {
+                q0 = fma(v, v, q0);
+                o = q0 * s_inv[j];
+            }
+            *reinterpret_cast<Vec *>(out + (t0 + j) * ldo + p) = o;
+        };
+        size_t j = 0;
+        for (; j + 4 <= nt; j += 4) {                      // four rows in flight
+            Vec v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = a[(t + u) * ld + p];
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const Vec *>(a + (t0 + j + u) * ld + p);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            q = fma(v[u], v[u], q);
-            out[(t + u) * ldo + p] = q / static_cast<double>(t + u + 1);
+            for (int u = 0; u < 4; ++u) one(v[u], j + u);
         }
-    }
-    for (; t < n_rows; ++t) {
-        const double v = a[t * ld + p];
-        q = fma(v, v, q);
-        out[t * ldo + p] = q / static_cast<double>(t + 1);
+        for (; j < nt; ++j) one(*reinterpret_cast<const Vec *>(a + (t0 + j) * ld + p), j);
     }
 }
 
@@ -1291,22 +1429,31 @@ __global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_expiries_
 #define SVMC_HESTON_ATTR               // A/B hook (tools/ubench/build_variants.sh): e.g. __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 // FEW: the launch runs a few waves per SIMD (see logsv_rng_few_kernel): the draw's table reads of a call in flight together
-template <bool FEW, class Step>
-__device__ __forceinline__ void heston_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab, Step &&step)
+// kernel-template scheme ids: the C ABI's two (SVMC_HESTON_EULER_FLOOR = 0, SVMC_HESTON_QE = 1) and QE specialised at compile
+// time for parameter sets that never leave the quadratic branch and keep the martingale correction defined (QeConsts::quad_only
+// && e_below_one; heston_qe_step<true>) -- the host picks it, the caller never sees it
+constexpr int HESTON_QE_QUAD = 2;
+constexpr bool heston_is_qe(int scheme) { return scheme == SVMC_HESTON_QE || scheme == HESTON_QE_QUAD; }
+static inline int heston_kernel_scheme(int scheme, const QeConsts &qc)
 {
-    if constexpr (FEW) rng_time_loop_few_waves(lane, step0, nb, tab, step);
-    else rng_time_loop(lane, step0, nb, tab, step);
+    return (scheme == SVMC_HESTON_QE && qc.quad_only && qc.e_below_one) ? HESTON_QE_QUAD : scheme;
 }
 
-template <int SCHEME, bool FEW>
+template <int LOOP, class Step>
+__device__ __forceinline__ void heston_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab, Step &&step)
+{
+    gen_time_loop<LOOP>(lane, step0, nb, tab, step);
+}
+
+template <int SCHEME, int LOOP>
 __device__ __forceinline__ void heston_rng_body(double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n,
                                                 int nb_steps, HestonConsts c, QeConsts qc, uint64_t seed, uint32_t c3,
                                                 uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init)
 {
     __shared__ RngTablesLds s_tab;
-    __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
+    __shared__ LogTabEntry s_log[heston_is_qe(SCHEME) ? 512 : 1];
     RngTables tab;
-    if constexpr (SCHEME == SVMC_HESTON_QE) tab = stage_rng_log_tables(s_tab, s_log);
+    if constexpr (heston_is_qe(SCHEME)) tab = stage_rng_log_tables(s_tab, s_log);
     else tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -1321,24 +1468,32 @@ __device__ __forceinline__ void heston_rng_body(double *__restrict__ x, double *
             v = var[p];
             q = qvar[p];
         }
-        const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
+        const PhiloxLane lane = philox_prepare(seed, heston_is_qe(SCHEME) ? (c3 | 4u) : c3, path_offset + p);
         const HestonEulerFast ef = make_heston_euler_fast(c);
         double xacc = 0.0, vacc = 0.0;
-        if (SCHEME == SVMC_HESTON_QE) {
+        if constexpr (SCHEME == HESTON_QE_QUAD) {
+            double vsum = 0.0, ksum = 0.0;
+            const double v_first = v;
+            const QeVec qv = make_qe_vec(qc);
+            heston_time_loop<LOOP>(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
+                heston_qe_step<true>(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, []() { return 0.0; });
+            });
+            heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
+        } else if constexpr (SCHEME == SVMC_HESTON_QE) {
             const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);
             QeUniforms uc;
             uint32_t step = step_offset;
             double vsum = 0.0, ksum = 0.0;
             const double v_first = v;
             const QeVec qv = make_qe_vec(qc);
-            heston_time_loop<FEW>(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
+            heston_time_loop<LOOP>(lane, step_offset, nb_steps, tab, [&](double w0, double w1) {
                 heston_qe_step(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, [&]() { return qe_uniform(lane_u, step, uc); });
                 ++step;
             });
             heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
         } else {
             v = heston_euler_guard_zero(v);
-            heston_time_loop<FEW>(lane, step_offset, nb_steps, tab,
+            heston_time_loop<LOOP>(lane, step_offset, nb_steps, tab,
                                   [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
             heston_fold_acc(ef, xv, q, v, xacc, vacc);
         }
@@ -1356,17 +1511,17 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
                                                            uint32_t c3, uint64_t path_offset,
                                                            uint32_t step_offset, SliceOut so, StateInit init)
 {
-    heston_rng_body<SCHEME, false>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
+    heston_rng_body<SCHEME, GEN_LOOP_FULL>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
 }
 
 // the same generator for a launch of a few waves per SIMD (n_path <= few_waves_max_paths(); the reference's default is 10^5
 // paths): the statements -- and the bits -- of heston_rng_kernel, compiled for latency (see logsv_rng_few_kernel)
-template <int SCHEME>
-__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void heston_rng_few_kernel(
+template <int SCHEME, int LOOP, int WAVES, int TB>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void heston_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n, int nb_steps, HestonConsts c, QeConsts qc,
     uint64_t seed, uint32_t c3, uint64_t path_offset, uint32_t step_offset, SliceOut so, StateInit init)
 {
-    heston_rng_body<SCHEME, true>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
+    heston_rng_body<SCHEME, LOOP>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
 }
 
 // whole-chain variant, as logsv_chain_rng_kernel: the slice loop inside the kernel, one launch tail per chain
@@ -1378,7 +1533,7 @@ struct HestonChainSlices {
     int m;
 };
 
-template <int SCHEME, bool FEW>
+template <int SCHEME, int LOOP>
 __device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar,
                                                       size_t n, const HestonChainSlices &cs, uint64_t seed, uint32_t c3,
                                                       uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap,
@@ -1386,9 +1541,9 @@ __device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, do
                                                       const StateInit &init)
 {
     __shared__ RngTablesLds s_tab;
-    __shared__ LogTabEntry s_log[(SCHEME == SVMC_HESTON_QE) ? 512 : 1];
+    __shared__ LogTabEntry s_log[heston_is_qe(SCHEME) ? 512 : 1];
     RngTables tab;
-    if constexpr (SCHEME == SVMC_HESTON_QE) tab = stage_rng_log_tables(s_tab, s_log);
+    if constexpr (heston_is_qe(SCHEME)) tab = stage_rng_log_tables(s_tab, s_log);
     else tab = stage_rng_tables(s_tab);
     const size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool active = p < n;
@@ -1404,8 +1559,8 @@ __device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, do
             q = qvar[p];
         }
     }
-    const PhiloxLane lane = philox_prepare(seed, (SCHEME == SVMC_HESTON_QE) ? (c3 | 4u) : c3, path_offset + p);
-    const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);      // QE's uniforms
+    const PhiloxLane lane = philox_prepare(seed, heston_is_qe(SCHEME) ? (c3 | 4u) : c3, path_offset + p);
+    const PhiloxLane lane_u = philox_prepare(seed, c3 | 5u, path_offset + p);      // QE's uniforms (dead in the other schemes)
     QeUniforms uc;
     uint32_t step = step_offset;
     for (int i = 0; i < cs.m; ++i) {
@@ -1415,19 +1570,27 @@ __device__ __forceinline__ void heston_chain_rng_body(double *__restrict__ x, do
             const QeConsts qc = cs.qc[i];
             const HestonEulerFast ef = make_heston_euler_fast(c);
             double xacc = 0.0, vacc = 0.0;
-            if (SCHEME == SVMC_HESTON_QE) {
+            if constexpr (SCHEME == HESTON_QE_QUAD) {
+                double vsum = 0.0, ksum = 0.0;
+                const double v_first = v;
+                const QeVec qv = make_qe_vec(qc);
+                heston_time_loop<LOOP>(lane, step, nb, tab, [&](double w0, double w1) {
+                    heston_qe_step<true>(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, []() { return 0.0; });
+                });
+                heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
+            } else if constexpr (SCHEME == SVMC_HESTON_QE) {
                 double vsum = 0.0, ksum = 0.0;
                 const double v_first = v;
                 uint32_t st = step;
                 const QeVec qv = make_qe_vec(qc);
-                heston_time_loop<FEW>(lane, step, nb, tab, [&](double w0, double w1) {
+                heston_time_loop<LOOP>(lane, step, nb, tab, [&](double w0, double w1) {
                     heston_qe_step(qc, qv, tab.log, xv, v, vsum, ksum, w0, w1, [&]() { return qe_uniform(lane_u, st, uc); });
                     ++st;
                 });
                 heston_qe_fold(qc, xv, q, vsum, ksum, v_first, v);
             } else {
                 v = heston_euler_guard_zero(v);
-                heston_time_loop<FEW>(lane, step, nb, tab,
+                heston_time_loop<LOOP>(lane, step, nb, tab,
                                       [&](double w0, double w1) { heston_euler_step_acc(ef, xacc, v, vacc, w0, w1); });
                 heston_fold_acc(ef, xv, q, v, xacc, vacc);
             }
@@ -1452,16 +1615,16 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_chain_rng_k
                                                                  double *__restrict__ x_snap, double *__restrict__ q_snap,
                                                                  double *__restrict__ partials, StateInit init)
 {
-    heston_chain_rng_body<SCHEME, false>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
+    heston_chain_rng_body<SCHEME, GEN_LOOP_FULL>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
 }
 
-template <int SCHEME>
-__global__ __launch_bounds__(FEW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void heston_chain_rng_few_kernel(
+template <int SCHEME, int LOOP, int WAVES, int TB>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void heston_chain_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n, HestonChainSlices cs, uint64_t seed,
     uint32_t c3, uint64_t path_offset, uint32_t step_offset, double *__restrict__ x_snap, double *__restrict__ q_snap,
     double *__restrict__ partials, StateInit init)
 {
-    heston_chain_rng_body<SCHEME, true>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
+    heston_chain_rng_body<SCHEME, LOOP>(x, var, qvar, n, cs, seed, c3, path_offset, step_offset, x_snap, q_snap, partials, init);
 }
 
 __global__ __launch_bounds__(BLOCK) void heston_w_kernel(double *__restrict__ x, double *__restrict__ var,
@@ -1787,10 +1950,9 @@ static int logsv_rng_launch(const char *fn, double *x, double *sigma, double *qv
     if (n_path == 0) return SVMC_OK;
     LogsvFast c = logsv_fast_in_log_units(make_logsv_fast(
         make_logsv_consts(dt, theta, kappa1, kappa2, beta, volvol, vol_backbone_eta, is_spot_measure)));
-    if (n_path <= few_waves_max_paths())
-        hipLaunchKernelGGL(logsv_rng_few_kernel, dim3(static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK)), dim3(FEW_BLOCK), 0,
-                           as_stream(stream), x, sigma, qvar, n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset,
-                           so, init, armed_probe());
+    if (const LogsvLatVariant *v = logsv_lat_variant(n_path))
+        hipLaunchKernelGGL(v->slice, dim3(lat_grid(n_path, v->block)), dim3(v->block), 0, as_stream(stream), x, sigma, qvar, n_path,
+                           nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, armed_probe());
     else
         hipLaunchKernelGGL(logsv_rng_kernel, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, sigma, qvar,
                            n_path, nb_steps, c, seed, make_c3(call_id), path_offset, step_offset, so, init, armed_probe());
@@ -1901,10 +2063,10 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
         }
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
-        if (n_path <= few_waves_max_paths())
-            hipLaunchKernelGGL(logsv_chain_rng_few_kernel, dim3(static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK)),
-                               dim3(FEW_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path, cs, seed, make_c3(call_id), path_offset,
-                               step_offset, xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit(), armed_probe());
+        if (const LogsvLatVariant *v = logsv_lat_variant(n_path))
+            hipLaunchKernelGGL(v->chain, dim3(lat_grid(n_path, v->block)), dim3(v->block), 0, as_stream(stream), x, sigma, qvar, n_path,
+                               cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
+                               (i0 == 0) ? init : StateInit(), armed_probe());
         else
             hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
                                cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
@@ -2276,9 +2438,57 @@ int svmc_expanding_mean_squares(const double *a, size_t ld, size_t n_rows, size_
     SVMC_REQUIRE(a != nullptr && out != nullptr, "svmc_expanding_mean_squares: null pointer");
     SVMC_REQUIRE(ld >= n_cols && ldo >= n_cols, "svmc_expanding_mean_squares: leading dimension < n_cols");
     if (n_rows == 0 || n_cols == 0) return SVMC_OK;
-    hipLaunchKernelGGL(expanding_mean_sq_kernel, dim3(grid_for(n_cols)), dim3(BLOCK), 0, as_stream(stream), a, ld, n_rows, n_cols, out,
-                       ldo);
+    // two columns per lane (16-byte accesses) where the layout allows it: even column count and leading dimensions, 16-byte bases
+    const bool pair = (n_cols % 2 == 0) && (ld % 2 == 0) && (ldo % 2 == 0) && (reinterpret_cast<uintptr_t>(a) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    if (pair)
+        hipLaunchKernelGGL(expanding_mean_sq_kernel<true>, dim3(grid_for(n_cols / 2)), dim3(BLOCK), 0, as_stream(stream), a, ld, n_rows,
+                           n_cols, out, ldo);
+    else
+        hipLaunchKernelGGL(expanding_mean_sq_kernel<false>, dim3(grid_for(n_cols)), dim3(BLOCK), 0, as_stream(stream), a, ld, n_rows,
+                           n_cols, out, ldo);
     return check_launch("svmc_expanding_mean_squares");
+}
+
+// the compiled few-waves forms of the Heston generators, per scheme (see LOGSV_LAT_VARIANTS: entry 0 the product form, the rest
+// measurement alternatives behind SVMC_GEN_VARIANT).  The Euler step has no LDS read of its own, so one pair ahead hides the
+// draw's round trip completely; QE (100 registers by itself) runs the same loop at the 128-register budget.
+using HestonSliceKernel = void (*)(double *, double *, double *, size_t, int, HestonConsts, QeConsts, uint64_t, uint32_t, uint64_t, uint32_t,
+                                   SliceOut, StateInit);
+using HestonChainKernel = void (*)(double *, double *, double *, size_t, HestonChainSlices, uint64_t, uint32_t, uint64_t, uint32_t, double *,
+                                   double *, double *, StateInit);
+struct HestonLatVariant {
+    HestonSliceKernel slice;
+    HestonChainKernel chain;
+    int block;
+};
+#define SVMC_HESTON_LAT(S, LOOP, WAVES, TB) {heston_rng_lat_kernel<S, LOOP, WAVES, TB>, heston_chain_rng_lat_kernel<S, LOOP, WAVES, TB>, TB}
+constexpr int N_HESTON_LAT_VARIANTS = 3;
+static const HestonLatVariant HESTON_LAT_VARIANTS[3][N_HESTON_LAT_VARIANTS] = {
+    {   // Euler with the reference's floor
+        SVMC_HESTON_LAT(SVMC_HESTON_EULER_FLOOR, GEN_LOOP_PAIR, 4, 256),
+        SVMC_HESTON_LAT(SVMC_HESTON_EULER_FLOOR, GEN_LOOP_FEW, 2, 256),
+        SVMC_HESTON_LAT(SVMC_HESTON_EULER_FLOOR, GEN_LOOP_AHEAD, 4, 256),
+    },
+    {   // QE
+        SVMC_HESTON_LAT(SVMC_HESTON_QE, GEN_LOOP_PAIR, 3, 256),
+        SVMC_HESTON_LAT(SVMC_HESTON_QE, GEN_LOOP_FEW, 2, 256),
+        SVMC_HESTON_LAT(SVMC_HESTON_QE, GEN_LOOP_AHEAD, 3, 256),
+    },
+    {   // QE, quadratic branch only
+        SVMC_HESTON_LAT(HESTON_QE_QUAD, GEN_LOOP_PAIR, 4, 256),
+        SVMC_HESTON_LAT(HESTON_QE_QUAD, GEN_LOOP_FEW, 2, 256),
+        SVMC_HESTON_LAT(HESTON_QE_QUAD, GEN_LOOP_AHEAD, 3, 256),
+    }};
+#undef SVMC_HESTON_LAT
+
+static const HestonLatVariant *heston_lat_variant(int scheme, size_t n_path)
+{
+    const HestonLatVariant *row = HESTON_LAT_VARIANTS[scheme];       // kernel scheme id: 0, 1 or HESTON_QE_QUAD
+    const int forced = forced_gen_variant();
+    if (forced == -1) return nullptr;
+    if (forced >= 0) return &row[forced < N_HESTON_LAT_VARIANTS ? forced : 0];
+    return few_waves_launch(n_path) ? &row[0] : nullptr;
 }
 
 static int heston_rng_launch(const char *fn, double *x, double *var, double *qvar, size_t n_path, int nb_steps, double dt,
@@ -2293,19 +2503,19 @@ static int heston_rng_launch(const char *fn, double *x, double *var, double *qva
     if (n_path == 0) return SVMC_OK;
     const HestonConsts c = make_heston_consts(dt, theta, kappa, rho, volvol);
     const QeConsts qc = make_qe_consts(dt, theta, kappa, rho, volvol);
-    const bool few = n_path <= few_waves_max_paths();
-    const dim3 grid(few ? static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK) : rng_grid(n_path)), block(few ? FEW_BLOCK : rng_block());
-#define SVMC_HESTON_LAUNCH(KERNEL)                                                                                              \
-    hipLaunchKernelGGL(KERNEL, grid, block, 0, as_stream(stream), x, var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), \
-                       path_offset, step_offset, so, init)
-    if (scheme == SVMC_HESTON_QE) {
-        if (few) SVMC_HESTON_LAUNCH(heston_rng_few_kernel<SVMC_HESTON_QE>);
-        else SVMC_HESTON_LAUNCH(heston_rng_kernel<SVMC_HESTON_QE>);
-    } else {
-        if (few) SVMC_HESTON_LAUNCH(heston_rng_few_kernel<SVMC_HESTON_EULER_FLOOR>);
-        else SVMC_HESTON_LAUNCH(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>);
-    }
-#undef SVMC_HESTON_LAUNCH
+    const int ks = heston_kernel_scheme(scheme, qc);
+    if (const HestonLatVariant *v = heston_lat_variant(ks, n_path))
+        hipLaunchKernelGGL(v->slice, dim3(lat_grid(n_path, v->block)), dim3(v->block), 0, as_stream(stream), x, var, qvar, n_path, nb_steps,
+                           c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
+    else if (ks == HESTON_QE_QUAD)
+        hipLaunchKernelGGL(heston_rng_kernel<HESTON_QE_QUAD>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, var, qvar,
+                           n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
+    else if (scheme == SVMC_HESTON_QE)
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_QE>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x, var, qvar,
+                           n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
+    else
+        hipLaunchKernelGGL(heston_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(rng_grid(n_path)), dim3(rng_block()), 0, as_stream(stream), x,
+                           var, qvar, n_path, nb_steps, c, qc, seed, make_c3(call_id), path_offset, step_offset, so, init);
     return check_launch(fn);
 }
 
@@ -2393,19 +2603,26 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
         }
         double *xs = x_snapshots + static_cast<size_t>(i0) * n_path;
         double *qs = qvar_snapshots ? qvar_snapshots + static_cast<size_t>(i0) * n_path : nullptr;
-        const bool few = n_path <= few_waves_max_paths();
-        const dim3 grid(few ? static_cast<unsigned>((n_path + FEW_BLOCK - 1) / FEW_BLOCK) : g), block(few ? FEW_BLOCK : rng_block());
-#define SVMC_HESTON_LAUNCH(KERNEL)                                                                                              \
-    hipLaunchKernelGGL(KERNEL, grid, block, 0, as_stream(stream), x, var, qvar, n_path, cs, seed, make_c3(call_id), path_offset, \
-                       step_offset, xs, qs, static_cast<double *>(workspace), (i0 == 0) ? init : StateInit())
-        if (scheme == SVMC_HESTON_QE) {
-            if (few) SVMC_HESTON_LAUNCH(heston_chain_rng_few_kernel<SVMC_HESTON_QE>);
-            else SVMC_HESTON_LAUNCH(heston_chain_rng_kernel<SVMC_HESTON_QE>);
-        } else {
-            if (few) SVMC_HESTON_LAUNCH(heston_chain_rng_few_kernel<SVMC_HESTON_EULER_FLOOR>);
-            else SVMC_HESTON_LAUNCH(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>);
+        const StateInit init_i = (i0 == 0) ? init : StateInit();
+        double *const ws = static_cast<double *>(workspace);
+        int ks = scheme;
+        if (scheme == SVMC_HESTON_QE) {                    // the specialised kernel only if EVERY slice of the launch allows it
+            ks = HESTON_QE_QUAD;
+            for (int i = 0; i < cs.m; ++i)
+                if (heston_kernel_scheme(scheme, cs.qc[i]) != HESTON_QE_QUAD) ks = scheme;
         }
-#undef SVMC_HESTON_LAUNCH
+        if (const HestonLatVariant *v = heston_lat_variant(ks, n_path))
+            hipLaunchKernelGGL(v->chain, dim3(lat_grid(n_path, v->block)), dim3(v->block), 0, as_stream(stream), x, var, qvar, n_path, cs,
+                               seed, make_c3(call_id), path_offset, step_offset, xs, qs, ws, init_i);
+        else if (ks == HESTON_QE_QUAD)
+            hipLaunchKernelGGL(heston_chain_rng_kernel<HESTON_QE_QUAD>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, var, qvar,
+                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, ws, init_i);
+        else if (scheme == SVMC_HESTON_QE)
+            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_QE>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, var, qvar,
+                               n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, ws, init_i);
+        else
+            hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, var,
+                               qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, ws, init_i);
         hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
                            static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;

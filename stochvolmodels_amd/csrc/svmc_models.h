@@ -152,6 +152,33 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc,
     (void)s2;                                     // sigma^2 is not carried: the fold squares the terminal sigma itself
 }
 
+// logsv_step_acc in two halves around its exp-table read (rng_time_loop_pipelined puts state-independent work between them):
+// front = everything up to the ISSUE of the table read, back = what consumes the value.  logsv_step_acc's operations with
+// exp2u_tab as the exponential, in its order: the same bits.
+struct LogsvStepInFlight {
+    double r, t;
+    int ni;
+};
+__device__ __forceinline__ void logsv_step_acc_front(const LogsvFast &f, double &xacc, double &L, double sigma, double z0, double z1,
+                                                     const double *exp_table, LogsvStepInFlight &h)
+{
+    const double y = rcp_1n(sigma);
+    xacc = fma(sigma, z0, xacc);
+    L = fma(f.c2, sigma, L);
+    L = fma(f.c1, y, L);
+    L = L + f.c3;
+    L = fma(f.bs, z0, L);
+    L = fma(f.es, z1, L);
+    exp2u_reduce(L, h.ni, h.r);
+    h.t = exp_table[h.ni & 255];
+}
+__device__ __forceinline__ void logsv_step_acc_back(double &sigma, double &acc, const LogsvStepInFlight &h)
+{
+    const double sn = exp2u_scale(h.t, exp2u_tail(h.r), h.ni);
+    acc = fma(sn, sn, acc);
+    sigma = sn;
+}
+
 // logsv_step_acc for P independent states of one lane (P parameter sets on the same two normals), piece by piece ACROSS the
 // states: the reciprocals, the five updates of L, the exp's reduction, all P table reads, the tails, the scalings.  Per
 // state these are logsv_step_acc's operations in logsv_step_acc's order -- the same bits -- but the P dependent chains
@@ -412,7 +439,11 @@ __device__ __forceinline__ double log_one_minus(double e, const LogTabEntry *tab
 // bits), logs go through the LDS table.  x advances by sqrt(K3 v0 + K4 v1) z0 alone; the drift terms are SUMS over the
 // steps -- K1m sum v0 + K2 sum v1 + sum K0* -- and are folded in once (heston_qe_fold: `vsum` = sum v1, `ksum` = sum 2 K0*,
 // sum v0 = v_first + vsum - v_last), as is the quadratic variance dt (vsum + (v_first - v_last)/2).
-template <class DrawU>
+// QUAD (compile time): the parameters rule the exponential branch out (c.quad_only) AND keep the martingale correction's
+// argument below one (c.e_below_one) -- both C3 sets, every Feller-satisfying set with rho <= 0: a kernel instantiated so carries
+// neither branch, their registers, nor the uniform's Philox state.  The statements that remain are the general form's, so are
+// the bits.
+template <bool QUAD = false, class DrawU>
 __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &cv, const LogTabEntry *tab, double &x,
                                                double &var, double &vsum, double &ksum, double z0, double z1, DrawU &&draw_u)
 {
@@ -424,13 +455,15 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
     double v1, Kd;                                        // Kd = 2 K0, K0 without its -K13 v0 term (that rides in K1m)
     bool quad = true;
     double u = m;                                         // any defined value: only lanes past the test below read it
-    if (!c.quad_only) {                                   // (wave-uniform)
-        quad = w >= 0.25 * m2;                            // psi <= psi_c = 3/2 (s2 <= 3/2 m^2), decided without the divide
-        // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
-        // on-device draw is a Philox call that serves four steps: every lane must take part in it)
-        if (!__all(quad)) u = draw_u();
+    if constexpr (!QUAD) {
+        if (!c.quad_only) {                               // (wave-uniform)
+            quad = w >= 0.25 * m2;                        // psi <= psi_c = 3/2 (s2 <= 3/2 m^2), decided without the divide
+            // the uniform of the exponential branch is fetched by the WHOLE wave as soon as one of its lanes needs it (the
+            // on-device draw is a Philox call that serves four steps: every lane must take part in it)
+            if (!__all(quad)) u = draw_u();
+        }
     }
-    if (quad) {
+    if (QUAD || quad) {
         double h;                                         // ~ 1 / (2 alpha)
         const double al = sqrt_pos_1g_h(w, h);            // alpha to 2^-47
         // a = m - alpha cancels: alpha's 2^-47 would reach it multiplied by alpha / a = 4 / psi (3e-12 at C3's psi ~ 0.01).
@@ -445,7 +478,7 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
             Kd = 0.0;
         } else {
             const double e = c.twoA * a;                  // 2 A a
-            if (c.e_below_one || e < 1.0) {
+            if (QUAD || c.e_below_one || e < 1.0) {
                 double inv;
                 const double ln_den = log_one_minus(e, tab, inv);
                 Kd = fma(-(c.twoA * al), inv, ln_den);    // ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)

@@ -342,6 +342,196 @@ __device__ __forceinline__ void rng_time_loop_few_waves(const PhiloxLane &lane, 
     }
 }
 
+// rng_time_loop for launches of three to seven waves per SIMD (2^17 < paths < 2^20: the path counts the reference's own runs
+// use -- 10^5 by default, 4 x 10^5 in its paper).  There the batched draw of rng_time_loop_few_waves turns against itself: the
+// waves of a CU run the same code from the same start, so they all sit in the draw's LDS phase together (8 ds_read_b128 per
+// wave, ~100 LDS cycles each with the bank conflicts of random indices) and then all in the VALU phase together -- LDS time and
+// VALU time ADD (measured: 1250 cycles per step at three waves per SIMD, against 620 of issue and 670 of LDS).  Here every wave
+// overlaps the two BY ITSELF: the words, indices and table reads of call c + 1 are issued before the two steps of call c, its
+// cubics run after them (the draw does not depend on the state), so the LDS pipe works through a wave's reads while that
+// wave's own steps issue.  The last trip draws a call nobody uses rather than branching inside the trip (a branch splits the
+// scheduling region: logsv_chain_rng_sets_kernel measured it).  The edge halves of a slice that starts or ends on an odd step
+// are peeled.  Which (path, step) sees which word is rng_time_loop's rule, the operations on them are normal_icdf32's: the
+// same bits.  Costs ~40 live registers more than rng_time_loop (the eight table pieces in flight across two steps).
+template <class Step>
+__device__ __forceinline__ void rng_time_loop_ahead(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                                    Step &&step)
+{
+    if (nb <= 0) return;
+    const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
+    uint32_t c = first >> 1, r[4];
+    double a0, a1;
+    if (first & 1u) {
+        philox_draw(lane, c, r);
+        normals_from_words(r[2], r[3], tab, a0, a1);
+        step(a0, a1);
+        ++c;
+    }
+    const uint32_t c_end = (last + 1u) >> 1;               // the full calls are [c, c_end)
+    if (c < c_end) {
+        DrawInFlight d;
+        philox_draw(lane, c, r);
+        draw_issue(r, tab, d);
+        for (; c < c_end; ++c) {
+            double z[4];
+            draw_finish(d, z);
+            philox_draw(lane, c + 1u, r);
+            draw_issue(r, tab, d);
+            step(z[0], z[1]);
+            step(z[2], z[3]);
+        }
+    }
+    if (!(last & 1u)) {
+        philox_draw(lane, last >> 1, r);
+        normals_from_words(r[0], r[1], tab, a0, a1);
+        step(a0, a1);
+    }
+}
+
+// The draw of ONE time step's pair of normals in three pieces (prepare: word -> t and table offset; read: the four
+// ds_read_b128; finish: the two cubics), for the loops that keep one pair in flight under the step before it.  normal_icdf32's
+// operations on the same operands: the same bits.
+struct PairInFlight {
+    double t[2];
+    IcdfPiece e0[2], e1[2];
+};
+__device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTables &tab, PairInFlight &d)
+{
+    static_assert(SVMC_ICDF_RAW != 0, "the split draw is written for the raw form of the table");
+    const uint32_t w[2] = {ra, rb};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        d.t[k] = static_cast<double>(static_cast<int32_t>(w[k])) + 0.5;
+        const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
+        const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
+        d.e0[k] = *reinterpret_cast<const IcdfPiece *>(base);
+        d.e1[k] = *reinterpret_cast<const IcdfPiece *>(base + 16 * SVMC_ICDF_SEGMENTS);
+    }
+}
+__device__ __forceinline__ void pair_finish(const PairInFlight &d, double &z0, double &z1)
+{
+    double z[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double a = fabs(d.t[k]);
+        double p = fma(d.e1[k].b, a, d.e1[k].a);
+        p = fma(p, a, d.e0[k].b);
+        p = fma(p, a, d.e0[k].a);
+        z[k] = copysign(p, d.t[k]);
+    }
+    z0 = z[0];
+    z1 = z[1];
+}
+
+// rng_time_loop with ONE PAIR ahead: the table reads of the next step's two normals are issued before this step runs and
+// their cubics evaluated after it -- half the registers of rng_time_loop_ahead (one pair in flight, not four normals), for
+// launches that still want five to seven waves per SIMD.  Same words, same operations: the same bits.
+template <class Step>
+__device__ __forceinline__ void rng_time_loop_pair_ahead(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                                         Step &&step)
+{
+    if (nb <= 0) return;
+    const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
+    uint32_t c = first >> 1, r[4];
+    double a0, a1;
+    if (first & 1u) {
+        philox_draw(lane, c, r);
+        normals_from_words(r[2], r[3], tab, a0, a1);
+        step(a0, a1);
+        ++c;
+    }
+    const uint32_t c_end = (last + 1u) >> 1;               // the full calls are [c, c_end)
+    if (c < c_end) {
+        PairInFlight d;
+        philox_draw(lane, c, r);
+        pair_issue(r[0], r[1], tab, d);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; c < c_end; ++c) {
+            double z0, z1;
+            pair_finish(d, z0, z1);
+            pair_issue(r[2], r[3], tab, d);
+            __builtin_amdgcn_sched_barrier(0);
+            step(z0, z1);
+            pair_finish(d, z0, z1);
+            philox_draw(lane, c + 1u, r);                  // the last trip draws a call nobody uses (no branch in the trip)
+            pair_issue(r[0], r[1], tab, d);
+            __builtin_amdgcn_sched_barrier(0);
+            step(z0, z1);
+        }
+    }
+    if (!(last & 1u)) {
+        philox_draw(lane, last >> 1, r);
+        normals_from_words(r[0], r[1], tab, a0, a1);
+        step(a0, a1);
+    }
+}
+
+// The same idea one level finer, for a step that itself waits on an LDS read (LogSV: the exp table): the step comes in two
+// halves, front(z0, z1) -- everything up to and including the ISSUE of its table read -- and back() -- what consumes the
+// value.  Between them runs work that does not depend on the state: the cubics of the NEXT step's pair (its reads are older
+// than the step's own read, so they have landed when it has), the Philox call after this one, and the issue of the pair after
+// that -- whose reads are younger than the step's own, so back() waits for the exp value only (s_waitcnt lgkmcnt(4)) and the
+// pair's four reads stay in flight under back() and the next front().  A lone wave thus overlaps its own LDS round trips with
+// its own arithmetic, and the waves of a CU cannot fall into a common LDS phase.  Same words, same operations: the same bits.
+template <class Front, class Back>
+__device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                                        Front &&front, Back &&back)
+{
+    if (nb <= 0) return;
+    const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
+    uint32_t c = first >> 1, r[4];
+    double a0, a1;
+    if (first & 1u) {
+        philox_draw(lane, c, r);
+        normals_from_words(r[2], r[3], tab, a0, a1);
+        front(a0, a1);
+        back();
+        ++c;
+    }
+    const uint32_t c_end = (last + 1u) >> 1;               // the full calls are [c, c_end)
+    if (c < c_end) {
+        PairInFlight d;
+        double z0, z1;
+        philox_draw(lane, c, r);
+        pair_issue(r[0], r[1], tab, d);
+        pair_finish(d, z0, z1);
+        pair_issue(r[2], r[3], tab, d);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; c < c_end; ++c) {
+            front(z0, z1);                                 // step 2c; its table read is now the youngest LDS operation
+            __builtin_amdgcn_sched_barrier(0);
+            pair_finish(d, z0, z1);                        // the normals of step 2c + 1
+            philox_draw(lane, c + 1u, r);                  // the last trip draws a call nobody uses (no branch in the trip)
+            pair_issue(r[0], r[1], tab, d);                // ... of step 2c + 2: in flight under back() and the next front()
+            __builtin_amdgcn_sched_barrier(0);
+            back();
+            front(z0, z1);                                 // step 2c + 1
+            __builtin_amdgcn_sched_barrier(0);
+            pair_finish(d, z0, z1);                        // the normals of step 2c + 2
+            pair_issue(r[2], r[3], tab, d);                // ... of step 2c + 3
+            __builtin_amdgcn_sched_barrier(0);
+            back();
+        }
+    }
+    if (!(last & 1u)) {
+        philox_draw(lane, last >> 1, r);
+        normals_from_words(r[0], r[1], tab, a0, a1);
+        front(a0, a1);
+        back();
+    }
+}
+
+// the three forms of the generators' time loop, by launch size (generator_loop_for() in svmc_kernels.hip picks)
+enum GenLoop { GEN_LOOP_FULL = 0, GEN_LOOP_FEW = 1, GEN_LOOP_PAIR = 2, GEN_LOOP_AHEAD = 3, GEN_LOOP_PIPE = 4 };
+template <int LOOP, class Step>
+__device__ __forceinline__ void gen_time_loop(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab, Step &&step)
+{
+    if constexpr (LOOP == GEN_LOOP_FEW) rng_time_loop_few_waves(lane, step0, nb, tab, step);
+    else if constexpr (LOOP == GEN_LOOP_AHEAD) rng_time_loop_ahead(lane, step0, nb, tab, step);
+    else if constexpr (LOOP == GEN_LOOP_PAIR || LOOP == GEN_LOOP_PIPE) rng_time_loop_pair_ahead(lane, step0, nb, tab, step);
+    else rng_time_loop(lane, step0, nb, tab, step);
+}
+
 // stream 0 for a single (path, step), from scratch: the step's two UNSCALED N(0,1)  (svmc_fill_normals)
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t c3, uint64_t path, uint32_t step,
                                              const RngTables &t, double &w0, double &w1)

@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
-from ..engine import HESTON_EULER_FLOOR, HESTON_QE, get_engine
+from ..engine import HESTON_EULER_FLOOR, HESTON_QE, get_engine, marshalled_chain, option_type_codes
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
@@ -51,6 +51,8 @@ def _scheme_code(scheme) -> int:
 
 # heston_mc_chain_pricer steps all expiries of a multi-expiry chain in one launch (svmc_heston_chain_rng) when True
 WHOLE_CHAIN_STEPPING = True
+# single-GPU chains go through svmc_heston_chain_price on the engine's own state (one C-ABI call per chain) when True
+FUSED_MC_CHAIN_DRIVER = True
 
 
 class HestonPricer(ModelPricer):
@@ -221,6 +223,13 @@ def heston_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: 
     offset, n_local = svdist.shard_range(nb_path, comm.rank, comm.world)
     eng = get_engine(n_local, path_offset=offset)
     rng_seed, call_id = next_rng_call(seed)
+    if FUSED_MC_CHAIN_DRIVER and WHOLE_CHAIN_STEPPING and comm.world == 1 and hasattr(eng, "price_heston_chain_fused"):
+        # one GPU: ONE call of the fused C driver on the engine's own state (see logsv_mc_chain_pricer)
+        ch = marshalled_chain(ttms, forwards, discfactors, strikes_ttms, [option_type_codes(t) for t in optiontypes_ttms])
+        prices, stderrs = eng.price_heston_chain_fused(ch, v0, theta, kappa, rho, volvol, code, nb_steps_per_year, vt_code,
+                                                       rng_seed, call_id)
+        return ([a.reshape(np.shape(k)) for a, k in zip(prices, strikes_ttms)],
+                [a.reshape(np.shape(k)) for a, k in zip(stderrs, strikes_ttms)])
     grids, t0 = [], 0.0
     for ttm in ttms:
         nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)

@@ -19,14 +19,14 @@ import pandas as pd
 
 from .. import dist as svdist
 from ..data.option_chain import OptionChain
-from ..engine import DeviceRandoms, get_engine, option_type_codes, payoff_finalize
+from ..engine import DeviceRandoms, get_engine, marshalled_chain, option_type_codes, payoff_finalize
 from ..mc_chain import price_chain_on_engine, variable_type_code
 from ..utils.calibration import ImpliedVolObjective, chain_calibration_weights, minimize_slsqp
 from ..utils.config import VariableType
 from ..utils.funcs import next_rng_call, set_time_grid, time_grid_steps, timer
 from ..analytic import AnalyticGrid, qvar_prices_from_sums, vanilla_prices_from_capped
 from ..utils import mgf_pricer as mgfp
-from .logsv.affine_expansion import ExpansionOrder, _order_code
+from .logsv.affine_expansion import ExpansionOrder, _order_code, note_integrator_flags
 from .logsv.logsv_params import LogSvParams
 from .logsv.vol_moments_ode import fit_model_vol_backbone_to_varswaps
 from .model_pricer import ModelPricer
@@ -115,6 +115,9 @@ def _calibration_constraints(parse, constraints_type: ConstraintsType):
 WHOLE_CHAIN_STEPPING = True
 # single-GPU chains on resident randoms go through svmc_logsv_chain_price_fixed (one C++ call per chain) when True
 FUSED_FIXED_RANDOMS_DRIVER = True
+# single-GPU chains with on-device randoms go through svmc_logsv_chain_price on the engine's own state (one C-ABI call per chain)
+# when True; False (or WHOLE_CHAIN_STEPPING off, or several ranks): the phase-by-phase Python driver mc_chain.price_chain_on_engine
+FUSED_MC_CHAIN_DRIVER = True
 # rough LogSV chains: every expiry in one stepping launch (svmc_rough_logsv_chain); False = one launch per expiry (A/B, tests)
 ROUGH_CHAIN_ONE_LAUNCH = True
 
@@ -408,8 +411,7 @@ def logsv_chain_pricer(params: LogSvParams, ttms: np.ndarray, forwards: np.ndarr
     vt = int(getattr(variable_type, "value", variable_type))
     if vt not in (1, 2):
         raise NotImplementedError
-    if is_analytic:
-        raise NotImplementedError("the semi-analytic fixed-point path is not part of this package")
+    note_integrator_flags(is_stiff_solver, is_analytic)       # both accepted: one device integrator answers them (warned once)
     order = _order_code(expansion_order)
     if vol_scaler is None:
         vol_scaler = set_vol_scaler(sigma0=params.sigma0, ttm=np.min(ttms))
@@ -564,6 +566,16 @@ def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: n
                                     call_id)
     comm = comm or svdist.get_default_comm()
     rng_seed, call_id = next_rng_call(seed)
+    if FUSED_MC_CHAIN_DRIVER and WHOLE_CHAIN_STEPPING and comm.world == 1:
+        eng = get_engine(nb_path)
+        if hasattr(eng, "price_logsv_chain_fused"):
+            # one GPU: the whole chain is ONE call of the fused C driver on the engine's own state (the kernels of the route
+            # below in the same order: the same bits; -21 us of interpreter and ctypes per call)
+            ch = marshalled_chain(ttms, forwards, discfactors, strikes_ttms, [option_type_codes(t) for t in optiontypes_ttms])
+            prices, stderrs = eng.price_logsv_chain_fused(ch, v0, theta, kappa1, kappa2, beta, volvol, vol_backbone_etas,
+                                                          is_spot_measure, nb_steps_per_year, vt_code, rng_seed, call_id)
+            return ([_shaped_like(a, k) for a, k in zip(prices, strikes_ttms)],
+                    [_shaped_like(a, k) for a, k in zip(stderrs, strikes_ttms)])
     grids, t0 = [], 0.0
     for ttm in ttms:
         nb, dt = time_grid_steps(ttm=ttm - t0, nb_steps_per_year=nb_steps_per_year)

@@ -148,6 +148,89 @@ def g_logsv_chain_philox():
     save("logsv_chain_philox", **out)
 
 
+# -- a3 / a6 at 2^16 paths on C4's chain shape, the svmc Philox stream fed INTO the reference ------------------------
+def c4_shape_chain():
+    ttms = np.arange(1, 9) / 8.0
+    forwards = 67000.0 * np.exp(0.05 * ttms)
+    dfs = np.exp(-0.05 * ttms)
+    strikes = tuple(f * np.linspace(0.6, 1.6, 21) for f in forwards)
+    types = tuple(np.where(k >= f, "C", "P") for k, f in zip(strikes, forwards))
+    return ttms, forwards, dfs, strikes, types
+
+
+def philox_feed(seed, n, ttms, spy, call_id=0):
+    """the stream-0 normals of a chain, slice by slice, as the generators index them (chain-global step index)"""
+    W0s, W1s, dts, nbs, step0, t0 = [], [], [], [], 0, 0.0
+    for ttm in ttms:
+        nb, dt, _ = set_time_grid(ttm=ttm - t0, nb_steps_per_year=spy)
+        W0, W1 = oracle.fill_normals(seed, n, nb, call_id=call_id, step_offset=step0)
+        W0s.append(W0), W1s.append(W1), dts.append(dt), nbs.append(nb)
+        step0 += nb
+        t0 = ttm
+    return W0s, W1s, dts, nbs
+
+
+def g_philox_c4_shape():
+    """bench config C4's chain (8 expiries k/8 at 1016 steps a year = 8 x 128 steps, 21 strikes each, BTC-scale forwards) at
+    2^16 paths: the reference's LogSV and Heston chain pricers run on the svmc Philox stream (the oracle materialises the
+    normals, the reference consumes them through its own interfaces).  Kept: prices, standard errors and the first 256 paths'
+    states at every expiry -- a reference-fed fixture at 32 x the paths of logsv_chain_philox.npz / heston.npz."""
+    n, spy, seed, head = 1 << 16, 1016, 20240614, 256
+    ttms, forwards, dfs, strikes, types = c4_shape_chain()
+    etas = np.ones(ttms.size)
+    W0s, W1s, dts, nbs = philox_feed(seed, n, ttms, spy)
+    out = dict(ttms=ttms, forwards=forwards, discfactors=dfs, strikes=np.stack(strikes), types=np.stack(types), seed=seed,
+               spy=spy, n_path=n, nb_steps=np.array(nbs), dts=np.array(dts), logsv_params=params_vec(BTC))
+    for tag, spot in (("spot", True), ("inv", False)):
+        pr, sd, st = run_chain_with_states(BTC, ttms, forwards, dfs, strikes, types, W0s, W1s, dts, etas, spot,
+                                           VariableType.LOG_RETURN)
+        out[f"logsv_prices_{tag}"], out[f"logsv_stderrs_{tag}"] = np.stack(pr), np.stack(sd)
+        out[f"logsv_states_{tag}"] = np.stack([a[:, :head] for a in st])
+    qv_strikes = tuple(np.linspace(0.2, 1.6, 21) for _ in ttms)
+    qv_types = (np.where(qv_strikes[0] >= 0.7, "C", "P"),) * ttms.size
+    pr, sd, _ = run_chain_with_states(BTC, ttms, forwards, dfs, qv_strikes, qv_types, W0s, W1s, dts, etas, True, VariableType.Q_VAR)
+    out["qv_strikes"], out["qv_types"] = np.stack(qv_strikes), np.stack(qv_types)
+    out["logsv_prices_qvar"], out["logsv_stderrs_qvar"] = np.stack(pr), np.stack(sd)
+    # Heston (Euler with the floor: the reference's scheme), its internal np.random.normal fed the same way as g_heston
+    par = dict(v0=0.8, theta=1.0, kappa=2.0, rho=0.0, volvol=2.0)                 # BTC_HESTON_PARAMS
+    base = dict(v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4)
+    # (the reference's Heston chain pricer takes no step count: its 360 steps a year, 8 x 46 steps here)
+    H0s, H1s, hdts, hnbs = philox_feed(seed, n, ttms, 360)
+    out["heston_spy"], out["heston_nb_steps"], out["heston_dts"] = 360, np.array(hnbs), np.array(hdts)
+    for tag, hpar in (("btc", par), ("base", base)):
+        feed = []
+        for a, b in zip(H0s, H1s):
+            feed += [a, b]
+        orig = np.random.normal
+        try:
+            it = iter(feed)
+
+            def feeder(loc, scale, size):
+                a = next(it)
+                assert a.shape == tuple(size)
+                return a
+
+            np.random.normal = feeder
+            pr, sd = hp.heston_mc_chain_pricer(ttms=ttms, forwards=forwards, discfactors=dfs, strikes_ttms=strikes,
+                                               optiontypes_ttms=types, nb_path=n, **hpar)
+            it = iter(feed)
+            xs, vs, qs = np.zeros(n), hpar["v0"] * np.ones(n), np.zeros(n)
+            states, t0 = [], 0.0
+            for ttm in ttms:
+                xs, vs, qs = hp.simulate_heston_x_vol_terminal(ttm=ttm - t0, x0=xs, var0=vs, qvar0=qs, nb_path=n,
+                                                               theta=hpar["theta"], kappa=hpar["kappa"],
+                                                               rho=hpar["rho"], volvol=hpar["volvol"])
+                t0 = ttm
+                states.append(np.stack([xs[:head], vs[:head], qs[:head]]))
+        finally:
+            np.random.normal = orig
+        out[f"heston_params_{tag}"] = np.array([hpar["v0"], hpar["theta"], hpar["kappa"], hpar["rho"], hpar["volvol"]])
+        out[f"heston_prices_{tag}"] = np.stack([np.asarray(a) for a in pr])
+        out[f"heston_stderrs_{tag}"] = np.stack([np.asarray(a) for a in sd])
+        out[f"heston_states_{tag}"] = np.stack(states)
+    save("philox_c4_shape", **out)
+
+
 # -- the reference's own fixed-random test case (tests/test_logsv_characterization.py:346-458) ------
 def g_logsv_reference_test_case():
     nb_path, nb_steps, ttm = 40_000, 91, 0.25
@@ -740,6 +823,7 @@ if __name__ == "__main__":
     g_logsv_zero_noise()
     g_logsv_tiny_chain()
     g_logsv_chain_philox()
+    g_philox_c4_shape()
     g_logsv_reference_test_case()
     g_vol_paths()
     g_heston()

@@ -63,8 +63,8 @@ def test_normals_match_oracle_stream(sv, oracle):
     W0 = eng.download(w0p, nb * n).reshape(nb, n)
     W1 = eng.download(w1p, nb * n).reshape(nb, n)
     O0, O1 = oracle.fill_normals(seed, n, nb, call_id=3, path_offset=123456789012, step_offset=11)
-    np.testing.assert_allclose(W0, O0, rtol=0, atol=1e-13)
-    np.testing.assert_allclose(W1, O1, rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(W0, O0)                   # the stream is DEFINED by the twin's expression: bit for bit
+    np.testing.assert_array_equal(W1, O1)
     eng.close()
 
 
@@ -169,6 +169,46 @@ def test_logsv_chain_philox_vs_reference(sv, oracle, golden, tag, spot, vt):
         from stochvolmodels_amd.engine import get_engine
         x, s, q = get_engine(int(g["n_path"])).get_state()      # terminal state of the last expiry, all paths
         np.testing.assert_allclose(np.stack([x, s, q]), g[f"states_{tag}"][-1], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,spot,vt", [("spot", True, 1), ("inv", False, 1), ("qvar", True, 2)])
+def test_logsv_philox_c4_shape_vs_reference(sv, golden, tag, spot, vt):
+    """the on-device-RNG chain pricer at 2^16 paths on bench config C4's chain (8 x 128 steps, 8 x 21 strikes, BTC-scale forwards)
+    against the REFERENCE's logsv_mc_chain_pricer_fixed_randoms fed the same Philox stream (philox_c4_shape.npz: prices, standard
+    errors, the first 256 paths' terminal states) -- the whole-chain stepping kernel, its slice loop and epilogues, the payoff
+    pass, 32 x the paths of logsv_chain_philox.npz"""
+    g = golden("philox_c4_shape")
+    p = P(g["logsv_params"])
+    strikes, types = (g["qv_strikes"], g["qv_types"]) if tag == "qvar" else (g["strikes"], g["types"])
+    n = int(g["n_path"])
+    pr, sd = sv.logsv_mc_chain_pricer(ttms=g["ttms"], forwards=g["forwards"], discfactors=g["discfactors"], strikes_ttms=tuple(strikes),
+                                      optiontypes_ttms=tuple(types), vol_backbone_etas=np.ones(8), is_spot_measure=spot,
+                                      variable_type=sv.VariableType(vt), nb_path=n, nb_steps_per_year=int(g["spy"]),
+                                      seed=int(g["seed"]), **p)
+    scale = g["forwards"][:, None] if tag != "qvar" else 1.0
+    np.testing.assert_allclose(np.stack(pr), g[f"logsv_prices_{tag}"], rtol=1e-11, atol=0)
+    np.testing.assert_allclose(np.stack(sd) / scale, g[f"logsv_stderrs_{tag}"] / scale, rtol=1e-11, atol=1e-14)
+    if tag != "qvar":
+        from stochvolmodels_amd.engine import get_engine
+        x, s, q = get_engine(n).get_state()
+        np.testing.assert_allclose(np.stack([x[:256], s[:256], q[:256]]), g[f"logsv_states_{tag}"][-1], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["btc", "base"])
+def test_heston_philox_c4_shape_vs_reference(sv, golden, tag):
+    """the same for the reference's heston_mc_chain_pricer (Euler with the floor, 8 x 46 steps) at 2^16 paths"""
+    g = golden("philox_c4_shape")
+    v0, theta, kappa, rho, volvol = (float(a) for a in g[f"heston_params_{tag}"])
+    n = int(g["n_path"])
+    pr, sd = sv.heston_mc_chain_pricer(ttms=g["ttms"], forwards=g["forwards"], discfactors=g["discfactors"],
+                                       strikes_ttms=tuple(g["strikes"]), optiontypes_ttms=tuple(g["types"]), v0=v0, theta=theta,
+                                       kappa=kappa, rho=rho, volvol=volvol, nb_path=n, seed=int(g["seed"]))
+    scale = g["forwards"][:, None]
+    np.testing.assert_allclose(np.stack(pr) / scale, g[f"heston_prices_{tag}"] / scale, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(np.stack(sd) / scale, g[f"heston_stderrs_{tag}"] / scale, rtol=1e-11, atol=1e-14)
+    from stochvolmodels_amd.engine import get_engine
+    x, v, q = get_engine(n).get_state()
+    np.testing.assert_allclose(np.stack([x[:256], v[:256], q[:256]]), g[f"heston_states_{tag}"][-1], rtol=1e-10, atol=1e-12)
 
 
 def test_logsv_reference_test_case(sv, golden):

@@ -187,6 +187,48 @@ def test_logsv_chain_philox(oracle, golden, tag, spot, vt):
         np.testing.assert_array_equal(np.stack([x, s, q]), np.stack(st))
 
 
+@pytest.mark.parametrize("tag,spot,vt", [("spot", True, 1), ("inv", False, 1), ("qvar", True, 2)])
+def test_logsv_philox_c4_shape(oracle, golden, tag, spot, vt):
+    """the reference's LogSV chain pricer fed the svmc Philox stream at 2^16 paths on bench config C4's chain (8 expiries k/8 at
+    1016 steps a year, 21 strikes each; tests/golden/make_golden.py g_philox_c4_shape): the twin's on-the-fly generator on the
+    same (seed, path, step) must give the reference's prices, standard errors and the first 256 paths' states at every expiry"""
+    g = golden("philox_c4_shape")
+    p = P(g["logsv_params"])
+    n, seed = int(g["n_path"]), int(g["seed"])
+    strikes, types = (g["qv_strikes"], g["qv_types"]) if tag == "qvar" else (g["strikes"], g["types"])
+    x, s, q = np.zeros(n), p["sigma0"] * np.ones(n), np.zeros(n)
+    step0 = 0
+    for i, (nb, dt) in enumerate(zip(g["nb_steps"], g["dts"])):
+        x, s, q = oracle.logsv_terminal_rng(x, s, q, int(nb), float(dt), p["theta"], p["kappa1"], p["kappa2"], p["beta"],
+                                            p["volvol"], seed, is_spot_measure=spot, step_offset=step0)
+        step0 += int(nb)
+        pr, sd = oracle.payoff(x, q, float(g["ttms"][i]), float(g["forwards"][i]), strikes[i], types[i], float(g["discfactors"][i]),
+                               variable_type=vt)
+        np.testing.assert_allclose(pr, g[f"logsv_prices_{tag}"][i], rtol=1e-11, atol=1e-13 * float(g["forwards"][i]))
+        np.testing.assert_allclose(sd, g[f"logsv_stderrs_{tag}"][i], rtol=1e-11, atol=1e-13 * float(g["forwards"][i]))
+        if tag != "qvar":
+            np.testing.assert_allclose(np.stack([x[:256], s[:256], q[:256]]), g[f"logsv_states_{tag}"][i], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("tag", ["btc", "base"])
+def test_heston_philox_c4_shape(oracle, golden, tag):
+    """... and the reference's Heston chain pricer (Euler with the floor, its 360 steps a year) on the same stream"""
+    g = golden("philox_c4_shape")
+    v0, theta, kappa, rho, volvol = (float(a) for a in g[f"heston_params_{tag}"])
+    n, seed = int(g["n_path"]), int(g["seed"])
+    x, v, q = np.zeros(n), v0 * np.ones(n), np.zeros(n)
+    step0 = 0
+    for i, (nb, dt) in enumerate(zip(g["heston_nb_steps"], g["heston_dts"])):
+        x, v, q = oracle.heston_terminal_rng(x, v, q, int(nb), float(dt), theta, kappa, rho, volvol, seed,
+                                             scheme=oracle.HESTON_EULER_FLOOR, step_offset=step0)
+        step0 += int(nb)
+        pr, sd = oracle.payoff(x, q, float(g["ttms"][i]), float(g["forwards"][i]), g["strikes"][i], g["types"][i],
+                               float(g["discfactors"][i]))
+        np.testing.assert_allclose(pr, g[f"heston_prices_{tag}"][i], rtol=1e-11, atol=1e-13 * float(g["forwards"][i]))
+        np.testing.assert_allclose(sd, g[f"heston_stderrs_{tag}"][i], rtol=1e-11, atol=1e-13 * float(g["forwards"][i]))
+        np.testing.assert_allclose(np.stack([x[:256], v[:256], q[:256]]), g[f"heston_states_{tag}"][i], rtol=1e-12, atol=1e-14)
+
+
 def test_logsv_reference_test_case(oracle, golden):
     """the reference's own fixed-random case, tests/test_logsv_characterization.py:346-458"""
     g = golden("logsv_reference_test_case")
