@@ -10,6 +10,7 @@
 // This is the path a C/C++ host takes (examples/price_chain.c).  The Python host drives the same kernels through
 // mc_chain.py because it also has to place the two all-reduces of the multi-GPU case between the phases.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "svmc_internal.h"
@@ -58,6 +59,10 @@ struct Session {
                                             // pageable memory costs 16 us more per chain: tools/ubench/sync_latency.py)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // the generators' per-wave spot partials [2 max_expiries][wave_rows(n_path)], apart from `ws` (the payoff launch's block
+    // partials): on one device the payoff kernel reads them while it writes those (one_device_tail)
+    double *spot_ws = nullptr;
+    size_t spot_ws_bytes = 0;
     hipStream_t stream = nullptr;
     bool owns_state = true, owns_stream = true;   // false: svmc_session_create_on -- the caller's state arrays / stream
     // svmc_session_time_stepping: HIP events around the stepping launch (+ its spot-sum reduce) of the on-device-RNG chain
@@ -108,7 +113,8 @@ static void session_release(Session *s)
     if (s->owns_state)
         for (void *p : {static_cast<void *>(s->x), static_cast<void *>(s->vol), static_cast<void *>(s->qvar)})
             if (p != nullptr) (void)hipFree(p);
-    for (void *p : {static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws})
+    for (void *p : {static_cast<void *>(s->snap), static_cast<void *>(s->spot), static_cast<void *>(s->sums), s->ws,
+                    static_cast<void *>(s->spot_ws)})
         if (p != nullptr) (void)hipFree(p);
     if (s->sums_pinned != nullptr) (void)hipHostFree(s->sums_pinned);
     if (s->ev0 != nullptr) (void)hipEventDestroy(s->ev0);
@@ -246,8 +252,57 @@ static int all_reduce(Session *s, double *buf, size_t n)
     return svmc_rccl_all_reduce_sum(s->comm, buf, n, reinterpret_cast<svmc_stream_t>(s->stream));
 }
 
-static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type, double *prices, double *stderrs)
+// The tail of an on-device-RNG chain on ONE device (no communicator): the stepping launch left its per-wave spot partials in
+// s->spot_ws unreduced; the payoff kernel sums them itself (up to 2048 rows; a reduce launch ahead of it otherwise) and
+// chain_finish_kernel, a wave per quote, forms the column sums in reduce_columns_kernel's order (the bits of the five-node tail
+// below) and stores them straight into the pinned host buffer.  Whether a chain takes it: one_device_tail().
+static bool one_device_tail(const Session *s, const ChainView &c)
 {
+    static const bool off = getenv("SVMC_CHAIN_TAIL_NODES") != nullptr && atoi(getenv("SVMC_CHAIN_TAIL_NODES")) == 5;   // A/B, tests
+    return !off && !s->sharded() && c.m <= MAX_FUSED_SLICES &&
+           static_cast<size_t>(wave_rows(s->n_path)) * 2 * static_cast<size_t>(c.m) * sizeof(double) <= s->spot_ws_bytes &&
+           payoff_sets_fit(s->n_path, c.m, c.offsets, c.types, 1, s->ws_bytes);
+}
+
+static void payoff_shifts_of(const ChainView &c, int variable_type, std::vector<double> &shifts)
+{
+    shifts.resize(c.offsets[c.m]);
+    for (int i = 0; i < c.m; ++i)
+        for (size_t k = c.offsets[i]; k < c.offsets[i + 1]; ++k)
+            shifts[k] = payoff_shift(c.strikes[k], c.types[k], c.forwards[i], variable_type);
+}
+
+static int enqueue_one_device_tail(Session *s, const ChainView &c, int variable_type, const std::vector<double> &shifts, double *sums_out)
+{
+    const size_t n = s->n_path;
+    std::vector<const double *> xs(c.m), qs(c.m);
+    for (int i = 0; i < c.m; ++i) {
+        xs[i] = s->snap + static_cast<size_t>(i) * n;
+        qs[i] = s->snap + static_cast<size_t>(c.m + i) * n;
+    }
+    const bool in_kernel = spot_sums_in_payoff_kernel(n);
+    if (!in_kernel)
+        if (int rc = reduce_spot_partials(s->spot_ws, n, 2 * c.m, s->spot, s->stream)) return rc;
+    return chain_payoff_and_finish(xs.data(), variable_type == SVMC_Q_VAR ? qs.data() : nullptr, n, c.forwards, c.ttms, s->spot,
+                                   in_kernel ? s->spot_ws : nullptr, c.m, c.strikes, c.types, shifts.data(), c.offsets, variable_type,
+                                   s->ws, s->ws_bytes, s->stream, sums_out);
+}
+
+// partials_pending: the stepping launch(es) left the per-wave spot partials in s->spot_ws unreduced (the on-device-RNG drivers);
+// false: s->spot already holds this rank's spot sums (the slice-by-slice fixed-randoms route)
+static int reduce_and_finalize(Session *s, const ChainView &c, int variable_type, double *prices, double *stderrs,
+                               bool partials_pending)
+{
+    if (partials_pending && one_device_tail(s, c)) {
+        std::vector<double> shifts;
+        payoff_shifts_of(c, variable_type, shifts);
+        if (int rc = enqueue_one_device_tail(s, c, variable_type, shifts, s->sums_pinned)) return rc;
+        SVMC_HIP_TRY(hipStreamSynchronize(s->stream));
+        stepping_read(s);
+        return finalize_prices(s, c, s->sums_pinned, shifts, prices, stderrs);
+    }
+    if (partials_pending)
+        if (int rc = reduce_spot_partials(s->spot_ws, s->n_path, 2 * c.m, s->spot, s->stream)) return rc;
     if (int rc = all_reduce(s, s->spot, 2 * static_cast<size_t>(c.m))) return rc;
     std::vector<double> shifts;
     if (int rc = enqueue_payoff_sums(s, c, variable_type, shifts)) return rc;
@@ -323,6 +378,8 @@ static int session_create(const char *fn, svmc_session_t *session, size_t n_path
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->spot), 2 * static_cast<size_t>(max_expiries) * sizeof(double));
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->sums), 3 * max_strikes_total * sizeof(double));
     if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(&s->ws, ws);
+    s->spot_ws_bytes = (fused_sets > 2 * sizeof(double)) ? fused_sets : 2 * sizeof(double);
+    if (rc == SVMC_OK && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->spot_ws), s->spot_ws_bytes);
     if (rc == SVMC_OK && e == hipSuccess)
         e = hipHostMalloc(reinterpret_cast<void **>(&s->sums_pinned), 3 * max_strikes_total * sizeof(double), hipHostMallocDefault);
     if (rc != SVMC_OK || e != hipSuccess) {
@@ -424,24 +481,24 @@ int svmc_logsv_chain_price(svmc_session_t session, const double *ttms_host, cons
         time_grid(c.ttms[i] - t0, nb_steps_per_year, nbs[i], dts[i]);
         t0 = c.ttms[i];
     }
+    // the stepping launch (a single expiry: the plain slice kernel -- the same bits, and the one bench.py profiles); its per-wave
+    // spot partials stay in s->spot_ws, reduce_and_finalize decides who sums them
+    double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
     stepping_begin(s);
-    if (c.m == 1) {       // a single expiry: the plain slice kernel (same bits, and the one bench.py profiles)
-        if (int rc = svmc_logsv_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa1, kappa2, beta, volvol,
-                                          vol_backbone_etas_host ? vol_backbone_etas_host[0] : 1.0, is_spot_measure, seed,
-                                          call_id, s->path_offset, 0, c.forwards[0], s->snap,
-                                          (variable_type == SVMC_Q_VAR) ? s->snap + n : nullptr, s->spot, s->ws, s->ws_bytes,
-                                          s->stream))
+    if (c.m > MAX_FUSED_SLICES) {          // more expiries than one stepping launch takes: launch by launch, each reducing its own
+        if (int rc = svmc_logsv_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
+                                               c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
+                                               s->path_offset, 0, s->snap, qsnap, s->spot, s->ws, s->ws_bytes, s->stream))
             return rc;
         stepping_end(s);
-        return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+        return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host, false);
     }
-    if (int rc = svmc_logsv_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host,
-                                      c.forwards, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
-                                      s->path_offset, 0, s->snap, (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr,
-                                      s->spot, s->ws, s->ws_bytes, s->stream))
+    if (int rc = logsv_step_partials(v0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), vol_backbone_etas_host, c.forwards, theta,
+                                     kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id, s->path_offset, s->snap, qsnap,
+                                     s->spot_ws, s->spot_ws_bytes, s->stream))
         return rc;
     stepping_end(s);
-    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host, true);
 }
 
 int svmc_logsv_chain_price_fixed(svmc_session_t session, const double *ttms_host, const double *forwards_host,
@@ -600,7 +657,7 @@ int svmc_logsv_chain_price_fixed_iv(svmc_session_t session, const double *ttms_h
                                         s->stream))
             return rc;
     }
-    if (int rc = reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host)) return rc;
+    if (int rc = reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host, false)) return rc;
     if (ivols_host != nullptr) implied_vols_on_host(c, variable_type, prices_host, ivols_host);
     return SVMC_OK;
 }
@@ -935,18 +992,19 @@ int svmc_heston_chain_price(svmc_session_t session, const double *ttms_host, con
     }
     double *qsnap = (variable_type == SVMC_Q_VAR) ? s->snap + static_cast<size_t>(c.m) * n : nullptr;
     stepping_begin(s);
-    if (c.m == 1) {
-        if (int rc = svmc_heston_slice_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, nbs[0], dts[0], theta, kappa, rho, volvol, scheme, seed,
-                                           call_id, s->path_offset, 0, c.forwards[0], s->snap, qsnap, s->spot, s->ws, s->ws_bytes,
-                                           s->stream))
+    if (c.m > MAX_FUSED_SLICES) {
+        if (int rc = svmc_heston_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
+                                                rho, volvol, scheme, seed, call_id, s->path_offset, 0, s->snap, qsnap, s->spot, s->ws,
+                                                s->ws_bytes, s->stream))
             return rc;
-    } else if (int rc = svmc_heston_chain_rng_from(0.0, v0, 0.0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa,
-                                              rho, volvol, scheme, seed, call_id, s->path_offset, 0, s->snap, qsnap, s->spot, s->ws,
-                                              s->ws_bytes, s->stream)) {
-        return rc;
+        stepping_end(s);
+        return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host, false);
     }
+    if (int rc = heston_step_partials(v0, s->x, s->vol, s->qvar, n, c.m, nbs.data(), dts.data(), c.forwards, theta, kappa, rho, volvol, scheme,
+                                      seed, call_id, s->path_offset, s->snap, qsnap, s->spot_ws, s->spot_ws_bytes, s->stream))
+        return rc;
     stepping_end(s);
-    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host);
+    return reduce_and_finalize(s, c, variable_type, prices_host, stderrs_host, true);
 }
 
 int svmc_session_state(svmc_session_t session, double *x_host, double *vol_host, double *qvar_host)

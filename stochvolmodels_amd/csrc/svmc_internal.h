@@ -64,6 +64,25 @@ int payoff_sums_chain_sets(const double *const *x_snapshots_host, const double *
                            const size_t *strike_offsets_host, int variable_type, double *sums, void *workspace,
                            size_t workspace_bytes, hipStream_t stream, int n_sets, size_t x_set_stride, size_t q_set_stride,
                            size_t spot_set_stride);
+// ---- the one-device tail of an on-device-RNG chain (round 6): stepping WITHOUT the reduce of its per-wave spot partials, then the
+// payoff kernel (up to 2048 partial rows: every block sums its expiry's two columns itself) and chain_finish_kernel (a wave per
+// quote: column sums in reduce_columns_kernel's order, stored where the host reads them)
+int logsv_step_partials(double sigma0, double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                        const double *dts_host, const double *etas_host, const double *forwards_host, double theta, double kappa1,
+                        double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                        uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace, size_t workspace_bytes,
+                        hipStream_t stream);
+int heston_step_partials(double var0, double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                         const double *dts_host, const double *forwards_host, double theta, double kappa, double rho, double volvol,
+                         int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset, double *x_snapshots,
+                         double *qvar_snapshots, void *workspace, size_t workspace_bytes, hipStream_t stream);
+bool spot_sums_in_payoff_kernel(size_t n_path);
+int reduce_spot_partials(const void *workspace, size_t n_path, int n_cols, double *spot_sums, hipStream_t stream);
+int chain_payoff_and_finish(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
+                            const double *forwards_host, const double *ttms_host, double *spot_sums, const double *spot_partials,
+                            int n_expiries, const double *strikes_host, const int8_t *types_host, const double *shifts_host,
+                            const size_t *strike_offsets_host, int variable_type, void *workspace, size_t workspace_bytes,
+                            hipStream_t stream, double *sums_out);
 constexpr int IV_QUOTE_DOUBLES_HOST = 6;   // = IV_QUOTE_DOUBLES of svmc_kernels.hip: {strike, code, shift, forward, ttm, df}
 // ivols_out and sums_copy (nullable: the kernel also stores the 3 x n_quotes sums it read) may be device-visible pinned host
 // memory: the results of a graph then reach the host without copy nodes

@@ -191,6 +191,110 @@ __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *lds /* 
     block_sum_apply<NV>(v, lds, n_out, [&](int j, double t) { out[j] = t; });
 }
 
+// The sum of one column, the ONE order of additions every column reduction of the library uses (so that a sum does not depend on
+// which kernel formed it).  256 (virtual) threads: thread t adds rows t, t + 256, ... into four accumulators -- sixteen rows at a
+// time into a[k mod 4] while sixteen remain, then four at a time into a[0..3], then the last three or fewer into a[0] --, forms
+// (a0 + a1) + (a2 + a3), each wave adds its 64 lanes in a fixed shuffle tree and the four wave totals are added in wave order.
+// A row is one 8-byte read at a stride of ld -- latency, not bandwidth: what a reduction costs is how many DEPENDENT round trips
+// it makes, so the loads are batched (sixteen per trip in the long loop; a column of up to NR x 256 rows has ALL its loads in
+// flight before the first addition -- round 6: the spot columns of a 10^5-path launch were 1 + 3 dependent round trips, 4.7 us of
+// a 5 us kernel) and the additions keep the order above: the same bits whichever route.
+template <int NR>
+__device__ __forceinline__ void column_rows_load(const double *__restrict__ partials, unsigned r, unsigned n_rows, size_t ld, double (&t)[NR])
+{
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const unsigned rk = r + static_cast<unsigned>(k) * BLOCK;
+        t[k] = (rk < n_rows) ? partials[static_cast<size_t>(rk) * ld] : 0.0;
+    }
+}
+// ... for n_rows <= NR x 256 (NR = 4 or 8: the sixteen-row loop never runs): the additions of the loops, on the preloaded rows
+template <int NR>
+__device__ __forceinline__ double column_rows_add(const double (&t)[NR], unsigned r, unsigned n_rows)
+{
+    static_assert(NR == 4 || NR == 8, "one or two trips of the four-row loop");
+    const unsigned cnt = (n_rows > r) ? (n_rows - r + BLOCK - 1) / BLOCK : 0u;        // rows of this thread
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    unsigned k = 0;
+    if (cnt >= 4u) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += t[u];
+        k = 4;
+        if constexpr (NR == 8) {
+            if (cnt >= 8u) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] += t[4 + u];
+                k = 8;
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NR; ++kk)
+        if (static_cast<unsigned>(kk) >= k && static_cast<unsigned>(kk) < cnt) a[0] += t[kk];
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+// any n_rows: the loops themselves
+__device__ __forceinline__ double column_rows_sum(const double *__restrict__ partials, unsigned r, unsigned n_rows, size_t ld)
+{
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; r + 15 * BLOCK < n_rows; r += 16 * BLOCK) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += t[4 * k + u];
+        }
+    }
+    for (; r + 3 * BLOCK < n_rows; r += 4 * BLOCK) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += t[u];
+    }
+    for (; r < n_rows; r += BLOCK) a[0] += partials[static_cast<size_t>(r) * ld];
+    return (a[0] + a[1]) + (a[2] + a[3]);
+}
+
+// by a 256-thread block: every thread calls; thread 0 returns the total (the others a partial)
+__device__ __forceinline__ double block_column_sum(const double *__restrict__ partials, unsigned n_rows, size_t ld, double *lds /* [4] */)
+{
+    double v[1];
+    if (n_rows <= 8u * BLOCK) {                             // (block-uniform)
+        double t[8];
+        column_rows_load<8>(partials, threadIdx.x, n_rows, ld, t);
+        v[0] = column_rows_add<8>(t, threadIdx.x, n_rows);
+    } else {
+        v[0] = column_rows_sum(partials, threadIdx.x, n_rows, ld);
+    }
+    double total = 0.0;
+    block_sum_apply<1>(v, lds, 1, [&](int, double t) { total = t; });
+    return total;
+}
+
+// two columns by one block with the loads of BOTH in flight together (the payoff kernel's spot sums: [sum F exp(x), count])
+__device__ __forceinline__ void block_column_sum2(const double *__restrict__ p0, const double *__restrict__ p1, unsigned n_rows, double *lds,
+                                                  double &s0, double &s1)
+{
+    double v0[1], v1[1];
+    if (n_rows <= 8u * BLOCK) {
+        double t0[8], t1[8];
+        column_rows_load<8>(p0, threadIdx.x, n_rows, 1, t0);
+        column_rows_load<8>(p1, threadIdx.x, n_rows, 1, t1);
+        v0[0] = column_rows_add<8>(t0, threadIdx.x, n_rows);
+        v1[0] = column_rows_add<8>(t1, threadIdx.x, n_rows);
+    } else {
+        v0[0] = column_rows_sum(p0, threadIdx.x, n_rows, 1);
+        v1[0] = column_rows_sum(p1, threadIdx.x, n_rows, 1);
+    }
+    s0 = s1 = 0.0;
+    block_sum_apply<1>(v0, lds, 1, [&](int, double t) { s0 = t; });
+    __syncthreads();                                        // thread 0 has read the wave totals: lds may be written again
+    block_sum_apply<1>(v1, lds, 1, [&](int, double t) { s1 = t; });
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LogSV generators (pricers/logsv_pricer.py:950-1047)
 // ---------------------------------------------------------------------------------------------------
@@ -859,6 +963,9 @@ constexpr int LOGSV_FAST_DOUBLES = static_cast<int>(sizeof(LogsvFast) / sizeof(d
 //   * the (slice, set) constants are plain loads from the block's LDS copy: loop-invariant, the compiler keeps them in
 //     registers across the time loop where the budget allows and re-reads them where it does not.
 // The launch shape (block size, one block per CU) was measured NOT to matter: the dispatcher spreads 391 blocks evenly.
+#ifndef SVMC_FROZEN_DRAW_DEFAULT
+#define SVMC_FROZEN_DRAW_DEFAULT(P) 4      // which form of the draw the P-set kernel compiles (see the comment in its time loop)
+#endif
 template <int P>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFast *__restrict__ consts,
@@ -921,7 +1028,20 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
             ke[s] = s_c[s].es;
         }
         const auto step = [&](double z0, double z1) { logsv_step_acc_sets<P>(k1, k2, k3, kb, ke, xacc, L, sg, acc, z0, z1, s_exp); };
-        if (nb > 0) {
+#ifdef SVMC_FROZEN_DRAW
+        constexpr int DRAW = SVMC_FROZEN_DRAW;
+#else
+        constexpr int DRAW = SVMC_FROZEN_DRAW_DEFAULT(P);
+#endif
+        if constexpr (DRAW == 4) {
+            // round 6: the generators' pipelined loop -- the step in two halves around its P exp-table reads, the next pair's
+            // cubics, the next Philox call and the issue of the pair after that between them (rng_time_loop_pipelined)
+            LogsvSetsInFlight<P> h;
+            rng_time_loop_pipelined(
+                lane, tg, nb, tab,
+                [&](double z0, double z1) { logsv_step_acc_sets_front<P>(k1, k2, k3, kb, ke, xacc, L, sg, z0, z1, s_exp, h); },
+                [&]() { logsv_step_acc_sets_back<P>(sg, acc, h); });
+        } else if (nb > 0) {
             // rng_time_loop's rule -- call c serves the steps 2c (words 0, 1) and 2c + 1 (words 2, 3) -- as an odd-start half
             // call, the full calls, an even-end half call
             const uint32_t first = tg, last = tg + static_cast<uint32_t>(nb) - 1u;
@@ -942,12 +1062,9 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
             //      round trip hides behind the steps (it does not depend on the state); the last trip draws a call nobody
             //      uses rather than branch inside the trip (with the branch, form 2, the trip is 8 us slower than form 0):
             //      0.175 / 0.410.
-            // One set runs form 1, several run form 3 (SVMC_FROZEN_DRAW forces one form: tools/ubench A/B builds).
-#ifdef SVMC_FROZEN_DRAW
-            constexpr int DRAW = SVMC_FROZEN_DRAW;
-#else
-            constexpr int DRAW = (P == 1) ? 1 : 3;
-#endif
+            //   4  (round 6) the step itself in two halves around its exp-table reads with the draw's pieces between them:
+            //      see above.
+            // SVMC_FROZEN_DRAW forces one form (tools/ubench A/B builds); round 5 ran form 1 for one set, form 3 for several.
             const uint32_t c_end = (last + 1u) >> 1;
             if constexpr (DRAW == 0) {
                 for (; c < c_end; ++c) {
@@ -1720,6 +1837,10 @@ struct PayoffGroup {
     uint32_t put_mask;         // bit k set: put, sg = -1; clear: call, sg = +1: pay = max(fma(sg, u, c), 0)
     int k;                     // live strikes in this group
     int col;                   // first output column of the group within this launch (in strikes)
+    // round 6: the expiry's spot sums formed IN this kernel from the generators' per-wave partial columns (column 0 at
+    // spot_partials, column 1 spot_rows further on) instead of by a reduce launch ahead of it; null: read spot_sums
+    const double *spot_partials;
+    unsigned spot_rows;
 };
 struct PayoffGroupPack {
     PayoffGroup g[PAYOFF_GROUPS];
@@ -1728,6 +1849,7 @@ struct PayoffGroupPack {
 // output rows lie at fixed distances, and blockIdx.z picks the set: doubles between consecutive sets (zeros for one set)
 struct PayoffSetStrides {
     size_t x, q, spot;
+    size_t spot_partials = 0;  // doubles between consecutive sets' partial columns (PayoffGroup::spot_partials)
 };
 static_assert(sizeof(PayoffGroupPack) + sizeof(PayoffSetStrides) + 64 <= 4096, "the payoff descriptors travel in the kernel arguments");
 
@@ -1756,9 +1878,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
     const size_t set = blockIdx.z;                          // parameter set (one launch prices gridDim.z of them)
     const double *__restrict__ x = d.x + set * sets.x;
     const double *__restrict__ qvar = NEED_Q ? d.qvar + set * sets.q : nullptr;
-    const double *__restrict__ spot_sums = d.spot_sums + set * sets.spot;
     const double forward = d.forward, inv_ttm_arg = d.ttm;
-    const double corr = spot_sums[0] / spot_sums[1] - forward;                                  // :62
+    double spot0, spot1;
+    if (d.spot_partials != nullptr) {                       // (block-uniform)
+        // [sum F exp(x), count] of this expiry from the generators' per-wave rows, in block_column_sum's order: the bits of
+        // reduce_columns_kernel, formed by every block for itself (a few rows per thread out of L2) instead of by a launch
+        __shared__ double s_spot[2];
+        const double *__restrict__ sp = d.spot_partials + set * sets.spot_partials;
+        double t0, t1;
+        block_column_sum2(sp, sp + d.spot_rows, d.spot_rows, lds, t0, t1);
+        if (threadIdx.x == 0) {
+            s_spot[0] = t0;
+            s_spot[1] = t1;
+            if (blockIdx.x == 0 && d.spot_sums != nullptr) {        // ... and left where a separate reduce would have put them
+                double *out = const_cast<double *>(d.spot_sums) + set * sets.spot;
+                out[0] = t0;
+                out[1] = t1;
+            }
+        }
+        __syncthreads();
+        spot0 = s_spot[0];
+        spot1 = s_spot[1];
+    } else {
+        const double *__restrict__ spot_sums = d.spot_sums + set * sets.spot;
+        spot0 = spot_sums[0];
+        spot1 = spot_sums[1];
+    }
+    const double corr = spot0 / spot1 - forward;                                                // :62
     const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
     const int nk = d.k;
     const uint32_t inv_mask = d.inv_mask;
@@ -1846,34 +1992,8 @@ __global__ __launch_bounds__(BLOCK) void reduce_columns_kernel(const double *__r
 {
     __shared__ double lds[4];
     const int j = blockIdx.x;
-    const double *__restrict__ partials = partials_base + static_cast<size_t>(j) * col_stride;
-    const size_t ld = row_stride;
-    // four rows per trip into four accumulators; fixed order of additions, hence deterministic.  A row is one 8-byte read
-    // at a stride of ld -- latency, not bandwidth -- so the loads of FOUR trips are put in flight together where that many
-    // remain (the whole-chain generators leave 2^15 rows: 32 round trips per thread became 8, 35 us became ~10); the
-    // additions keep the order of the one-trip loop, so the sums are the same bits
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    unsigned r = threadIdx.x;
-    for (; r + 15 * BLOCK < n_rows; r += 16 * BLOCK) {
-        double t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] += t[4 * k + u];
-        }
-    }
-    for (; r + 3 * BLOCK < n_rows; r += 4 * BLOCK) {
-        double t[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = partials[static_cast<size_t>(r + u * BLOCK) * ld];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] += t[u];
-    }
-    for (; r < n_rows; r += BLOCK) a[0] += partials[static_cast<size_t>(r) * ld];
-    double v[1] = {(a[0] + a[1]) + (a[2] + a[3])};
-    block_sum_store<1>(v, lds, out + j, 1);
+    const double t = block_column_sum(partials_base + static_cast<size_t>(j) * col_stride, n_rows, row_stride, lds);
+    if (threadIdx.x == 0) out[j] = t;
 }
 
 static inline unsigned reduce_grid(size_t n)
@@ -1967,10 +2087,13 @@ static int finish_slice_sums(const char *fn, unsigned block_rows, double *spot_s
     return check_launch(fn);
 }
 
+// allow_null_spot (the two on-device-RNG slice launchers, for their internal callers only -- the public entry points reject a null
+// spot_sums first): with spot_sums == nullptr the launch leaves its per-wave partial columns in the workspace unreduced, and the
+// payoff kernel of svmc_chain.hip's one-device tail sums them itself
 static int check_slice_args(const char *fn, size_t n_path, const double *x_snapshot, const double *spot_sums,
-                            const void *workspace, size_t workspace_bytes)
+                            const void *workspace, size_t workspace_bytes, bool allow_null_spot = false)
 {
-    if (x_snapshot == nullptr || spot_sums == nullptr || workspace == nullptr)
+    if (x_snapshot == nullptr || (spot_sums == nullptr && !allow_null_spot) || workspace == nullptr)
         return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": null snapshot / spot_sums / workspace");
     if (workspace_bytes < static_cast<size_t>(wave_rows(n_path)) * 2 * sizeof(double))
         return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": workspace too small (svmc_slice_workspace_bytes)");
@@ -1996,12 +2119,13 @@ static int logsv_slice_rng_impl(const char *fn, const StateInit &init, double *x
                          uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
                          double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
-    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes, true)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
     const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = logsv_rng_launch(fn, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2, beta, volvol,
                                   vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset, so, stream, init))
         return rc;
+    if (spot_sums == nullptr) return SVMC_OK;
     return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
@@ -2013,6 +2137,7 @@ int svmc_logsv_slice_rng(double *x, double *sigma, double *qvar, size_t n_path, 
                          uint32_t step_offset, double forward, double *x_snapshot, double *qvar_snapshot,
                          double *spot_sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_logsv_slice_rng: null spot_sums");
     return logsv_slice_rng_impl("svmc_logsv_slice_rng", StateInit(), x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2,
                                 beta, volvol, vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset,
                                 forward, x_snapshot, qvar_snapshot, spot_sums, workspace, workspace_bytes, stream);
@@ -2025,6 +2150,7 @@ int svmc_logsv_slice_rng_from(double x0, double sigma0, double qvar0, double *x,
                               double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
                               svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_logsv_slice_rng_from: null spot_sums");
     const StateInit init = {1, x0, sigma0, qvar0};
     return logsv_slice_rng_impl("svmc_logsv_slice_rng_from", init, x, sigma, qvar, n_path, nb_steps, dt, theta, kappa1, kappa2,
                                 beta, volvol, vol_backbone_eta, is_spot_measure, seed, call_id, path_offset, step_offset,
@@ -2040,8 +2166,9 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
                          double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
                          svmc_stream_t stream)
 {
-    SVMC_REQUIRE(x && sigma && qvar && x_snapshots && spot_sums && workspace, std::string(fn) + ": null pointer");
+    SVMC_REQUIRE(x && sigma && qvar && x_snapshots && workspace, std::string(fn) + ": null pointer");
     SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, std::string(fn) + ": null grids / no slices");
+    SVMC_REQUIRE(spot_sums != nullptr || n_slices <= MAX_CHAIN_SLICES, std::string(fn) + ": unreduced partials need one launch");
     SVMC_REQUIRE(call_id < (1u << 24), std::string(fn) + ": call_id must fit 24 bits");
     SVMC_REQUIRE(n_path > 0, std::string(fn) + ": n_path must be positive");
     for (int i = 0; i < n_slices; ++i)
@@ -2071,8 +2198,9 @@ static int logsv_chain_rng_impl(const char *fn, const StateInit &init, double *x
             hipLaunchKernelGGL(logsv_chain_rng_kernel, dim3(g), dim3(CHAIN_BLOCK), 0, as_stream(stream), x, sigma, qvar, n_path,
                                cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, static_cast<double *>(workspace),
                                (i0 == 0) ? init : StateInit(), armed_probe());
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
+        if (spot_sums != nullptr)
+            hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
+                               static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(cs.total_steps);
     }
@@ -2088,6 +2216,7 @@ int svmc_logsv_chain_rng(double *x, double *sigma, double *qvar, size_t n_path, 
                          double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
                          svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_logsv_chain_rng: null spot_sums");
     return logsv_chain_rng_impl("svmc_logsv_chain_rng", StateInit(), x, sigma, qvar, n_path, n_slices, nb_steps_host, dts_host,
                                 etas_host, forwards_host, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
                                 path_offset, step_offset, x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes,
@@ -2101,6 +2230,7 @@ int svmc_logsv_chain_rng_from(double x0, double sigma0, double qvar0, double *x,
                               uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
                               void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_logsv_chain_rng_from: null spot_sums");
     const StateInit init = {1, x0, sigma0, qvar0};
     return logsv_chain_rng_impl("svmc_logsv_chain_rng_from", init, x, sigma, qvar, n_path, n_slices, nb_steps_host, dts_host,
                                 etas_host, forwards_host, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id,
@@ -2313,8 +2443,9 @@ int logsv_chain_rng_sets(size_t n_path, int n_sets, int n_slices, const int *nb_
         break;
     }
 #undef SVMC_RNG_SETS_CASE
-    hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
-                       wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
+    if (spot_sums != nullptr)                  // (null: the caller's payoff kernel sums the partial columns itself)
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(cols), dim3(BLOCK), 0, stream, static_cast<const double *>(workspace),
+                           wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums);
     return check_launch(fn);
 }
 
@@ -2537,12 +2668,13 @@ static int heston_slice_rng_impl(const char *fn, const StateInit &init, double *
                           double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
                           svmc_stream_t stream)
 {
-    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes)) return rc;
+    if (int rc = check_slice_args(fn, n_path, x_snapshot, spot_sums, workspace, workspace_bytes, true)) return rc;
     SVMC_REQUIRE(n_path > 0 && nb_steps > 0, std::string(fn) + ": n_path and nb_steps must be positive");
     const SliceOut so = {x_snapshot, qvar_snapshot, static_cast<double *>(workspace), forward, wave_rows(n_path)};
     if (int rc = heston_rng_launch(fn, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed,
                                    call_id, path_offset, step_offset, so, stream, init))
         return rc;
+    if (spot_sums == nullptr) return SVMC_OK;
     return finish_slice_sums(fn, wave_rows(n_path), spot_sums, workspace, stream);
 }
 
@@ -2554,6 +2686,7 @@ int svmc_heston_slice_rng(double *x, double *var, double *qvar, size_t n_path, i
                           double *qvar_snapshot, double *spot_sums, void *workspace, size_t workspace_bytes,
                           svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_heston_slice_rng: null spot_sums");
     return heston_slice_rng_impl("svmc_heston_slice_rng", StateInit(), x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho,
                                  volvol, scheme, seed, call_id, path_offset, step_offset, forward, x_snapshot, qvar_snapshot,
                                  spot_sums, workspace, workspace_bytes, stream);
@@ -2565,6 +2698,7 @@ int svmc_heston_slice_rng_from(double x0, double var0, double qvar0, double *x, 
                                double *x_snapshot, double *qvar_snapshot, double *spot_sums, void *workspace,
                                size_t workspace_bytes, svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_heston_slice_rng_from: null spot_sums");
     const StateInit init = {1, x0, var0, qvar0};
     return heston_slice_rng_impl("svmc_heston_slice_rng_from", init, x, var, qvar, n_path, nb_steps, dt, theta, kappa, rho,
                                  volvol, scheme, seed, call_id, path_offset, step_offset, forward, x_snapshot, qvar_snapshot,
@@ -2579,8 +2713,9 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
                           uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
                           void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
-    SVMC_REQUIRE(x && var && qvar && x_snapshots && spot_sums && workspace, std::string(fn) + ": null pointer");
+    SVMC_REQUIRE(x && var && qvar && x_snapshots && workspace, std::string(fn) + ": null pointer");
     SVMC_REQUIRE(nb_steps_host && dts_host && forwards_host && n_slices >= 1, std::string(fn) + ": null grids / no slices");
+    SVMC_REQUIRE(spot_sums != nullptr || n_slices <= MAX_CHAIN_SLICES, std::string(fn) + ": unreduced partials need one launch");
     SVMC_REQUIRE(scheme == SVMC_HESTON_EULER_FLOOR || scheme == SVMC_HESTON_QE, std::string(fn) + ": unknown scheme");
     SVMC_REQUIRE(call_id < (1u << 24), std::string(fn) + ": call_id must fit 24 bits");
     SVMC_REQUIRE(n_path > 0, std::string(fn) + ": n_path must be positive");
@@ -2623,8 +2758,9 @@ static int heston_chain_rng_impl(const char *fn, const StateInit &init, double *
         else
             hipLaunchKernelGGL(heston_chain_rng_kernel<SVMC_HESTON_EULER_FLOOR>, dim3(g), dim3(rng_block()), 0, as_stream(stream), x, var,
                                qvar, n_path, cs, seed, make_c3(call_id), path_offset, step_offset, xs, qs, ws, init_i);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
-                           static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
+        if (spot_sums != nullptr)
+            hipLaunchKernelGGL(reduce_columns_kernel, dim3(2 * cs.m), dim3(BLOCK), 0, as_stream(stream),
+                               static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)), spot_sums + 2 * i0);
         if (int rc = check_launch(fn)) return rc;
         step_offset += static_cast<uint32_t>(steps);
     }
@@ -2639,6 +2775,7 @@ int svmc_heston_chain_rng(double *x, double *var, double *qvar, size_t n_path, i
                           uint32_t step_offset, double *x_snapshots, double *qvar_snapshots, double *spot_sums,
                           void *workspace, size_t workspace_bytes, svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_heston_chain_rng: null spot_sums");
     return heston_chain_rng_impl("svmc_heston_chain_rng", StateInit(), x, var, qvar, n_path, n_slices, nb_steps_host, dts_host,
                                  forwards_host, theta, kappa, rho, volvol, scheme, seed, call_id, path_offset, step_offset,
                                  x_snapshots, qvar_snapshots, spot_sums, workspace, workspace_bytes, stream);
@@ -2651,6 +2788,7 @@ int svmc_heston_chain_rng_from(double x0, double var0, double qvar0, double *x, 
                                double *qvar_snapshots, double *spot_sums, void *workspace, size_t workspace_bytes,
                                svmc_stream_t stream)
 {
+    SVMC_REQUIRE(spot_sums != nullptr, "svmc_heston_chain_rng_from: null spot_sums");
     const StateInit init = {1, x0, var0, qvar0};
     return heston_chain_rng_impl("svmc_heston_chain_rng_from", init, x, var, qvar, n_path, n_slices, nb_steps_host, dts_host,
                                  forwards_host, theta, kappa, rho, volvol, scheme, seed, call_id, path_offset, step_offset,
@@ -2930,11 +3068,21 @@ static void launch_payoff_groups(int kt, dim3 grid, hipStream_t st, const Payoff
     hipLaunchKernelGGL(kern, grid, dim3(BLOCK), 0, st, pack, n, partials, ld, sets);
 }
 
+// spot_partials != null: the expiries' spot sums are formed inside the payoff kernel from the generators' per-wave partial columns
+// (expiry i's pair 2 spot_rows i doubles in; sets.spot_partials between sets) -- no reduce launch ahead of this one, and
+// spot_sums (nullable then) is only written.  partials_out != null: NO column reduce either -- the chain must fit one launch
+// (payoff_sets_fit) and the caller ends it with chain_finish (one wave per quote: the column sums, the prices' implied vols,
+// everything stored where the host reads it).
+struct PayoffPartialsOut {
+    unsigned rows = 0;      // path blocks of the launch = rows of the partials
+    int cols = 0;           // strike columns per set
+};
 static int payoff_sums_impl(const char *fn, const double *const *xs, const double *const *qs, size_t n_path,
                             const double *forwards, const double *ttms, const double *spot_sums, int n_expiries,
                             const double *strikes, const int8_t *types, const double *shifts, const size_t *offsets,
                             int variable_type, double *sums, void *workspace, size_t workspace_bytes, svmc_stream_t stream,
-                            int n_sets = 1, const PayoffSetStrides &sets = PayoffSetStrides{0, 0, 0})
+                            int n_sets = 1, const PayoffSetStrides &sets = PayoffSetStrides{0, 0, 0},
+                            const double *spot_partials = nullptr, unsigned spot_rows = 0, PayoffPartialsOut *partials_out = nullptr)
 {
     // n_sets > 1: xs / qs / spot_sums / sums are those of set 0 and the others lie `sets` (and 3 x total sums) further on; the
     // chain must then fit ONE launch (payoff_sets_fit), whose path blocks are those of a one-set launch -- the same partial
@@ -2966,12 +3114,19 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
         if (n_sets > 1 && (first_strike != 0 || static_cast<size_t>(cols) != total ||
                            static_cast<size_t>(gx) * n_sets * 3 * cols * sizeof(double) > workspace_bytes))
             return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": the parameter sets do not fit one payoff launch");
+        if (partials_out != nullptr && (first_strike != 0 || static_cast<size_t>(cols) != total))
+            return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": the chain does not fit one payoff launch");
         if (has_inv)
             launch_payoff_groups<true>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols, sets);
         else
             launch_payoff_groups<false>(kt, grid, as_stream(stream), pack, n_path, variable_type, partials, 3 * cols, sets);
-        hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols * n_sets), dim3(BLOCK), 0, as_stream(stream), partials,
-                           static_cast<unsigned>(gx), static_cast<size_t>(3 * cols) * n_sets, size_t(1), sums + 3 * first_strike);
+        if (partials_out != nullptr) {
+            partials_out->rows = gx;
+            partials_out->cols = cols;
+        } else {
+            hipLaunchKernelGGL(reduce_columns_kernel, dim3(3 * cols * n_sets), dim3(BLOCK), 0, as_stream(stream), partials,
+                               static_cast<unsigned>(gx), static_cast<size_t>(3 * cols) * n_sets, size_t(1), sums + 3 * first_strike);
+        }
         first_strike += static_cast<size_t>(cols);
         n_groups = cols = kt = 0;
         has_inv = false;
@@ -2983,7 +3138,9 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
             PayoffGroup &d = pack.g[n_groups];
             d.x = xs[i];
             d.qvar = (variable_type == SVMC_Q_VAR) ? qs[i] : nullptr;
-            d.spot_sums = spot_sums + 2 * i;
+            d.spot_sums = spot_sums ? spot_sums + 2 * i : nullptr;
+            d.spot_partials = spot_partials ? spot_partials + 2 * static_cast<size_t>(spot_rows) * i : nullptr;
+            d.spot_rows = spot_rows;
             d.forward = forwards[i];
             d.ttm = ttms[i];
             const size_t left = offsets[i + 1] - k0;
@@ -3041,6 +3198,119 @@ int payoff_sums_chain_sets(const double *const *x_snapshots_host, const double *
                             spot_sums, n_expiries, strikes_host, types_host, shifts_host, strike_offsets_host, variable_type, sums,
                             workspace, workspace_bytes, reinterpret_cast<svmc_stream_t>(stream), n_sets,
                             PayoffSetStrides{x_set_stride, q_set_stride, spot_set_stride});
+}
+
+// The tail of an on-device-RNG chain on ONE device (svmc_chain.hip, round 6): (1) the payoff launch -- with spot_partials, every
+// block forms its expiry's spot sums itself from the generators' per-wave partial columns ([expiry][2][spot_rows]: one batched
+// round trip of loads for up to 2048 rows), without, it reads spot_sums as ever; (2) chain_finish_kernel, a wave per quote: the
+// three column sums of the quote in reduce_columns_kernel's order of additions (the same bits), stored at sums_out -- the
+// caller's pinned host buffer: no copy node.  Measured (tools/r06/chain_call_breakdown.py, 4 x 13 chain): reduce 4.8 + payoff 5.0 +
+// reduce 4.9 + copy 4.3 us at 2^16 paths became payoff 7.5 + finish 4.4.  What was measured and NOT kept: the spot sums inside
+// the payoff kernel above 2048 rows (every block repeats two or three dependent round trips: payoff 10.2 -> 17.9 us at 2 x 10^5
+// paths, more than the reduce launch it saves), the same tail for the calibration objective's parameter sets (payoff of seven
+// sets 19 -> 31 us), and the implied vols inside the finish kernel (one lane of 52 waves on 13 CUs: 24.6 us against 5.0 + 12.2
+// for reduce + chain_implied_vols_kernel, whose one wave inverts 64 quotes side by side) -- profiles/r06_frozen_trace.txt.
+// The chain must fit one payoff launch (payoff_sets_fit).
+__global__ __launch_bounds__(BLOCK) void chain_finish_kernel(const double *__restrict__ partials, unsigned n_rows, int cols,
+                                                             double *__restrict__ sums_out)
+{
+    const size_t q = static_cast<size_t>(blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6);        // this wave's quote
+    if (q >= static_cast<size_t>(cols)) return;                                                 // (wave-uniform)
+    const size_t ld = 3 * static_cast<size_t>(cols);         // partials[path block][3 x cols]: column 3 q + which
+    // lane l plays the threads l, 64 + l, 128 + l, 192 + l of block_column_sum one after the other -- the same additions in the
+    // same order, the same bits -- with the loads of all three columns (a payoff launch has at most 1024 path blocks: four rows
+    // per virtual thread) in flight before the first addition: one round trip, not twelve
+    const unsigned lane = threadIdx.x & 63u;
+    double t[3][4][4], sm[3];
+#pragma unroll
+    for (int which = 0; which < 3; ++which)
+#pragma unroll
+        for (int vw = 0; vw < 4; ++vw) column_rows_load<4>(partials + 3 * q + which, vw * 64u + lane, n_rows, ld, t[which][vw]);
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        double total = 0.0;
+#pragma unroll
+        for (int vw = 0; vw < 4; ++vw) {
+            const double w = wave_sum(column_rows_add<4>(t[which][vw], vw * 64u + lane, n_rows));
+            total = (vw == 0) ? w : total + w;
+        }
+        sm[which] = total;
+    }
+    if (lane != 0u) return;
+    sums_out[3 * q] = sm[0];
+    sums_out[3 * q + 1] = sm[1];
+    sums_out[3 * q + 2] = sm[2];
+}
+
+int chain_payoff_and_finish(const double *const *x_snapshots_host, const double *const *qvar_snapshots_host, size_t n_path,
+                            const double *forwards_host, const double *ttms_host, double *spot_sums, const double *spot_partials,
+                            int n_expiries, const double *strikes_host, const int8_t *types_host, const double *shifts_host,
+                            const size_t *strike_offsets_host, int variable_type, void *workspace, size_t workspace_bytes,
+                            hipStream_t stream, double *sums_out)
+{
+    const char *fn = "chain_payoff_and_finish";
+    const unsigned rows = wave_rows(n_path);
+    PayoffPartialsOut po;
+    if (int rc = payoff_sums_impl(fn, x_snapshots_host, qvar_snapshots_host, n_path, forwards_host, ttms_host, spot_sums, n_expiries,
+                                  strikes_host, types_host, shifts_host, strike_offsets_host, variable_type, nullptr, workspace,
+                                  workspace_bytes, reinterpret_cast<svmc_stream_t>(stream), 1, PayoffSetStrides{0, 0, 0}, spot_partials,
+                                  rows, &po))
+        return rc;
+    if (po.cols == 0) return SVMC_OK;
+    if (po.rows > 4u * BLOCK) return fail(SVMC_ERR_WORKSPACE, std::string(fn) + ": more path blocks than chain_finish_kernel sums");
+    hipLaunchKernelGGL(chain_finish_kernel, dim3(static_cast<unsigned>((po.cols + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, stream,
+                       static_cast<const double *>(workspace), po.rows, po.cols, sums_out);
+    return check_launch(fn);
+}
+
+// the stepping launch of a chain WITHOUT the reduce of its per-wave partial columns (they stay in `workspace`):
+// svmc_*_slice_rng_from / svmc_*_chain_rng_from with spot_sums = null, for svmc_chain.hip's one-device tail
+int logsv_step_partials(double sigma0, double *x, double *sigma, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                        const double *dts_host, const double *etas_host, const double *forwards_host, double theta, double kappa1,
+                        double kappa2, double beta, double volvol, int is_spot_measure, uint64_t seed, uint32_t call_id,
+                        uint64_t path_offset, double *x_snapshots, double *qvar_snapshots, void *workspace, size_t workspace_bytes,
+                        hipStream_t stream)
+{
+    const StateInit init = {1, 0.0, sigma0, 0.0};
+    const svmc_stream_t st = reinterpret_cast<svmc_stream_t>(stream);
+    if (n_slices == 1)
+        return logsv_slice_rng_impl("logsv_step_partials", init, x, sigma, qvar, n_path, nb_steps_host[0], dts_host[0], theta, kappa1,
+                                    kappa2, beta, volvol, etas_host ? etas_host[0] : 1.0, is_spot_measure, seed, call_id, path_offset, 0,
+                                    forwards_host[0], x_snapshots, qvar_snapshots, nullptr, workspace, workspace_bytes, st);
+    return logsv_chain_rng_impl("logsv_step_partials", init, x, sigma, qvar, n_path, n_slices, nb_steps_host, dts_host, etas_host,
+                                forwards_host, theta, kappa1, kappa2, beta, volvol, is_spot_measure, seed, call_id, path_offset, 0,
+                                x_snapshots, qvar_snapshots, nullptr, workspace, workspace_bytes, st);
+}
+
+int heston_step_partials(double var0, double *x, double *var, double *qvar, size_t n_path, int n_slices, const int *nb_steps_host,
+                         const double *dts_host, const double *forwards_host, double theta, double kappa, double rho, double volvol,
+                         int scheme, uint64_t seed, uint32_t call_id, uint64_t path_offset, double *x_snapshots,
+                         double *qvar_snapshots, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    const StateInit init = {1, 0.0, var0, 0.0};
+    const svmc_stream_t st = reinterpret_cast<svmc_stream_t>(stream);
+    if (n_slices == 1)
+        return heston_slice_rng_impl("heston_step_partials", init, x, var, qvar, n_path, nb_steps_host[0], dts_host[0], theta, kappa, rho,
+                                     volvol, scheme, seed, call_id, path_offset, 0, forwards_host[0], x_snapshots, qvar_snapshots,
+                                     nullptr, workspace, workspace_bytes, st);
+    return heston_chain_rng_impl("heston_step_partials", init, x, var, qvar, n_path, n_slices, nb_steps_host, dts_host, forwards_host,
+                                 theta, kappa, rho, volvol, scheme, seed, call_id, path_offset, 0, x_snapshots, qvar_snapshots, nullptr,
+                                 workspace, workspace_bytes, st);
+}
+
+// the largest launch whose payoff blocks form their spot sums themselves: 2048 rows = 131072 paths, ONE batched round trip of
+// loads per block (block_column_sum2); above, the reduce launch is cheaper than what every block would repeat (see above)
+bool spot_sums_in_payoff_kernel(size_t n_path) { return wave_rows(n_path) <= 8u * BLOCK; }
+
+// reduce the generators' per-wave partial columns [n_cols][rows] into spot_sums[n_cols] (what the stepping entry points do
+// themselves unless told not to)
+int reduce_spot_partials(const void *workspace, size_t n_path, int n_cols, double *spot_sums, hipStream_t stream)
+{
+    if (n_cols <= 0) return SVMC_OK;
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(static_cast<unsigned>(n_cols)), dim3(BLOCK), 0, stream,
+                       static_cast<const double *>(workspace), wave_rows(n_path), size_t(1), static_cast<size_t>(wave_rows(n_path)),
+                       spot_sums);
+    return check_launch("reduce_spot_partials");
 }
 
 }  // namespace svmc

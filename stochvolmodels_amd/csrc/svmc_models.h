@@ -217,6 +217,50 @@ __device__ __forceinline__ void logsv_step_acc_sets(const double (&c1)[P], const
     }
 }
 
+// logsv_step_acc_sets in two halves around the P exp-table reads (rng_time_loop_pipelined): front = everything up to the ISSUE
+// of the reads, back = what consumes them.  Per state logsv_step_acc_sets' operations in its order: the same bits.
+template <int P>
+struct LogsvSetsInFlight {
+    double r[P], t[P];
+    int ni[P];
+};
+template <int P>
+__device__ __forceinline__ void logsv_step_acc_sets_front(const double (&c1)[P], const double (&c2)[P], const double (&c3)[P],
+                                                          const double (&bs)[P], const double (&es)[P], double (&xacc)[P],
+                                                          double (&L)[P], const double (&sigma)[P], double z0, double z1,
+                                                          const double *exp_table, LogsvSetsInFlight<P> &h)
+{
+    double y[P];
+#pragma unroll
+    for (int s = 0; s < P; ++s) y[s] = rcp_1n(sigma[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) xacc[s] = fma(sigma[s], z0, xacc[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        double l = fma(c2[s], sigma[s], L[s]);
+        l = fma(c1[s], y[s], l);
+        l = l + c3[s];
+        l = fma(bs[s], z0, l);
+        L[s] = fma(es[s], z1, l);
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s) exp2u_reduce(L[s], h.ni[s], h.r[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) h.t[s] = exp_table[h.ni[s] & 255];
+}
+template <int P>
+__device__ __forceinline__ void logsv_step_acc_sets_back(double (&sigma)[P], double (&acc)[P], LogsvSetsInFlight<P> &h)
+{
+#pragma unroll
+    for (int s = 0; s < P; ++s) h.r[s] = exp2u_tail(h.r[s]);
+#pragma unroll
+    for (int s = 0; s < P; ++s) {
+        const double sn = exp2u_scale(h.t[s], h.r[s], h.ni[s]);
+        acc[s] = fma(sn, sn, acc[s]);
+        sigma[s] = sn;
+    }
+}
+
 // sigma^2 as a rounded product of its own: without this the compiler may fuse the multiplication into the subtraction of
 // logsv_fold_acc (s2_start - sigma_T^2 as one FMA) in one kernel and not in another -- whichever way the inlined code around
 // it falls -- and the one-slice, whole-chain and streamed generators must agree to the bit (a persistent-launch variant of

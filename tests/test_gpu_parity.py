@@ -13,6 +13,8 @@ below SURVEY App. B.7's 1e-12 (stepping) -- so 1e-12 on states / sums, ST = 1e-1
 the reference's golden vectors (numpy's libm on the other side).  Statistical checks use the reference's own criterion
 |MC - analytic| <= 4 stderr (reference tests/test_logsv_characterization.py:407).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1544,6 +1546,27 @@ def test_config_c4_btc_style_chain(sv, oracle):
     x, s, q = get_engine(n).get_state()
     assert abs(np.mean(np.exp(x)) - 1.0) <= 4.0 * np.std(np.exp(x)) / np.sqrt(n)
     assert np.all(s > 0) and np.all(q >= 0)
+
+
+def test_one_device_tail_equals_five_node_tail(sv):
+    """round 6 ends a chain on one device with two launches -- the payoff kernel (its blocks sum their expiry's per-wave spot
+    partials themselves) and chain_finish_kernel (a wave per quote: the column sums, price -> implied vol, results stored in
+    pinned memory) -- where round 5 ran reduce, payoff, reduce, [implied vols,] copy.  Every sum is formed in the same order of
+    additions, so LogSV (chain with inverse options, one expiry, Q_VAR), Heston (Euler, QE) and the frozen-randoms objective
+    (one set, five sets, implied vols) must come out BIT FOR BIT the same either way, below and above the few-waves switch"""
+    import json
+    import subprocess
+    import sys as _sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tail_nodes_worker.py")
+    got = {}
+    for nodes in ("2", "5"):
+        env = dict(os.environ, SVMC_CHAIN_TAIL_NODES=nodes)
+        r = subprocess.run([_sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[nodes] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert got["2"].keys() == got["5"].keys() and len(got["2"]) == 29
+    diff = [k for k in got["2"] if got["2"][k] != got["5"][k]]
+    assert not diff, diff
 
 
 @pytest.mark.parametrize("n", [131072, 131073])
