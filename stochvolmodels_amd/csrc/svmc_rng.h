@@ -58,8 +58,20 @@ struct RngTables {
 };
 
 constexpr unsigned ICDF_PIECES = SVMC_ICDF_PIECES;
+// SVMC_ICDF_MIXED (measurement builds only, round 6, VERDICT r05 item 2: "one LDS read per normal"): the EDGE form of the table
+// with its two high-order coefficients kept as fp32 in LDS -- 24 bytes per normal (one ds_read_b128 + one ds_read_b64) instead of
+// 32 (two ds_read_b128); the cubic then runs a3 d + a2 in fp32 and the two low-order steps in fp64 (12 VALU instructions per
+// normal against the product's 8).  Another stream (other bits): never the product.  tools/r06/ab_icdf.sh builds and times it.
+#ifndef SVMC_ICDF_MIXED
+#define SVMC_ICDF_MIXED 0
+#endif
 struct RngTablesLds {
+#if SVMC_ICDF_MIXED
+    IcdfPiece icdf[SVMC_ICDF_SEGMENTS];
+    float2 hi[SVMC_ICDF_SEGMENTS];
+#else
     IcdfPiece icdf[ICDF_PIECES * SVMC_ICDF_SEGMENTS];
+#endif
 };
 
 // the log table alone (the streamed Heston QE kernel: its martingale correction takes logs, it draws nothing)
@@ -72,7 +84,16 @@ __device__ __forceinline__ const LogTabEntry *stage_log_table(LogTabEntry (&lds)
 
 __device__ __forceinline__ void copy_icdf_table(RngTablesLds &lds)
 {
+#if SVMC_ICDF_MIXED
+    static_assert(SVMC_ICDF_EDGE && !SVMC_ICDF_RAW && SVMC_ICDF_DEG == 3, "the mixed-precision table is the edge form of a cubic");
+    for (unsigned i = threadIdx.x; i < SVMC_ICDF_SEGMENTS; i += blockDim.x) {
+        lds.icdf[i] = g_icdf_table[i];
+        const IcdfPiece h = g_icdf_table[SVMC_ICDF_SEGMENTS + i];
+        lds.hi[i] = make_float2(static_cast<float>(h.a), static_cast<float>(h.b));
+    }
+#else
     for (unsigned i = threadIdx.x; i < ICDF_PIECES * SVMC_ICDF_SEGMENTS; i += blockDim.x) lds.icdf[i] = g_icdf_table[i];
+#endif
 }
 
 __device__ __forceinline__ RngTables stage_rng_tables(RngTablesLds &lds)
@@ -241,8 +262,31 @@ __device__ __forceinline__ double uniform_32(uint32_t k)
 }
 
 // The two normals of a time step from two words, each by inversion (svmc_math.h normal_icdf32)
+#if SVMC_ICDF_MIXED
+__device__ __forceinline__ double normal_icdf32_mixed(uint32_t w, const IcdfPiece *tab)
+{
+    const double t = static_cast<double>(static_cast<int32_t>(w)) + 0.5;
+    const uint32_t hi = double_hi(t);
+    const uint32_t off = (hi >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
+    const char *base = reinterpret_cast<const char *>(tab);
+    const IcdfPiece e0 = *reinterpret_cast<const IcdfPiece *>(base + off);
+    const float2 e1 = *reinterpret_cast<const float2 *>(base + 16 * SVMC_ICDF_SEGMENTS + (off >> 1));
+    const double edge = bits_to_double(0u, hi & (0x7FFFFFFFu & ~((1u << (20 - SVMC_ICDF_M)) - 1u)));
+    const double d = fabs(t) - edge;
+    const float q = fmaf(e1.y, static_cast<float>(d), e1.x);
+    double p = fma(static_cast<double>(q), d, e0.b);
+    p = fma(p, d, e0.a);
+    return copysign(p, t);
+}
+#endif
+
 __device__ __forceinline__ void normals_from_words(uint32_t ra, uint32_t rb, const RngTables &t, double &w0, double &w1)
 {
+#if SVMC_ICDF_MIXED
+    w0 = normal_icdf32_mixed(ra, t.icdf);
+    w1 = normal_icdf32_mixed(rb, t.icdf);
+    return;
+#endif
     w0 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(ra, t.icdf);
     w1 = normal_icdf32<SVMC_ICDF_M, SVMC_ICDF_SEGMENTS, SVMC_ICDF_DEG, SVMC_ICDF_EDGE != 0, SVMC_ICDF_RAW != 0>(rb, t.icdf);
 }
@@ -254,6 +298,16 @@ struct DrawInFlight {
     double t[4];
     IcdfPiece e0[4], e1[4];
 };
+#if SVMC_ICDF_MIXED          // (the measurement build times the full-launch kernels only: the split forms just have to compile)
+__device__ __forceinline__ void draw_issue(const uint32_t (&r)[4], const RngTables &tab, DrawInFlight &d)
+{
+    for (int k = 0; k < 4; ++k) d.t[k] = normal_icdf32_mixed(r[k], tab.icdf);
+}
+__device__ __forceinline__ void draw_finish(const DrawInFlight &d, double (&z)[4])
+{
+    for (int k = 0; k < 4; ++k) z[k] = d.t[k];
+}
+#else
 __device__ __forceinline__ void draw_issue(const uint32_t (&r)[4], const RngTables &tab, DrawInFlight &d)
 {
     static_assert(SVMC_ICDF_RAW != 0, "the split draw is written for the raw form of the table");
@@ -278,6 +332,7 @@ __device__ __forceinline__ void draw_finish(const DrawInFlight &d, double (&z)[4
         z[k] = copysign(p, d.t[k]);
     }
 }
+#endif
 
 // The time loop of every on-device-RNG generator: time steps [0, nb) of a lane whose first step has the chain-global
 // index step0.  One Philox call serves the two steps 2c, 2c + 1, so the loop runs over CALLS and each half is guarded by
@@ -395,6 +450,18 @@ struct PairInFlight {
     double t[2];
     IcdfPiece e0[2], e1[2];
 };
+#if SVMC_ICDF_MIXED
+__device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTables &tab, PairInFlight &d)
+{
+    d.t[0] = normal_icdf32_mixed(ra, tab.icdf);
+    d.t[1] = normal_icdf32_mixed(rb, tab.icdf);
+}
+__device__ __forceinline__ void pair_finish(const PairInFlight &d, double &z0, double &z1)
+{
+    z0 = d.t[0];
+    z1 = d.t[1];
+}
+#else
 __device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTables &tab, PairInFlight &d)
 {
     static_assert(SVMC_ICDF_RAW != 0, "the split draw is written for the raw form of the table");
@@ -422,6 +489,7 @@ __device__ __forceinline__ void pair_finish(const PairInFlight &d, double &z0, d
     z0 = z[0];
     z1 = z[1];
 }
+#endif
 
 // rng_time_loop with ONE PAIR ahead: the table reads of the next step's two normals are issued before this step runs and
 // their cubics evaluated after it -- half the registers of rng_time_loop_ahead (one pair in flight, not four normals), for
