@@ -24,7 +24,8 @@ LIB = os.path.join(PKG, "libsvmc.so")
 # compiler's own assembly of THIS build, and the library's sha256 -- bench.py prices its roofline from it and marks the
 # line stale when the library it loaded is not the one the histogram describes
 ISA_JSON = os.path.join(PKG, "libsvmc.isa.json")
-ISA_KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "heston_rng_kernelILi0", "heston_rng_kernelILi1")
+ISA_KERNELS = ("logsv_rng_kernel", "logsv_chain_rng_kernel", "heston_rng_kernelILi0", "heston_rng_kernelILi1", "heston_rng_kernelILi2",
+               "logsv_rng_lat_kernelILi4ELi4ELi256", "logsv_chain_rng_lat_kernelILi4ELi4ELi256")
 SOURCES = ("svmc_runtime.hip", "svmc_kernels.hip", "svmc_analytic.hip", "svmc_chain.hip", "svmc_comm.hip", "svmc_multi.hip")
 HEADERS = ("svmc_internal.h", "svmc_models.h", "svmc_rng.h", "svmc_math.h", "svmc_log_table.h", "svmc_icdf_table.h", "svmc_black.h", "svmc_ode.h", "svmc_dop853.h")
 ARCH = "gfx950"

@@ -1174,6 +1174,9 @@ struct VolPathConsts {
 #define SVMC_VOLPATHS_RNG_BLOCK 1024   // drawing instantiation: two blocks per CU share one copy each of the draw's table
 #endif
 constexpr int VOLPATHS_RNG_BLOCK = SVMC_VOLPATHS_RNG_BLOCK;
+#ifndef SVMC_VOLPATHS_VARIANT
+#define SVMC_VOLPATHS_VARIANT 0        // measurement builds only (tools/r06/ab_vol_paths.sh): 1 = next call's reads ahead, 2 = four steps, four stores
+#endif
 #ifndef SVMC_VOLPATHS_PROBE
 #define SVMC_VOLPATHS_PROBE 0          // measurement builds only (tools/ubench/ab_vol_paths.py): 1 = no stores (the store stays in
 #endif                                 // the code behind a test that never holds), 2 = every store lands on row 1 (L2-resident)
@@ -1222,6 +1225,47 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
             const PhiloxLane pl = philox_prepare(seed, c3 | 2u, path_offset + p);
             uint32_t r[4];
             double a0, a1, b0, b1;
+#if SVMC_VOLPATHS_VARIANT == 1     // measurement: the NEXT call's table reads in flight under this call's four steps (the same bits)
+            if (t + 4 <= nb_steps) {
+                DrawInFlight d;
+                philox_draw(pl, 0u, r);
+                draw_issue(r, tab, d);
+                for (; t + 4 <= nb_steps; t += 4) {
+                    double z[4];
+                    draw_finish(d, z);
+                    philox_draw(pl, static_cast<uint32_t>((t >> 2) + 1), r);      // the last trip draws a call nobody uses
+                    draw_issue(r, tab, d);
+                    step(z[0]);
+                    step(z[1]);
+                    step(z[2]);
+                    step(z[3]);
+                }
+            }
+#elif SVMC_VOLPATHS_VARIANT == 2   // measurement: four steps into registers, then their four stores back to back (the same bits)
+            for (; t + 4 <= nb_steps; t += 4) {
+                philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
+                normals_from_words(r[0], r[1], tab, a0, a1);
+                normals_from_words(r[2], r[3], tab, b0, b1);
+                double sv[4];
+                const double zz[4] = {a0, a1, b0, b1};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double y = rcp_1n(s);
+                    L = fma(c.c2, s, L);
+                    L = fma(c.c1, y, L);
+                    L = L + c.c3;
+                    L = fma(c.cz, zz[u], L);
+                    s = exp2u_tab(L, s_exp);
+                    sv[u] = s;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    vol_paths_store(out, sv[u]);
+                    out += ld;
+                }
+            }
+#else
             for (; t + 4 <= nb_steps; t += 4) {
                 philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
                 normals_from_words(r[0], r[1], tab, a0, a1);
@@ -1231,6 +1275,7 @@ void logsv_vol_paths_kernel(double *__restrict__ sigma_t, size_t ld, size_t n, i
                 step(b0);
                 step(b1);
             }
+#endif
             if (t < nb_steps) {                            // the last, partial call (wave-uniform)
                 philox_draw(pl, static_cast<uint32_t>(t >> 2), r);
                 normals_from_words(r[0], r[1], tab, a0, a1);

@@ -464,6 +464,30 @@ __device__ __forceinline__ double log_one_minus(double e, const LogTabEntry *tab
     return -neg_log_tab(one_minus_e, tab);
 }
 
+// The martingale correction 2 K0* = ln(1 - e) - 2 A alpha / (1 - e), e = 2 A a = 2 A (m - alpha), as ONE polynomial where |e| is
+// small (round 6).  With M = 2 A m:  2 A alpha = M - e, so
+//     2 K0* = -M + ln(1 - e) + (1 - M) e / (1 - e) = -M - M e + sum_{k >= 2} (k - 1)/k - M) e^k ... i.e. coefficients
+//     c_0 = c_1 = -M,  c_k = (k - 1)/k - M,
+// to e^5 below 2^-10 (the next term, (5/6 - M) e^6, is under 9e-19): one product for M, four subtractions and five FMAs where
+// the two separate series (logarithm and reciprocal), the product 2 A alpha and the final FMA took sixteen instructions.  Larger
+// |e| keep the round-5 forms: log_one_minus (eight-term series to 2^-6, the table logarithm above) and the hardware reciprocal.
+// The regime is chosen PER LANE: a path's rounding does not depend on which other paths share its wave.
+__device__ __forceinline__ double qe_martingale_kd(double e, double al, double m, double twoA, const LogTabEntry *tab)
+{
+    if (fabs(e) < 0x1.0p-10) {
+        const double M = twoA * m;
+        double p = 0x1.999999999999ap-1 - M;              // 4/5 - M
+        p = fma(p, e, 0.75 - M);
+        p = fma(p, e, 0x1.5555555555555p-1 - M);          // 2/3 - M
+        p = fma(p, e, 0.5 - M);
+        p = fma(p, e, -M);
+        return fma(p, e, -M);
+    }
+    double inv;
+    const double ln_den = log_one_minus(e, tab, inv);
+    return fma(-(twoA * al), inv, ln_den);                // ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)
+}
+
 // One QE-M step.  z0 drives the log-price, z1 the quadratic branch; draw_u() hands over the uniform of the exponential
 // branch -- called by the whole wave as soon as one lane is there (the streamed kernel loads it; the on-device draw is a
 // lazily evaluated Philox call shared by four steps, svmc_rng.h qe_uniform).
@@ -523,9 +547,7 @@ __device__ __forceinline__ void heston_qe_step(const QeConsts &c, const QeVec &c
         } else {
             const double e = c.twoA * a;                  // 2 A a
             if (QUAD || c.e_below_one || e < 1.0) {
-                double inv;
-                const double ln_den = log_one_minus(e, tab, inv);
-                Kd = fma(-(c.twoA * al), inv, ln_den);    // ln(1 - 2 A a) - 2 A b^2 a / (1 - 2 A a)
+                Kd = qe_martingale_kd(e, al, m, c.twoA, tab);
             } else {
                 Kd = fma(c.K13_2, v0, c.K0_plain2);       // the plain drift: cancels the folded -K13 v0
             }
