@@ -78,6 +78,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6
 N_SIMD = 256 * 4
 MAX_CLOCK_HZ = 2.4e9
 SIMD_CYCLES_PEAK = N_SIMD * MAX_CLOCK_HZ               # SIMD issue cycles per second, whole chip
+FP64_VECTOR_PEAK_FLOPS = 78.6e12                       # MI355X_MICROARCH.md: fp64 vector (non-MFMA) peak, FMA = 2 flop
 # Issue cost of a wave64 VALU instruction on one SIMD, in shader cycles, by opcode class -- MEASURED on this chip with
 # tools/ubench/valu_rates.hip (profiles/r03_valu_rates.txt, s_memtime ticks, 8 waves per SIMD; measured 4.08-4.17 / 16.2 /
 # 4.07-4.17 / 2.17-2.25 / 8.1, rounded DOWN to the architectural figure so that the roof is never understated):
@@ -409,8 +410,20 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
             "clock_mhz_sensor": clock_mhz, "ms_per_launch": k_ms, "launches": launches,
             "traffic": traffic, "algorithmic_bytes": alg_bytes,
         }
+        # an implementation-independent reading beside the issue roofline: the fp64-class instructions of
+        # the loop (FMA / add / mul / cvt / 64-bit mad: two flops each at the vector unit's rate) against the 78.6 TFLOP/s fp64
+        # vector peak -- what is left of the issue budget is Philox int32 and the two quarter-rate reciprocals
+        fp64_per_wave_step = classes.get("fp64", 0) / steps_per_iteration
+        out["roofline"]["fp64_insts_per_wave_step"] = fp64_per_wave_step
+        out["roofline"]["fp64_fma_frac"] = fp64_per_wave_step * 2.0 * 64.0 * wave_steps / (k_ms * 1e-3) / FP64_VECTOR_PEAK_FLOPS
+        out["roofline"]["fp64_vector_peak_tflops"] = FP64_VECTOR_PEAK_FLOPS / 1e12
+        out["roofline"]["cycles_per_wave_step_measured"] = None
+        out["roofline"]["lds_busy_frac"] = None
         clk = clock_from_stamps(stamps) if stamps is not None else {}
         if clk.get("mhz"):
+            # SIMD cycles the chip delivered per wave-step at the clock measured inside the kernel, beside the issue cycles the
+            # loop's instructions need (issue_cycles_per_wave_step): the gap is idle issue -- LDS waits, the launch's tail
+            out["roofline"]["cycles_per_wave_step_measured"] = (k_ms * 1e-3) * clk["mhz"] * 1e6 * N_SIMD / wave_steps
             # the clock MEASURED INSIDE the last timed launch (s_memtime against the 100 MHz s_memrealtime, wave 0 of the
             # launch's first and last block): the same issue cycles against the cycles the chip actually delivered in the
             # kernel's time -- what is left of 1 is idle issue, not clock
@@ -431,6 +444,7 @@ def kernel_rooflines(kernel: str, k_ms: float, launches: int, n_local: int, wl, 
             # the second pipe the loop leans on, from the committed counter pass of THIS build: the randomly indexed table reads
             # of the inverse-CDF draw keep the LDS nearly as busy as the vector ALU
             cycles = gui / 8.0                                 # GRBM_GUI_ACTIVE counts per XCD
+            out["roofline"]["lds_busy_frac"] = lds / 256.0 / cycles
             out["roofline"]["counters"] = {
                 "valu_busy_frac": 4.0 * act / N_SIMD / cycles,                  # SQ_ACTIVE_INST_VALU ticks in quad-cycles
                 "lds_busy_frac": lds / 256.0 / cycles,                          # SQ_LDS_IDX_ACTIVE: LDS-array cycles, per CU
@@ -706,13 +720,32 @@ def secondary_block(sv, P) -> dict:
                         "hbm_bytes_for_randoms": 0,
                         "bit_equal_to_mc_chain_pricer": bool(all(np.array_equal(a, b) for a, b in zip(got[0] + got[1], want[0] + want[1])))}
 
+    # ---- mid: the reference's own path counts (10^5 by default, pricers/logsv_pricer.py:374; 4 x 10^5 in its paper), 4 x 13 chain x 364
+    #      steps -- 1.5 and 6.1 waves per SIMD: the few-waves (pipelined) generators, one C-ABI call per chain
+    mid = {"chain": "4 x 13 strikes, ttm 1/12 .. 1, 364 steps", "n_dev": n_dev}
+    for n_mid in (100_000, 400_000):
+        kw = dict(v0=P.sigma0, theta=P.theta, kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta, volvol=P.volvol, vol_backbone_etas=np.ones(4),
+                  nb_steps_per_year=360, seed=20240611, **ch)
+        ms, _ = _median_ms(lambda: sv.logsv_mc_chain_pricer(nb_path=n_mid, **kw), 60, 5)
+        mid[str(n_mid)] = {"ms": _sig(ms), "psps": _sig(n_mid * 364 / (ms * 1e-3))}
+    pr, _ = sv.logsv_mc_chain_pricer(nb_path=n_dev, **kw)
+    x, s_, q = np.zeros(n_dev), P.sigma0 * np.ones(n_dev), np.zeros(n_dev)
+    ref, step0, t0 = [], 0, 0.0
+    for ttm in tt:
+        nb_i, dt_i, _ = sv.set_time_grid(float(ttm) - t0, 360)
+        x, s_, q = oracle.logsv_terminal_rng(x, s_, q, nb_i, dt_i, P.theta, P.kappa1, P.kappa2, P.beta, P.volvol, 20240611, step_offset=step0)
+        ref.append(oracle.payoff(x, q, float(ttm), 1.0, k13, np.where(k13 >= 1.0, "C", "P"))[0])
+        step0, t0 = step0 + nb_i, float(ttm)
+    mid["dev"] = _sig(_prices_dev(pr, ref, 1e-3), 2)
+    out["mid"] = mid
+
     # ---- C2's call at 2^21 paths: the asymptotic rate (the 2^20-path launch ends in a second, partial residency round)
     wl = dict(ttms=np.array([1.0]), forwards=np.ones(1), discfactors=np.ones(1), strikes_ttms=(kk,), optiontypes_ttms=(types,))
     ms, _ = _median_ms(lambda: sv.logsv_mc_chain_pricer(v0=P.sigma0, theta=P.theta, kappa1=P.kappa1, kappa2=P.kappa2, beta=P.beta,
                                                         volvol=P.volvol, vol_backbone_etas=np.ones(1), nb_path=1 << 21,
                                                         nb_steps_per_year=1023, seed=20240602, **wl), 15, 10)   # (warm: the block's small launches before it leave the clocks low)
     out["c2_at_2e21_paths"] = {"ms": _sig(ms), "psps": _sig((1 << 21) * 1024 / (ms * 1e-3))}
-    for n in (1 << 22, 1 << 23, 1 << 21, 100_000, n_dev, 10_000):            # give the legs' HBM back
+    for n in (1 << 22, 1 << 23, 1 << 21, 100_000, 400_000, n_dev, 10_000):            # give the legs' HBM back
         try:
             get_engine(n).close()
         except Exception:                                   # noqa: BLE001

@@ -346,15 +346,30 @@ int svmc_multi_create(svmc_multi_t *multi, int n_shards, const int *devices_host
     const int rc = run_on_shards(*mu, [mu](Shard &s) {
         if (int rc = svmc_session_create(&s.session, s.n_path, mu->max_expiries, mu->max_strikes)) return rc;
         if (mu->mode == SVMC_MULTI_REDUCE_RCCL) {
-            if (int rc = svmc_session_set_comm(s.session, s.comm, s.rank, mu->R, mu->n_total, s.offset)) return rc;
+            // everything that can fail on ONE shard alone (the session above: an out-of-memory device; the communicator's
+            // attachment; the warm-up buffer) happens BEFORE the shards meet: a shard that fails here returns, worker_main aborts
+            // the barrier, and the others leave with an error instead of entering a collective whose peer never comes (inside
+            // ncclAllReduce a missing peer cannot be recovered from; a failed CREATION can and must -- round-5 advisor finding)
             double *warm = nullptr;
-            SVMC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&warm), sizeof(double)));
+            int rc = svmc_session_set_comm(s.session, s.comm, s.rank, mu->R, mu->n_total, s.offset);
+            if (rc == SVMC_OK && hipMalloc(reinterpret_cast<void **>(&warm), sizeof(double)) != hipSuccess)
+                rc = fail(SVMC_ERR_HIP, "svmc_multi_create: warm-up buffer");
             const double one = 1.0;
-            SVMC_HIP_TRY(hipMemcpy(warm, &one, sizeof(double), hipMemcpyHostToDevice));
-            int rc = svmc_rccl_all_reduce_sum(s.comm, warm, 1, nullptr);
+            if (rc == SVMC_OK && hipMemcpy(warm, &one, sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+                rc = fail(SVMC_ERR_HIP, "svmc_multi_create: warm-up upload");
+            if (rc != SVMC_OK) {
+                if (warm != nullptr) (void)hipFree(warm);
+                return rc;
+            }
+            if (!mu->barrier->arrive_and_wait()) {
+                (void)hipFree(warm);
+                return fail(SVMC_ERR_HIP, "multi-session all-reduce aborted: another shard failed while the multi-session was created");
+            }
+            rc = svmc_rccl_all_reduce_sum(s.comm, warm, 1, nullptr);
             if (rc == SVMC_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SVMC_ERR_HIP, "warm-up all-reduce failed");
             double seen = 0.0;
-            if (rc == SVMC_OK) SVMC_HIP_TRY(hipMemcpy(&seen, warm, sizeof(double), hipMemcpyDeviceToHost));
+            if (rc == SVMC_OK && hipMemcpy(&seen, warm, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(SVMC_ERR_HIP, "svmc_multi_create: warm-up download");
             (void)hipFree(warm);
             if (rc == SVMC_OK && s.rank == 0) mu->rccl_ranks_seen = static_cast<int>(seen + 0.5);
             return rc;

@@ -425,7 +425,15 @@ def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_time
         dist.init_process_group(backend="gloo")
     control = TorchComm()                                # the gloo world group
     report["control_plane"] = "gloo"
-    report["ranks_share_a_device"] = bool(n_dev and world > n_dev)
+    # do the ranks of some NODE outnumber the devices that node's ranks see?  Counted per node -- LOCAL_WORLD_SIZE (torchrun sets
+    # it; a bare launch of one node: the world) against the devices visible to this rank -- and agreed over the control plane, so
+    # that two nodes of eight (WORLD_SIZE 16, 8 devices each) are not mistaken for sharing and one rank's failed device query
+    # cannot send the ranks down different sequences of collectives (round-5 advisor finding)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    facts = [None] * world
+    dist.all_gather_object(facts, (local_world, n_dev))
+    report["ranks_share_a_device"] = any(nd > 0 and lw > nd for lw, nd in facts)
+    report["ranks_without_a_device"] = [r for r, (_, nd) in enumerate(facts) if nd == 0]
 
     def everyone(ok: bool) -> bool:
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
@@ -447,10 +455,14 @@ def init_with_fallback(rungs=("nccl", "rccl", "gloo"), on_phase=None, probe_time
             break
         if rung not in ("nccl", "rccl"):
             raise ValueError(f"unknown rung {rung!r}")
-        if n_dev == 0 and os.environ.get("SVMC_DIST_FORCE_PROBE") != "1":      # (forced: the CPU tests of the probe machinery)
-            ok, why = False, "no HIP device visible"
-        elif report["ranks_share_a_device"] and os.environ.get("SVMC_DIST_FORCE_PROBE") != "1":
-            ok, why = False, f"{world} ranks share {n_dev} device(s): RCCL takes one rank per device"
+        # skip or probe is decided from the facts every rank holds (gathered above): all ranks take the same branch, hence issue
+        # the same collectives below
+        forced = os.environ.get("SVMC_DIST_FORCE_PROBE") == "1"          # (the CPU tests of the probe machinery)
+        if report["ranks_without_a_device"] and not forced:
+            ok, why = False, ("no HIP device visible" if n_dev == 0
+                              else f"rank(s) {report['ranks_without_a_device']} see no HIP device")
+        elif report["ranks_share_a_device"] and not forced:
+            ok, why = False, f"{local_world} ranks of a node share {n_dev} device(s): RCCL takes one rank per device"
         else:
             port = [None]
             if rank == 0:

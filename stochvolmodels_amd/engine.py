@@ -161,6 +161,14 @@ def pipelined_download(src_ptr: int, n_doubles: int, stream=None, out: Optional[
                 if f is not None:
                     f.result()
         finally:
+            # an exception inside the loop (a failed copy, a failed drain) must not destroy the events while drain tasks still
+            # wait on them: every submitted task is waited for first, its own error swallowed -- the first one is already rising
+            for f in pending:
+                if f is not None:
+                    try:
+                        f.result()
+                    except Exception:               # noqa: BLE001
+                        pass
             for e in events:
                 lib.svmc_event_destroy(e)
     return out
@@ -276,8 +284,15 @@ def _dlpack_capsule(arr: "DeviceArray"):
 
     @DELETER
     def deleter(_p):
-        _DLPACK_ALIVE.pop(key, None)
+        # called by the consumer THROUGH the ctypes thunk `deleter` itself, with `m` as its argument: dropping the last reference
+        # to either from in here would free memory libffi / ctypes still read after this function returns.  The array (the HBM)
+        # goes now; the thunk, the tensor struct and its shape retire and are released two capsule creations later
+        kept = _DLPACK_ALIVE.pop(key, None)
+        if kept is not None:
+            _DLPACK_RETIRED[-1].append(kept[:3])
     m.deleter = deleter
+    _DLPACK_RETIRED.append([])                             # a new generation; the one before the previous is let go
+    del _DLPACK_RETIRED[:-2]
     _DLPACK_ALIVE[key] = (m, shape, deleter, arr)          # owner of everything the consumer may touch
     C.pythonapi.PyCapsule_New.restype = C.py_object
     C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, _CAPSULE_DESTRUCTOR]
@@ -285,6 +300,7 @@ def _dlpack_capsule(arr: "DeviceArray"):
 
 
 _DLPACK_ALIVE = {}
+_DLPACK_RETIRED = [[]]         # generations of (tensor struct, shape, deleter thunk) whose deleter has run (see _dlpack_capsule)
 _CAPSULE_DESTRUCTOR = C.CFUNCTYPE(None, C.c_void_p)
 
 
@@ -338,6 +354,9 @@ def marshalled_chain(ttms, forwards, discfactors, strikes: Sequence[np.ndarray],
     return hit
 
 
+BULK_KEEP_FRACTION = 0.125     # of the device's memory: what an engine's cached bulk buffers may hold between calls (trim_bulk)
+
+
 class HipEngine:
     def __init__(self, n_path: int, device: Optional[int] = None, path_offset: int = 0,
                  n_snapshots: int = 0, stream: Optional[int] = None):
@@ -368,6 +387,7 @@ class HipEngine:
         self._sums = {}
         self._pinned, self._pinned_doubles = None, 0    # page-locked staging of the small result downloads
         self._bulk = {}                                 # slot -> DeviceBuffer: multi-GB results kept between calls (_bulk_buffer)
+        self._device_bytes = None                       # the device's memory, asked once (trim_bulk)
         self._prof = None   # list of (name, start_event, stop_event) while kernel timing is on
         self._fused = None                              # svmc_session_t over this engine's state (fused_chain_session)
         self._fused_size = (0, 0)
@@ -544,6 +564,20 @@ class HipEngine:
             buf = DeviceBuffer(int(n_doubles))
             self._bulk[slot] = buf
         return buf
+
+    def trim_bulk(self) -> None:
+        """after a call whose bulk result has left the device: keep the cached buffers only while together they stay under an
+        eighth of the device's memory (36 GB of an MI355X's 288: C2-sized path arrays, 8.6 GB each, stay; a caller that once
+        simulated 10^7 paths does not pin 80 GB for the life of the process) -- BULK_KEEP_FRACTION, release_bulk() for all of it"""
+        held = 8 * sum(b.n for b in self._bulk.values())
+        if held == 0:
+            return
+        if self._device_bytes is None:
+            name, cus, khz, mem = C.create_string_buffer(128), C.c_int(), C.c_int(), C.c_size_t()
+            _lib.check(self.lib.svmc_device_info(self.device, name, 128, C.byref(cus), C.byref(khz), C.byref(mem)))
+            self._device_bytes = int(mem.value)
+        if held > BULK_KEEP_FRACTION * self._device_bytes:
+            self.release_bulk()
 
     def release_bulk(self) -> None:
         """give the cached bulk buffers back (they otherwise stay with the engine: up to two path arrays of the largest size seen)"""
@@ -745,6 +779,7 @@ class HipEngine:
             return arr
         host = arr.numpy(out_host)
         arr.free()
+        self.trim_bulk()
         return host
 
     def heston_rng(self, nb_steps, dt, theta, kappa, rho, volvol, scheme, seed, call_id, step_offset) -> None:

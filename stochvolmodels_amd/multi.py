@@ -131,6 +131,8 @@ class MultiDeviceSession:
 
 # One resident multi-session per (devices, paths, transport, thread): a chain priced again re-uses its buffers, threads and
 # communicators (creating them costs milliseconds to seconds -- RCCL builds its rings).  Grown when a larger chain arrives.
+# At most MAX_CACHED_MULTI per thread; a thread's sessions are released when it asks for one more, or by another thread's
+# request once the owner has ended.
 MAX_CACHED_MULTI = 2
 _CACHE = {}
 _CACHE_LOCK = threading.Lock()
@@ -146,8 +148,14 @@ def get_multi_session(devices, n_path_total: int, n_expiries: int, n_strikes_tot
             ms.close()
             ms = None
         if ms is None:
-            while len(_CACHE) >= MAX_CACHED_MULTI:
-                _CACHE.pop(next(iter(_CACHE))).close()
+            # make room -- but only among sessions no one can be pricing on right now: this thread's own (it is here, not inside
+            # a pricing call) and those of threads that have ended.  A session of another LIVE thread may be in the middle of
+            # svmc_multi_*_chain_price, outside this lock; destroying it would be a use-after-free (round-5 advisor finding)
+            me = threading.get_ident()
+            alive = {t.ident for t in threading.enumerate()}
+            mine = [k for k in _CACHE if k[3] == me or k[3] not in alive]
+            while mine and sum(1 for k in _CACHE if k[3] == me or k[3] not in alive) >= MAX_CACHED_MULTI:
+                _CACHE.pop(mine.pop(0)).close()
             ms = MultiDeviceSession(devs, n_path_total, max(n_expiries, 8), max(n_strikes_total, 256), reduce=reduce)
         _CACHE[key] = ms                                    # most recently used last
         return ms

@@ -541,6 +541,7 @@ def vol_path_moments(ttm: float, v0: float, theta: float, kappa1: float, kappa2:
         return out
     finally:
         sigma_t.free()
+        get_engine(nb_path).trim_bulk()        # the views are done: cached path arrays beyond an eighth of the device's memory go back
 
 
 def logsv_mc_chain_pricer(ttms: np.ndarray, forwards: np.ndarray, discfactors: np.ndarray,

@@ -370,6 +370,16 @@ def test_bench_workloads_and_roofline_arithmetic():
     assert r["peak"] == 1024 * 2.4e9 and abs(r["frac"] - want / (1024 * 2.4e9)) < 1e-12 and r["insts_per_wave_step"] == 53.0
     in_stream = (71 * 4 + 29 * 3.9 + 4 * 4 + 2 * 16) / 2.0
     assert abs(r["frac_in_stream_int32_cost"] - r["frac"] * in_stream / cyc) < 1e-12
+    # round 6: the implementation-independent readings beside it -- fp64-class instructions x 2 flop x 64 lanes against the 78.6
+    # TFLOP/s fp64 vector peak; without the in-kernel clock stamps the measured cycles per wave-step are not invented
+    wave_steps = (2 ** 20 / 64) * 1024
+    assert r["fp64_insts_per_wave_step"] == 35.5
+    assert abs(r["fp64_fma_frac"] - 35.5 * 2 * 64 * wave_steps / 2.0e-3 / 78.6e12) < 1e-12
+    assert r["cycles_per_wave_step_measured"] is None and r["lds_busy_frac"] is None
+    stamps = [0, 0, 2_200_000, 100_000, 0, 0, 2_200_000, 100_000]     # 2.2e6 shader ticks in 1e5 ticks of the 100 MHz clock: 2200 MHz
+    r2 = bench.kernel_rooflines("logsv_rng_kernel", 2.0, 50, 1 << 20, c2, isa, pmc, 2400.0, stamps)["roofline"]
+    assert abs(r2["clock_mhz_in_kernel"] - 2200.0) < 1e-9
+    assert abs(r2["cycles_per_wave_step_measured"] - 2.0e-3 * 2.2e9 * 1024 / wave_steps) < 1e-9
     assert r["clock_mhz_sensor"] == 2400.0 and r["traffic"] == 59.0e6 and r["stale"] is False
     assert r["insts_per_wave_step_counters"] == 53.2
     assert r["clock_mhz_in_kernel"] is None and r["frac_at_sustained_clock"] is None        # no stamps handed in
