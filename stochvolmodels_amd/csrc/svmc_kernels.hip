@@ -412,15 +412,15 @@ __global__ __launch_bounds__(RNG_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)
     slice_epilogue(so, p, active, xv, q);
 }
 
-// logsv_rng_kernel for a launch of a few waves per SIMD (n_path <= few_waves_max_paths(): the reference's default 10^5 paths
-// are 1.5 waves per SIMD).  Statement for statement the kernel above -- the same bits -- but compiled for latency instead
-// of residency: 256-thread blocks (every CU gets work), the register budget of two waves per SIMD, and the draw's table
-// reads of a call in flight together (rng_time_loop_few_waves).
-//
-// ... and for a launch of THREE TO SEVEN waves per SIMD (LOOP = GEN_LOOP_AHEAD, WAVES = 4: the register budget of four waves per
-// SIMD, which is also what four 256-thread blocks' tables leave room for in a CU's LDS): every wave keeps the next call's table
-// reads in flight under its own two steps (rng_time_loop_ahead) -- the batched draw of the two-wave form makes the waves of a CU
-// alternate, all together, between an LDS phase and a VALU phase.
+// logsv_rng_kernel for a launch of a few waves per SIMD (few_waves_launch(): up to seven; the reference's default 10^5 paths are
+// 1.5).  Statement for statement the kernel above -- the same bits -- but compiled for latency instead of residency: TB-thread
+// blocks (256 in the product: every CU gets work, and four blocks' tables fit a CU's LDS), the register budget of WAVES waves per
+// SIMD, and the time loop in form LOOP (svmc_rng.h):
+//   GEN_LOOP_PIPE   the product: the step in two halves around its exp-table read, the next pair's cubics, the next Philox call
+//                   and the issue of the pair after that between them -- a wave overlaps its own LDS round trips with its own
+//                   arithmetic, and the waves of a CU cannot fall into a common LDS phase
+//   GEN_LOOP_FEW    round 5's form (all eight reads of a call, then the cubics), GEN_LOOP_AHEAD / GEN_LOOP_PAIR: the alternatives
+//                   the round-6 sweep measured against it (LOGSV_LAT_VARIANTS below)
 constexpr int FEW_BLOCK = 256;
 // the time loop of a LogSV generator in form LOOP: the pipelined form takes the step in its two halves
 template <int LOOP>
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(CHAIN_BLOCK) __attribute__((amdgpu_waves_per_eu(SVM
     clock_probe_stamp(probe, 1);
 }
 
-// logsv_chain_rng_kernel for a launch of a few waves per SIMD (see logsv_rng_few_kernel): the same statements, the same bits
+// logsv_chain_rng_kernel for a launch of a few waves per SIMD (see logsv_rng_lat_kernel): the same statements, the same bits
 template <int LOOP, int WAVES, int TB>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void logsv_chain_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ sigma, double *__restrict__ qvar, size_t n, ChainSlices cs, uint64_t seed,
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(RNG ? RNG_BLOCK : BLOCK) void rough_logsv_expiries_
 #ifndef SVMC_HESTON_ATTR
 #define SVMC_HESTON_ATTR               // A/B hook (tools/ubench/build_variants.sh): e.g. __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-// FEW: the launch runs a few waves per SIMD (see logsv_rng_few_kernel): the draw's table reads of a call in flight together
+// LOOP: the form of the time loop (svmc_rng.h GenLoop): the full-launch kernels run GEN_LOOP_FULL, the few-waves ones GEN_LOOP_PAIR
 // kernel-template scheme ids: the C ABI's two (SVMC_HESTON_EULER_FLOOR = 0, SVMC_HESTON_QE = 1) and QE specialised at compile
 // time for parameter sets that never leave the quadratic branch and keep the martingale correction defined (QeConsts::quad_only
 // && e_below_one; heston_qe_step<true>) -- the host picks it, the caller never sees it
@@ -1676,8 +1676,8 @@ __global__ __launch_bounds__(RNG_BLOCK) SVMC_HESTON_ATTR void heston_rng_kernel(
     heston_rng_body<SCHEME, GEN_LOOP_FULL>(x, var, qvar, n, nb_steps, c, qc, seed, c3, path_offset, step_offset, so, init);
 }
 
-// the same generator for a launch of a few waves per SIMD (n_path <= few_waves_max_paths(); the reference's default is 10^5
-// paths): the statements -- and the bits -- of heston_rng_kernel, compiled for latency (see logsv_rng_few_kernel)
+// the same generator for a launch of a few waves per SIMD (few_waves_launch(); the reference's default is 10^5 paths): the
+// statements -- and the bits -- of heston_rng_kernel, compiled for latency (see logsv_rng_lat_kernel)
 template <int SCHEME, int LOOP, int WAVES, int TB>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void heston_rng_lat_kernel(
     double *__restrict__ x, double *__restrict__ var, double *__restrict__ qvar, size_t n, int nb_steps, HestonConsts c, QeConsts qc,
@@ -1894,7 +1894,6 @@ struct PayoffGroupPack {
 // output rows lie at fixed distances, and blockIdx.z picks the set: doubles between consecutive sets (zeros for one set)
 struct PayoffSetStrides {
     size_t x, q, spot;
-    size_t spot_partials = 0;  // doubles between consecutive sets' partial columns (PayoffGroup::spot_partials)
 };
 static_assert(sizeof(PayoffGroupPack) + sizeof(PayoffSetStrides) + 64 <= 4096, "the payoff descriptors travel in the kernel arguments");
 
@@ -1929,14 +1928,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(payoff_mi
         // [sum F exp(x), count] of this expiry from the generators' per-wave rows, in block_column_sum's order: the bits of
         // reduce_columns_kernel, formed by every block for itself (a few rows per thread out of L2) instead of by a launch
         __shared__ double s_spot[2];
-        const double *__restrict__ sp = d.spot_partials + set * sets.spot_partials;
+        const double *__restrict__ sp = d.spot_partials;   // (one-set launches only: payoff_sums_impl)
         double t0, t1;
         block_column_sum2(sp, sp + d.spot_rows, d.spot_rows, lds, t0, t1);
         if (threadIdx.x == 0) {
             s_spot[0] = t0;
             s_spot[1] = t1;
             if (blockIdx.x == 0 && d.spot_sums != nullptr) {        // ... and left where a separate reduce would have put them
-                double *out = const_cast<double *>(d.spot_sums) + set * sets.spot;
+                double *out = const_cast<double *>(d.spot_sums);
                 out[0] = t0;
                 out[1] = t1;
             }
@@ -3113,8 +3112,8 @@ static void launch_payoff_groups(int kt, dim3 grid, hipStream_t st, const Payoff
     hipLaunchKernelGGL(kern, grid, dim3(BLOCK), 0, st, pack, n, partials, ld, sets);
 }
 
-// spot_partials != null: the expiries' spot sums are formed inside the payoff kernel from the generators' per-wave partial columns
-// (expiry i's pair 2 spot_rows i doubles in; sets.spot_partials between sets) -- no reduce launch ahead of this one, and
+// spot_partials != null (one-set launches): the expiries' spot sums are formed inside the payoff kernel from the generators' per-wave
+// partial columns (expiry i's pair 2 spot_rows i doubles in) -- no reduce launch ahead of this one, and
 // spot_sums (nullable then) is only written.  partials_out != null: NO column reduce either -- the chain must fit one launch
 // (payoff_sets_fit) and the caller ends it with chain_finish (one wave per quote: the column sums, the prices' implied vols,
 // everything stored where the host reads it).
@@ -3133,6 +3132,8 @@ static int payoff_sums_impl(const char *fn, const double *const *xs, const doubl
     // chain must then fit ONE launch (payoff_sets_fit), whose path blocks are those of a one-set launch -- the same partial
     // sums added in the same order, hence the bits of n_sets calls
     const size_t total = offsets[n_expiries];
+    if (spot_partials != nullptr && n_sets != 1)
+        return fail(SVMC_ERR_INVALID_ARGUMENT, std::string(fn) + ": spot sums inside the payoff kernel are for one-set launches");
     bool any_inv = false;
     for (size_t k = 0; k < total; ++k) {
         if (types[k] < SVMC_CALL || types[k] > SVMC_INV_PUT)

@@ -482,9 +482,10 @@ def test_heston_qe_branches_the_parameters_decide(sv, oracle, tag, par):
     """the QE step skips what the parameters alone decide (svmc_models.h make_qe_consts: quad_only when volvol^2 <= 3 kappa theta,
     e_below_one when A <= 0): every combination -- never / sometimes / mostly exponential, rho of either sign and zero, vanishing
     vol of vol -- path by path against the CPU twin's textbook form on the same stream, one-slice kernel and chain kernel (few-waves
-    and full-launch forms), states and prices"""
+    and full-launch forms: 460 000 paths are past the seven-waves-per-SIMD switch), states and prices.  The two quadratic-only
+    sets with rho <= 0 run the kernels COMPILED without the exponential branch (HESTON_QE_QUAD), the others the general ones"""
     seed = 17
-    for n in (8192, 140_000):
+    for n in (8192, 140_000, 460_000):
         nb = 48
         eng = _engine(n)
         eng.fill_state(0.0, par["v0"], 0.0)
@@ -1553,7 +1554,8 @@ def test_one_device_tail_equals_five_node_tail(sv):
     partials themselves) and chain_finish_kernel (a wave per quote: the column sums, price -> implied vol, results stored in
     pinned memory) -- where round 5 ran reduce, payoff, reduce, [implied vols,] copy.  Every sum is formed in the same order of
     additions, so LogSV (chain with inverse options, one expiry, Q_VAR), Heston (Euler, QE) and the frozen-randoms objective
-    (one set, five sets, implied vols) must come out BIT FOR BIT the same either way, below and above the few-waves switch"""
+    (one set, five sets, implied vols: that route kept the five-node tail, so it checks nothing but itself) must come out BIT FOR
+    BIT the same either way, below and above the 2048-row switch of the in-kernel spot sums"""
     import json
     import subprocess
     import sys as _sys
@@ -1569,13 +1571,14 @@ def test_one_device_tail_equals_five_node_tail(sv):
     assert not diff, diff
 
 
-@pytest.mark.parametrize("n", [131072, 131073])
+@pytest.mark.parametrize("n", [131072, 131073, 458752, 458753])
 def test_few_waves_kernels_either_side_of_their_path_count(sv, oracle, n):
-    """up to two waves per SIMD (131072 paths) the on-device-RNG LogSV generators run as logsv_rng_few_kernel /
-    logsv_chain_rng_few_kernel (256-thread blocks, the draw's table reads of a call in flight together), above as the
-    full-launch kernels: the same statements -- path by path the CPU twin's numbers on the same stream either side of the
-    switch, for a chain (both kernels' slice loops, odd slice boundaries) and for one expiry, prices, standard errors and the
-    state the launch leaves behind"""
+    """up to seven waves per SIMD (458752 paths on an MI355X) the on-device-RNG LogSV generators run as logsv_rng_lat_kernel /
+    logsv_chain_rng_lat_kernel (256-thread blocks, the pipelined time loop), above as the full-launch kernels; 131072 paths are
+    the last launch whose payoff blocks sum the spot partials themselves (2048 rows), 131073 the first with a reduce launch ahead:
+    the same statements -- path by path the CPU twin's numbers on the same stream either side of both switches, for a chain
+    (both kernels' slice loops, odd slice boundaries) and for one expiry, prices, standard errors and the state the launch
+    leaves behind"""
     from stochvolmodels_amd.engine import get_engine
     P_ = sv.LOGSV_BTC_PARAMS
     seed, spy = 31, 60
