@@ -939,7 +939,7 @@ def test_vol_paths_resident_array_moments_and_pipelined_download(sv):
         np.testing.assert_allclose(mean[:, k], np.mean(m_k, axis=1), rtol=1e-11, atol=1e-13)
         np.testing.assert_allclose(std[:, k], np.std(m_k, axis=1), rtol=1e-9, atol=1e-12)
     q = dev.expanding_mean_of_squares()
-    want_q = pd.DataFrame(np.square(sig)).expanding(axis=0).mean().to_numpy()
+    want_q = pd.DataFrame(np.square(sig)).expanding().mean().to_numpy()
     np.testing.assert_allclose(q.numpy(), want_q, rtol=1e-13)
     q.free()
     mom = pricer.vol_path_moments(p, ttm=ttm, nb_path=n, seed=21, n_terms=4, with_qvar=True)
@@ -958,6 +958,30 @@ def test_vol_paths_resident_array_moments_and_pipelined_download(sv):
     eng = get_engine(1 << 22)
     np.testing.assert_array_equal(pipelined_download(eng.x.ptr, 1 << 22), x)
     np.testing.assert_array_equal(pipelined_download(eng.x.ptr + 8 * 12345, 999_983), x[12345:12345 + 999_983])
+
+
+@pytest.mark.parametrize("n", [4098, 4100, 1026, 130])
+def test_vol_path_reducers_on_even_and_misaligned_layouts(sv, n):
+    """the two streaming reducers on layouts that take their 16-byte forms: an even path count (expanding mean: two columns per
+    lane) whose quarter-row segments start on odd columns (row sums: the segment's first element peeled to reach a 16-byte
+    boundary) and end with an odd element -- against NumPy / pandas on the host copy of the same array"""
+    import pandas as pd
+    p = sv.LogSvParams(sigma0=0.9, theta=1.0, kappa1=3.0, kappa2=3.0, beta=0.1, volvol=1.4)
+    dev, _ = sv.LogSVPricer().simulate_vol_paths(p, ttm=0.3, nb_path=n, nb_steps=77, seed=3, return_device=True)
+    sig = dev.numpy()
+    mean, std = dev.row_moments(center=p.theta, n_moments=4)
+    for k in range(4):
+        m_k = np.power(sig - p.theta, k + 1)
+        np.testing.assert_allclose(mean[:, k], np.mean(m_k, axis=1), rtol=1e-11, atol=1e-13)
+        # (row 0 is the common start value: its exact standard deviation is 0, and E[d^2] - E[d]^2 leaves the rounding of two
+        # equal numbers under the square root -- 1e-10 -- whichever kernel formed the sums)
+        np.testing.assert_allclose(std[1:, k], np.std(m_k, axis=1)[1:], rtol=1e-9, atol=1e-12)
+        assert np.all(std[0] < 1e-8)
+    q = dev.expanding_mean_of_squares()
+    want = pd.DataFrame(np.square(sig)).expanding().mean().to_numpy()
+    np.testing.assert_allclose(q.numpy(), want, rtol=1e-13)
+    q.free()
+    dev.free()
 
 
 def test_vol_paths_ragged_sizes(sv, oracle):
