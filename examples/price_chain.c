@@ -1,7 +1,8 @@
 /*
  * price_chain.c -- a plain-C host of libsvmc.so: prices a two-expiry LogSV chain and a one-expiry Heston chain by
  * Monte Carlo on the GPU through the fused chain drivers of include/svmc.h, re-prices one expiry on fixed randoms
- * resident in HBM (the calibration inner loop) and prints the results as JSON.
+ * resident in HBM (the calibration inner loop), prices the LogSV chain once more on state arrays it owns itself
+ * (svmc_session_create_on) and prints the results as JSON.
  *
  *   gcc -O2 -Iinclude examples/price_chain.c -o price_chain -Lstochvolmodels_amd -lsvmc \
  *       -Wl,-rpath,$PWD/stochvolmodels_amd -lm
@@ -85,10 +86,34 @@ int main(int argc, char **argv)
     print_array("fixed_prices", fixed_prices, 6, 0);
     CHECK(svmc_black_implied_vols(fixed_prices + 1, strikes + 1, types + 1, 1, forwards[0], ttms[0], discfactors[0], 1e-6,
                                   10.0, ivol));
-    print_array("atm_call_ivol", ivol, 1, 1);
-    printf("}\n");
+    print_array("atm_call_ivol", ivol, 1, 0);
     CHECK(svmc_free(w0));
     CHECK(svmc_free(w1));
+
+    /* A host that keeps the state arrays itself (svmc_session_create_on: what the Python host does on one GPU): the session
+     * allocates only its snapshots and scratch, the fused driver leaves the terminal (x, sigma, qvar) of every path in the
+     * caller's arrays, and destroying the session frees neither them nor the stream.  Same kernels, same bits. */
+    double *x = NULL, *sigma = NULL, *qvar = NULL, own_prices[6], own_stderrs[6], head[3][4];
+    svmc_session_t on_mine;
+    CHECK(svmc_malloc((void **)&x, sizeof(double) * n_path));
+    CHECK(svmc_malloc((void **)&sigma, sizeof(double) * n_path));
+    CHECK(svmc_malloc((void **)&qvar, sizeof(double) * n_path));
+    CHECK(svmc_session_create_on(&on_mine, n_path, 2, 6, x, sigma, qvar, /*path_offset*/ 0, /*stream*/ NULL));
+    CHECK(svmc_logsv_chain_price(on_mine, ttms, forwards, discfactors, NULL, 2, strikes, types, offsets, 0.8376, 1.0413, 3.1844,
+                                 3.058, 0.1514, 1.8458, 1, 120, SVMC_LOG_RETURN, seed, 0, own_prices, own_stderrs));
+    CHECK(svmc_session_destroy(on_mine));
+    CHECK(svmc_memcpy_d2h(head[0], x, sizeof(double) * 4, NULL));          /* still ours, and holding the terminal state */
+    CHECK(svmc_memcpy_d2h(head[1], sigma, sizeof(double) * 4, NULL));
+    CHECK(svmc_memcpy_d2h(head[2], qvar, sizeof(double) * 4, NULL));
+    CHECK(svmc_stream_synchronize(NULL));
+    print_array("logsv_prices_on_caller_state", own_prices, 6, 0);
+    print_array("terminal_x_head", head[0], 4, 0);
+    print_array("terminal_sigma_head", head[1], 4, 0);
+    print_array("terminal_qvar_head", head[2], 4, 1);
+    printf("}\n");
+    CHECK(svmc_free(x));
+    CHECK(svmc_free(sigma));
+    CHECK(svmc_free(qvar));
 
     CHECK(svmc_session_destroy(session));
     return 0;

@@ -1693,6 +1693,14 @@ def test_c_host_example(sv, tmp_path):
                                       seed=123)
     np.testing.assert_array_equal(np.concatenate(pr), out["logsv_prices"])
     np.testing.assert_array_equal(np.concatenate(sd), out["logsv_stderrs"])
+    # ... and the same chain on state arrays the C host owns (svmc_session_create_on): the same prices, and the terminal state of
+    # the first paths where the host left its arrays -- the Python engine's, which is driven through that very entry point
+    np.testing.assert_array_equal(out["logsv_prices_on_caller_state"], out["logsv_prices"])
+    from stochvolmodels_amd.engine import get_engine
+    gx, gs, gq = get_engine(65536).get_state()
+    np.testing.assert_array_equal(gx[:4], out["terminal_x_head"])
+    np.testing.assert_array_equal(gs[:4], out["terminal_sigma_head"])
+    np.testing.assert_array_equal(gq[:4], out["terminal_qvar_head"])
     pr, sd = sv.heston_mc_chain_pricer(ttms=ttms[:1], forwards=fw[:1], discfactors=df[:1], strikes_ttms=strikes[:1],
                                        optiontypes_ttms=types[:1], v0=0.04, theta=0.04, kappa=4.0, rho=-0.5, volvol=0.4,
                                        nb_path=65536, seed=123)
