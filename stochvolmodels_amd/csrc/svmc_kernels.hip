@@ -429,9 +429,10 @@ __device__ __forceinline__ void logsv_gen_time_loop(const PhiloxLane &lane, uint
 {
     if constexpr (LOOP == GEN_LOOP_PIPE) {
         LogsvStepInFlight h;
+        const Exp2uTailV k = exp2u_tail_consts();
         rng_time_loop_pipelined(
             lane, step0, nb, tab, [&](double z0, double z1) { logsv_step_acc_front(c, xacc, L, s, z0, z1, exp_table, h); },
-            [&]() { logsv_step_acc_back(s, acc, h); });
+            [&]() { logsv_step_acc_mid(h, k); }, [&]() { logsv_step_acc_back(s, acc, h); });
     } else {
         double s2_unused = 0.0;
         gen_time_loop<LOOP>(lane, step0, nb, tab, [&](double z0, double z1) {

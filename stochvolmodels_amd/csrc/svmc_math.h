@@ -245,6 +245,29 @@ SVMC_HD double exp2u_tail(double r)
     return q * r;
 }
 
+// exp2u_tail with its four coefficients in VECTOR registers the caller keeps across its time loop (the few-waves generators:
+// registers to spare, and every instruction of a lone wave is an issue slot): plain v_fma_f64 on the same operands -- the same
+// bits as exp2u_tail -- but no inline assembly in the loop, so the scheduler may interleave the chain with the draw's integer
+// work and the hazard recogniser does not pad each step of it with an s_nop.
+struct Exp2uTailV {
+    double k0, k1, k2, k3;
+};
+SVMC_HD Exp2uTailV exp2u_tail_consts()
+{
+    Exp2uTailV c{0x1.3b2ab8452c312p-39, 0x1.c6b0903967234p-29, 0x1.ebfbdff82c584p-19, 0x1.62e42fefa39d8p-9};
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(c.k0), "+v"(c.k1), "+v"(c.k2), "+v"(c.k3));
+#endif
+    return c;
+}
+SVMC_HD double exp2u_tail_v(double r, const Exp2uTailV &c)
+{
+    double q = fma(c.k0, r, c.k1);
+    q = fma(q, r, c.k2);
+    q = fma(q, r, c.k3);
+    return q * r;
+}
+
 SVMC_HD double exp2u_scale(double t, double p, int ni)
 {
     return ldexp(fma(t, p, t), ni >> 8);
@@ -255,7 +278,12 @@ SVMC_HD double exp2u_tab(double y, const double *tab)
     int ni;
     double r;
     exp2u_reduce(y, ni, r);
+#if defined(SVMC_PROBE) && (SVMC_PROBE & 1)          // measurement build: no exp-table read
+    const double t = 1.0;
+    (void)tab;
+#else
     const double t = tab[ni & 255];
+#endif
     return exp2u_scale(t, exp2u_tail(r), ni);
 }
 
@@ -369,8 +397,14 @@ SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
     const uint32_t hi = double_hi(t);
     const uint32_t off = (hi >> (16 - M)) & ((static_cast<uint32_t>(SEGMENTS) - 1u) << 4);
     const char *base = reinterpret_cast<const char *>(tab) + off;
+#if defined(SVMC_PROBE) && (SVMC_PROBE & 2)          // measurement build: no table reads in the draw
+    const IcdfPiece e0 = IcdfPiece{1e-10 * off, 1e-10};
+    const IcdfPiece e1 = IcdfPiece{1e-20, 1e-30};
+    (void)base;
+#else
     const IcdfPiece e0 = *reinterpret_cast<const IcdfPiece *>(base);
     const IcdfPiece e1 = *reinterpret_cast<const IcdfPiece *>(base + 16 * SEGMENTS);
+#endif
     double p;
     if (RAW) {
         // pieces {a0, a1}, {a2, a3}: the cubic in |t| ITSELF.  Re-expanding a segment's polynomial about 0 makes its terms

@@ -156,7 +156,7 @@ __device__ __forceinline__ void logsv_step_acc(const LogsvFast &f, double &xacc,
 // front = everything up to the ISSUE of the table read, back = what consumes the value.  logsv_step_acc's operations with
 // exp2u_tab as the exponential, in its order: the same bits.
 struct LogsvStepInFlight {
-    double r, t;
+    double r, t, p;
     int ni;
 };
 __device__ __forceinline__ void logsv_step_acc_front(const LogsvFast &f, double &xacc, double &L, double sigma, double z0, double z1,
@@ -170,11 +170,21 @@ __device__ __forceinline__ void logsv_step_acc_front(const LogsvFast &f, double 
     L = fma(f.bs, z0, L);
     L = fma(f.es, z1, L);
     exp2u_reduce(L, h.ni, h.r);
+#if defined(SVMC_PROBE) && (SVMC_PROBE & 1)          // measurement build: no exp-table read on the step's chain
+    h.t = 1.0;
+#else
     h.t = exp_table[h.ni & 255];
+#endif
+}
+// the exponential's polynomial tail: needs the reduced argument only, so it runs in the loop's middle region, among the draw's
+// integer work, instead of as a dependent chain (with its hazard s_nop's) right before the table value is consumed
+__device__ __forceinline__ void logsv_step_acc_mid(LogsvStepInFlight &h, const Exp2uTailV &k)
+{
+    h.p = exp2u_tail_v(h.r, k);
 }
 __device__ __forceinline__ void logsv_step_acc_back(double &sigma, double &acc, const LogsvStepInFlight &h)
 {
-    const double sn = exp2u_scale(h.t, exp2u_tail(h.r), h.ni);
+    const double sn = exp2u_scale(h.t, h.p, h.ni);
     acc = fma(sn, sn, acc);
     sigma = sn;
 }

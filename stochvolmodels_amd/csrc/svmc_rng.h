@@ -205,6 +205,7 @@ __device__ __forceinline__ PhiloxLane philox_prepare(uint64_t seed, uint32_t c3,
     return l;
 }
 
+template <bool HOIST_KEYS = false>
 __device__ __forceinline__ void philox_draw(const PhiloxLane &l, uint32_t step, uint32_t (&r)[4])
 {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -218,7 +219,9 @@ __device__ __forceinline__ void philox_draw(const PhiloxLane &l, uint32_t step, 
     // the round keys are re-derived from (k0, k1) with scalar adds on every call: hoisted out of the time loop (what the
     // compiler does by itself) they would occupy a dozen SGPRs of a budget the loop already fills, and the spills come
     // back as v_readlane_b32 -- VALU instructions on the one port this loop is bound by
-    asm volatile("" : "+s"(k0), "+s"(k1));
+    // (HOIST_KEYS: the few-waves kernels, whose loop leaves two dozen SGPRs free -- there a wave issues one instruction of ANY
+    // kind per ~4.5 cycles, so the twelve scalar adds of a call are twelve issue slots of the one wave a SIMD has)
+    if constexpr (!HOIST_KEYS) asm volatile("" : "+s"(k0), "+s"(k1));
     c0 = l.hi_b ^ __builtin_amdgcn_readfirstlane(c1_r1 ^ k0);              // (uniform ^ uniform) stays on the scalar unit
     uint32_t c2 = __builtin_amdgcn_bitop3_b32(static_cast<uint32_t>(p0 >> 32), l.lo0, k1, 0x96);
     uint32_t c1 = l.lo_b;
@@ -471,8 +474,14 @@ __device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTa
         d.t[k] = static_cast<double>(static_cast<int32_t>(w[k])) + 0.5;
         const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
         const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
+#if defined(SVMC_PROBE) && (SVMC_PROBE & 2)          // measurement build: no table reads in the draw
+        d.e0[k] = IcdfPiece{1e-10 * off, 1e-10};
+        d.e1[k] = IcdfPiece{1e-20, 1e-30};
+        (void)base;
+#else
         d.e0[k] = *reinterpret_cast<const IcdfPiece *>(base);
         d.e1[k] = *reinterpret_cast<const IcdfPiece *>(base + 16 * SVMC_ICDF_SEGMENTS);
+#endif
     }
 }
 __device__ __forceinline__ void pair_finish(const PairInFlight &d, double &z0, double &z1)
@@ -491,6 +500,10 @@ __device__ __forceinline__ void pair_finish(const PairInFlight &d, double &z0, d
 }
 #endif
 
+// SVMC_PIPE_HOIST_KEYS (A/B hook, default 1): the few-waves loops below draw with the round keys hoisted out of the time loop
+#ifndef SVMC_PIPE_HOIST_KEYS
+#define SVMC_PIPE_HOIST_KEYS 1
+#endif
 // rng_time_loop with ONE PAIR ahead: the table reads of the next step's two normals are issued before this step runs and
 // their cubics evaluated after it -- half the registers of rng_time_loop_ahead (one pair in flight, not four normals), for
 // launches that still want five to seven waves per SIMD.  Same words, same operations: the same bits.
@@ -521,7 +534,7 @@ __device__ __forceinline__ void rng_time_loop_pair_ahead(const PhiloxLane &lane,
             __builtin_amdgcn_sched_barrier(0);
             step(z0, z1);
             pair_finish(d, z0, z1);
-            philox_draw(lane, c + 1u, r);                  // the last trip draws a call nobody uses (no branch in the trip)
+            philox_draw<SVMC_PIPE_HOIST_KEYS != 0>(lane, c + 1u, r);   // the last trip draws a call nobody uses (no branch in the trip)
             pair_issue(r[0], r[1], tab, d);
             __builtin_amdgcn_sched_barrier(0);
             step(z0, z1);
@@ -541,9 +554,9 @@ __device__ __forceinline__ void rng_time_loop_pair_ahead(const PhiloxLane &lane,
 // that -- whose reads are younger than the step's own, so back() waits for the exp value only (s_waitcnt lgkmcnt(4)) and the
 // pair's four reads stay in flight under back() and the next front().  A lone wave thus overlaps its own LDS round trips with
 // its own arithmetic, and the waves of a CU cannot fall into a common LDS phase.  Same words, same operations: the same bits.
-template <class Front, class Back>
+template <class Front, class Mid, class Back>
 __device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
-                                                        Front &&front, Back &&back)
+                                                        Front &&front, Mid &&mid, Back &&back)
 {
     if (nb <= 0) return;
     const uint32_t first = step0, last = step0 + static_cast<uint32_t>(nb) - 1u;
@@ -553,6 +566,7 @@ __device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, 
         philox_draw(lane, c, r);
         normals_from_words(r[2], r[3], tab, a0, a1);
         front(a0, a1);
+        mid();
         back();
         ++c;
     }
@@ -569,14 +583,16 @@ __device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, 
             front(z0, z1);                                 // step 2c; its table read is now the youngest LDS operation
             __builtin_amdgcn_sched_barrier(0);
             pair_finish(d, z0, z1);                        // the normals of step 2c + 1
-            philox_draw(lane, c + 1u, r);                  // the last trip draws a call nobody uses (no branch in the trip)
+            philox_draw<SVMC_PIPE_HOIST_KEYS != 0>(lane, c + 1u, r);   // the last trip draws a call nobody uses (no branch in the trip)
             pair_issue(r[0], r[1], tab, d);                // ... of step 2c + 2: in flight under back() and the next front()
+            mid();                                         // what of the step needs neither the table value nor another wave's time
             __builtin_amdgcn_sched_barrier(0);
             back();
             front(z0, z1);                                 // step 2c + 1
             __builtin_amdgcn_sched_barrier(0);
             pair_finish(d, z0, z1);                        // the normals of step 2c + 2
             pair_issue(r[2], r[3], tab, d);                // ... of step 2c + 3
+            mid();
             __builtin_amdgcn_sched_barrier(0);
             back();
         }
@@ -585,8 +601,16 @@ __device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, 
         philox_draw(lane, last >> 1, r);
         normals_from_words(r[0], r[1], tab, a0, a1);
         front(a0, a1);
+        mid();
         back();
     }
+}
+
+template <class Front, class Back>
+__device__ __forceinline__ void rng_time_loop_pipelined(const PhiloxLane &lane, uint32_t step0, int nb, const RngTables &tab,
+                                                        Front &&front, Back &&back)
+{
+    rng_time_loop_pipelined(lane, step0, nb, tab, front, []() {}, back);
 }
 
 // the three forms of the generators' time loop, by launch size (generator_loop_for() in svmc_kernels.hip picks)
