@@ -1038,10 +1038,19 @@ void logsv_chain_rng_sets_kernel(size_t n, ChainRngSetsSlices cs, const LogsvFas
             // round 6: the generators' pipelined loop -- the step in two halves around its P exp-table reads, the next pair's
             // cubics, the next Philox call and the issue of the pair after that between them (rng_time_loop_pipelined)
             LogsvSetsInFlight<P> h;
-            rng_time_loop_pipelined(
-                lane, tg, nb, tab,
-                [&](double z0, double z1) { logsv_step_acc_sets_front<P>(k1, k2, k3, kb, ke, xacc, L, sg, z0, z1, s_exp, h); },
-                [&]() { logsv_step_acc_sets_back<P>(sg, acc, h); });
+            if constexpr (P <= 6) {
+                // the tails in the middle region on coefficients in vector registers (seven sets have no registers left for them)
+                const Exp2uTailV tail_k = exp2u_tail_consts();
+                rng_time_loop_pipelined(
+                    lane, tg, nb, tab,
+                    [&](double z0, double z1) { logsv_step_acc_sets_front<P>(k1, k2, k3, kb, ke, xacc, L, sg, z0, z1, s_exp, h); },
+                    [&]() { logsv_step_acc_sets_mid<P>(h, tail_k); }, [&]() { logsv_step_acc_sets_back<P, true>(sg, acc, h); });
+            } else {
+                rng_time_loop_pipelined(
+                    lane, tg, nb, tab,
+                    [&](double z0, double z1) { logsv_step_acc_sets_front<P>(k1, k2, k3, kb, ke, xacc, L, sg, z0, z1, s_exp, h); },
+                    [&]() { logsv_step_acc_sets_back<P>(sg, acc, h); });
+            }
         } else if (nb > 0) {
             // rng_time_loop's rule -- call c serves the steps 2c (words 0, 1) and 2c + 1 (words 2, 3) -- as an odd-start half
             // call, the full calls, an even-end half call

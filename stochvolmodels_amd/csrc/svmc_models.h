@@ -258,11 +258,20 @@ __device__ __forceinline__ void logsv_step_acc_sets_front(const double (&c1)[P],
 #pragma unroll
     for (int s = 0; s < P; ++s) h.t[s] = exp_table[h.ni[s] & 255];
 }
+// (the tails in the loop's middle region, on coefficients in vector registers: see logsv_step_acc_mid)
 template <int P>
-__device__ __forceinline__ void logsv_step_acc_sets_back(double (&sigma)[P], double (&acc)[P], LogsvSetsInFlight<P> &h)
+__device__ __forceinline__ void logsv_step_acc_sets_mid(LogsvSetsInFlight<P> &h, const Exp2uTailV &k)
 {
 #pragma unroll
-    for (int s = 0; s < P; ++s) h.r[s] = exp2u_tail(h.r[s]);
+    for (int s = 0; s < P; ++s) h.r[s] = exp2u_tail_v(h.r[s], k);
+}
+template <int P, bool TAILS_DONE = false>
+__device__ __forceinline__ void logsv_step_acc_sets_back(double (&sigma)[P], double (&acc)[P], LogsvSetsInFlight<P> &h)
+{
+    if constexpr (!TAILS_DONE) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) h.r[s] = exp2u_tail(h.r[s]);
+    }
 #pragma unroll
     for (int s = 0; s < P; ++s) {
         const double sn = exp2u_scale(h.t[s], h.r[s], h.ni[s]);
