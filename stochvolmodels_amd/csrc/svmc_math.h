@@ -398,7 +398,8 @@ SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
     const uint32_t off = (hi >> (16 - M)) & ((static_cast<uint32_t>(SEGMENTS) - 1u) << 4);
     const char *base = reinterpret_cast<const char *>(tab) + off;
 #if defined(SVMC_PROBE) && (SVMC_PROBE & 2)          // measurement build: no table reads in the draw
-    const IcdfPiece e0 = IcdfPiece{1e-10 * off, 1e-10};
+    asm volatile("" : : "v"(off));                     // the offset is still computed: the VALU stream is the product's
+    const IcdfPiece e0 = IcdfPiece{1e-10, 1e-10};
     const IcdfPiece e1 = IcdfPiece{1e-20, 1e-30};
     (void)base;
 #else

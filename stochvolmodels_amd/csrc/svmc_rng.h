@@ -475,7 +475,8 @@ __device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTa
         const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
         const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
 #if defined(SVMC_PROBE) && (SVMC_PROBE & 2)          // measurement build: no table reads in the draw
-        d.e0[k] = IcdfPiece{1e-10 * off, 1e-10};
+        asm volatile("" : : "v"(off));                 // the offset is still computed: the VALU stream is the product's
+        d.e0[k] = IcdfPiece{1e-10, 1e-10};
         d.e1[k] = IcdfPiece{1e-20, 1e-30};
         (void)base;
 #else
