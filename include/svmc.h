@@ -68,8 +68,10 @@ SVMC_API int svmc_version(void);
 /* The version of the counter-based random stream the generators draw from (SVMC_RNG_STREAM_VERSION): results for a
  * given seed are reproducible only within one stream version.  1 = Philox4x32-10 + 52-bit Box-Muller (round 1);
  * 2 = Philox4x32-7, one call per two steps, 32-bit radius / angle Box-Muller (round 2); 3 = Philox4x32-7, one call per two
- * steps, each 32-bit word turned into one normal by a piecewise-cubic inverse CDF (round 3).  CHANGELOG.md. */
-#define SVMC_RNG_STREAM_VERSION 3
+ * steps, each 32-bit word turned into one normal by a piecewise-cubic inverse CDF on the lattice (int32) word + 1/2 (round 3);
+ * 4 = the same on the lattice (int32) word itself -- one instruction less per normal, still exactly symmetric (round 6).
+ * CHANGELOG.md. */
+#define SVMC_RNG_STREAM_VERSION 4
 SVMC_API int svmc_rng_stream_version(void);
 SVMC_API const char *svmc_last_error(void);
 SVMC_API int svmc_device_count(int *count);
@@ -117,7 +119,7 @@ SVMC_API int svmc_fill_state(double *x, double *vol, double *qvar, size_t n_path
  * pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370) ------------------------------
  * Philox4x32-7, key = seed, counter = (path_lo, path_hi, call index, stream | call_id << 8).  Stream 0: one call
  * serves the two normals (w0, w1) of each of the two time steps 2c, 2c + 1: every 32-bit word becomes one N(0,1)
- * variate by a piecewise-cubic inverse normal CDF (stream version 3, |z| <= 6.34); stream 1: one 52-bit uniform in
+ * variate by a piecewise-cubic inverse normal CDF (stream version 4, |z| <= 6.23); stream 1: one 52-bit uniform in
  * (0,1) per call.  `path` is the GLOBAL path id path_offset + p, `step` the chain-global step id step_offset + t, so
  * results do not depend on how paths are sharded over GPUs or how a chain is sliced.  `call_id` distinguishes the
  * calls of one seed: it occupies 24 bits of the counter (every entry point rejects call_id >= 2^24), so a host that

@@ -289,12 +289,13 @@ int svo_payoff(size_t n_path, const double *x, const double *qvar,
  * checked at its 10-round setting against the Random123 known-answer vectors in tests/test_oracle_golden.py).
  * The svmc streams use SEVEN rounds, the smallest Crush-resistant count the paper reports for 4x32.
  *
- * svmc stream definition, version 3 (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h).
+ * svmc stream definition, version 4 (DESIGN.md section "RNG"; device twin stochvolmodels_amd/csrc/svmc_rng.h).
  * One call yields the two normals of TWO consecutive time steps, each 32-bit word turned into ONE N(0,1) variate by
  * inversion:
  *   key = (seed_lo, seed_hi);  ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8)
  *   r0..r3 = philox4x32_7(ctr, key);  (ra, rb) = (r0, r1) for an even step, (r2, r3) for an odd one
- *   z(r):  t = (int32) r + 1/2 (symmetric about 0, never 0);  j = the segment of |t| -- (low 5 bits of the biased fp64
+ *   z(r):  t = (int32) r (version 3: + 1/2; here z = 0 at t = 0 and |t| = 2^31, every other magnitude with both signs);
+ *          j = the segment of |t| -- (low 5 bits of the biased fp64
  *          exponent) << M | (top M mantissa bits), 32 octaves x 2^M equal parts;
  *          z = sign(t) * fma(fma(fma(a3, |t|, a2), |t|, a1), |t|, a0)  with {a0..a3}[j] from svo_icdf_table.h, the
  *          piecewise cubic of -Phi^-1(|t| 2^-32) generated by tools/gen_icdf_table.py (the same bytes as the product's
@@ -351,7 +352,11 @@ static const double svo_icdf_p1[SVMC_ICDF_SEGMENTS][2] = { SVMC_ICDF_PIECE1_INIT
 /* one N(0,1) variate from one word (svmc_math.h normal_icdf32) */
 double svo_normal_from_word(uint32_t w)
 {
-    const double t = (double)(int32_t)w + 0.5;
+#if SVMC_ICDF_HALF_LATTICE
+    const double t = (double)(int32_t)w + 0.5;        /* stream version 3's lattice */
+#else
+    const double t = (double)(int32_t)w;              /* stream version 4: the signed word itself (z = 0 at t = 0 and |t| = 2^31) */
+#endif
     uint64_t bits;
     memcpy(&bits, &t, 8);
     const uint32_t hi = (uint32_t)(bits >> 32);

@@ -74,7 +74,7 @@ void svo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* The svmc draw (stream definition version 2, svmc_oracle.c): counter = (path_lo, path_hi, call index, stream |
  * call_id << 8), key = seed.  stream 0 -> the Box-Muller pair (w0, w1) of a time step (call step >> 1, half step & 1);
  * stream 1 -> one uniform in (0,1) (call = step). */
-/* one N(0,1) variate from one 32-bit word: the piecewise cubic of the inverse normal CDF (stream version 3) */
+/* one N(0,1) variate from one 32-bit word: the piecewise cubic of the inverse normal CDF (stream version 4) */
 double svo_normal_from_word(uint32_t w);
 void svo_draw_normals(uint64_t seed, uint32_t call_id, uint64_t path, uint32_t step,
                       double *w0, double *w1);

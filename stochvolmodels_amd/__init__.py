@@ -18,7 +18,7 @@ import importlib
 __version__ = "0.3.0"
 # the counter-based random stream the generators draw from (include/svmc.h SVMC_RNG_STREAM_VERSION, CHANGELOG.md): results
 # for a given seed are reproducible within one stream version
-RNG_STREAM_VERSION = 3
+RNG_STREAM_VERSION = 4
 
 _EXPORTS = {
     "OptionType": "utils.config", "VariableType": "utils.config",

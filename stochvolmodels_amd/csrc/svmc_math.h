@@ -370,9 +370,10 @@ SVMC_HD double neg_log_tab(double u, const LogTabEntry *tab)
     return fma(-dk, 0x1.62e42fefa39efp-1, nl);
 }
 
-// One N(0,1) variate from ONE 32-bit word by inversion (random stream version 3, tools/gen_icdf_table.py): the word is
-// read as a signed integer k, t = k + 1/2 is symmetric about 0 and never 0, and
-//     z = sign(t) P_j(|t| - c_j)   ~   sign(t) * -Phi^-1(|t| 2^-32),      |z| <= 6.34
+// One N(0,1) variate from ONE 32-bit word by inversion (random stream version 4, tools/gen_icdf_table.py): the word is
+// read as a signed integer t = k (version 3: k + 1/2 -- an add per normal that bought nothing: the magnitudes 1 .. 2^31 - 1
+// occur with both signs either way, and the two unpaired words k = 0 and k = -2^31 sit where the function is 0), and
+//     z = sign(t) P_j(|t| - c_j)   ~   sign(t) * -Phi^-1(|t| 2^-32),      |z| <= 6.23,  z = 0 for t = 0 and |t| = 2^31
 // with P_j the segment's cubic.  The segment index is read off the high word of t -- five exponent bits and the top
 // SVMC_ICDF_M mantissa bits: 32 octaves x 2^M equal parts, i.e. geometric spacing towards the tail where Phi^-1 is singular
 // -- by one shift and one mask that leave the BYTE offset of the segment's 16-byte pieces; the pieces sit in arrays one
@@ -390,10 +391,27 @@ struct alignas(16) IcdfPiece {
     double a, b;
 };
 
+// the lattice point of a word: the signed integer itself (stream version 4: magnitudes 0 .. 2^31, both ends map to z = 0, every
+// other magnitude occurs with both signs -- exactly symmetric with no add), or k + 1/2 (version 3's table: SVMC_ICDF_HALF_LATTICE)
+#ifndef SVMC_ICDF_HALF_LATTICE
+#define SVMC_ICDF_HALF_LATTICE 0
+#endif
+SVMC_HD double icdf_lattice_point(uint32_t w)
+{
+#if SVMC_ICDF_HALF_LATTICE
+    return static_cast<double>(static_cast<int32_t>(w)) + 0.5;
+#else
+    return static_cast<double>(static_cast<int32_t>(w));
+#endif
+}
+
 template <int M, int SEGMENTS, int DEG, bool EDGE = false, bool RAW = false>
 SVMC_HD double normal_icdf32(uint32_t w, const IcdfPiece *tab)
 {
-    const double t = static_cast<double>(static_cast<int32_t>(w)) + 0.5;
+#if !SVMC_ICDF_HALF_LATTICE
+    static_assert(RAW, "the integer lattice needs the raw form: t = 0 reads segment 0, whose line passes through the origin");
+#endif
+    const double t = icdf_lattice_point(w);
     const uint32_t hi = double_hi(t);
     const uint32_t off = (hi >> (16 - M)) & ((static_cast<uint32_t>(SEGMENTS) - 1u) << 4);
     const char *base = reinterpret_cast<const char *>(tab) + off;

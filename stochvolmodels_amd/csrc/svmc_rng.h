@@ -7,19 +7,19 @@
 // GPUs.  Replaces the reference's serial MT19937+polar draw of two [nb_steps, nb_path] arrays
 // (pricers/logsv_pricer.py:1025-1026, pricers/heston_pricer.py:369-370).
 //
-// Stream definition, version 3 (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals).  One call yields
+// Stream definition, version 4 (DESIGN.md "RNG"; CPU twin: oracle/svmc_oracle.c svo_draw_normals).  One call yields
 // four 32-bit words = the two normals of TWO consecutive time steps, each word turned into ONE N(0,1) variate by
 // inversion:
 //   (r0, r1, r2, r3) = philox4x32_7(ctr = (path_lo, path_hi, step >> 1, stream | call_id << 8), key = seed)
 //   (ra, rb) = (r0, r1) for an even chain-global step index, (r2, r3) for an odd one
-//   z(r) = sign(t) P_j(|t| - c_j),  t = (int32) r + 1/2:  the piecewise cubic of -Phi^-1(|t| 2^-32) of
-//          svmc_icdf_table.h (tools/gen_icdf_table.py; svmc_math.h normal_icdf32), |z| <= 6.34
+//   z(r) = sign(t) P_j(|t| - c_j),  t = (int32) r  (version 3: + 1/2):  the piecewise cubic of -Phi^-1(|t| 2^-32) of
+//          svmc_icdf_table.h (tools/gen_icdf_table.py; svmc_math.h normal_icdf32), |z| <= 6.23, z = 0 at t = 0 and |t| = 2^31
 //   (w0, w1) = (z(ra), z(rb))
 //   stream 1:  uniform = 52 bits of r1:r0 (one call per draw);  Heston QE: normals from stream 4 (as stream 0), the
 //   exponential branch's uniform (r[step & 3] + 1/2) 2^-32 of stream 5's call step >> 2, drawn lazily.
 // Resolution: a normal carries 32 random bits (as in version 2, whose Box-Muller pair spent 32 on the radius and 32 on
-// the angle); the lattice is 2^-32 in probability, symmetric about 0, largest |z| = -Phi^-1(2^-33) = 6.34 (truncated
-// mass 2.3e-10 per normal).  The cubic deviates from the exact inverse CDF by at most SVMC_ICDF_MAX_ABS_ERROR (7.431e-10,
+// the angle); the lattice is 2^-32 in probability, symmetric about 0 (every magnitude 1 .. 2^31 - 1 with both signs, two words
+// at 0), largest |z| = -Phi^-1(2^-32) = 6.23 (truncated mass 4.7e-10 per normal).  The cubic deviates from the exact inverse CDF by at most SVMC_ICDF_MAX_ABS_ERROR (7.431e-10,
 // svmc_icdf_table.h) -- a smooth deterministic distortion five orders below the Monte Carlo error of any chain priced here, pinned against
 // scipy's Phi^-1 in tests/test_oracle_golden.py.
 #pragma once
@@ -268,7 +268,7 @@ __device__ __forceinline__ double uniform_32(uint32_t k)
 #if SVMC_ICDF_MIXED
 __device__ __forceinline__ double normal_icdf32_mixed(uint32_t w, const IcdfPiece *tab)
 {
-    const double t = static_cast<double>(static_cast<int32_t>(w)) + 0.5;
+    const double t = icdf_lattice_point(w);
     const uint32_t hi = double_hi(t);
     const uint32_t off = (hi >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
     const char *base = reinterpret_cast<const char *>(tab);
@@ -316,7 +316,7 @@ __device__ __forceinline__ void draw_issue(const uint32_t (&r)[4], const RngTabl
     static_assert(SVMC_ICDF_RAW != 0, "the split draw is written for the raw form of the table");
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        d.t[k] = static_cast<double>(static_cast<int32_t>(r[k])) + 0.5;
+        d.t[k] = icdf_lattice_point(r[k]);
         const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
         const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
         d.e0[k] = *reinterpret_cast<const IcdfPiece *>(base);
@@ -471,7 +471,7 @@ __device__ __forceinline__ void pair_issue(uint32_t ra, uint32_t rb, const RngTa
     const uint32_t w[2] = {ra, rb};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        d.t[k] = static_cast<double>(static_cast<int32_t>(w[k])) + 0.5;
+        d.t[k] = icdf_lattice_point(w[k]);
         const uint32_t off = (double_hi(d.t[k]) >> (16 - SVMC_ICDF_M)) & ((static_cast<uint32_t>(SVMC_ICDF_SEGMENTS) - 1u) << 4);
         const char *base = reinterpret_cast<const char *>(tab.icdf) + off;
 #if defined(SVMC_PROBE) && (SVMC_PROBE & 2)          // measurement build: no table reads in the draw

@@ -13,7 +13,7 @@ holds with the committed build:
   * terminal states path by path, |gpu - cpu| / (1 + |cpu|),
   * prices and standard errors, |gpu - cpu| / (|cpu| + 1e-3 x forward)   [Q_VAR: forward -> 1],
   * and BASELINE.json north_star's criterion verbatim: |price_gpu - price_cpu| <= 2 x MC-stderr, per option.
-The two sides share the draw bit for bit (stream version 3: the same table and FMA sequence); they differ in the rounding
+The two sides share the draw bit for bit (stream version 4: the same table and FMA sequence); they differ in the rounding
 of exp / log / 1/x and in the accumulator form of the device step, amplified by sigma = exp(sum of increments).
 """
 import numpy as np

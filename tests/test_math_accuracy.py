@@ -158,7 +158,7 @@ def test_sqrt_and_rcp(probe):
 
 
 def test_normal_icdf32(probe):
-    """normal_icdf32: one N(0,1) variate from one raw 32-bit word (random stream version 3) -- the product's own source
+    """normal_icdf32: one N(0,1) variate from one raw 32-bit word (random stream version 4) -- the product's own source
     compiled for the host must be the CPU twin's function bit for bit (oracle svo_normal_from_word restates it in C), and
     within the table's stated error of Phi^-1"""
     from scipy.special import ndtri
@@ -172,8 +172,10 @@ def test_normal_icdf32(probe):
     probe.probe_normal_icdf32(w.ctypes.data_as(U32), z.ctypes.data_as(DP), C.c_size_t(w.size))
     twin = np.array([oracle.normal_from_word(int(v)) for v in w])
     np.testing.assert_array_equal(z, twin)
-    t = w.view(np.int32).astype(np.float64) + 0.5
-    assert float(np.max(np.abs(z - np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t)))) <= 1e-9
+    t = w.view(np.int32).astype(np.float64)                # stream version 4: the lattice point is the signed word itself
+    with np.errstate(divide="ignore"):
+        exact = np.where(t == 0.0, 0.0, np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t))
+    assert float(np.max(np.abs(z - exact))) <= 1e-9
 
 
 def test_log_state(probe):

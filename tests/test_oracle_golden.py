@@ -68,7 +68,7 @@ def test_normal_stream_moments(oracle):
 
 
 def test_inverse_cdf_table_against_scipy(oracle):
-    """stream version 3 turns a 32-bit word into a normal with a piecewise cubic of the inverse normal CDF
+    """stream version 4 (as 3) turns a 32-bit word into a normal with a piecewise cubic of the inverse normal CDF
     (tools/gen_icdf_table.py -> oracle/svo_icdf_table.h == stochvolmodels_amd/csrc/svmc_icdf_table.h).  Pin it against an
     independent Phi^-1 (scipy.special.ndtri) at the accuracy the header states, on the extreme words, around every octave
     edge of both signs and on a dense random set; and check the properties the stream's definition promises: exact
@@ -90,21 +90,26 @@ def test_inverse_cdf_table_against_scipy(oracle):
         words += [edge.astype(np.uint32), (-edge).astype(np.uint32)]
     w = np.concatenate(words)
     z = np.array([oracle.normal_from_word(int(v)) for v in w])
-    t = w.view(np.int32).astype(np.float64) + 0.5
-    exact = np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t)
+    t = w.view(np.int32).astype(np.float64)               # stream version 4: the signed word itself is the lattice point
+    with np.errstate(divide="ignore"):
+        exact = np.where(t == 0.0, 0.0, np.copysign(-ndtri(np.abs(t) * 2.0 ** -32), t))
     err = np.abs(z - exact)
     print(f"inverse-CDF table: max |z - Phi^-1| = {err.max():.3e} (stated {stated:.3e}) over {w.size} words")
     assert err.max() <= 1.02 * stated
-    # w and ~w are the lattice points t and -t
-    zc = np.array([oracle.normal_from_word(int(v)) for v in (~w[:5000])])
+    # w and -w (mod 2^32) are the lattice points t and -t: exactly symmetric -- the two words without a partner, 0 and
+    # 0x80000000 (|t| = 2^31, where -Phi^-1(1/2) = 0), both give zero
+    wn = (-w[:5000].astype(np.int64)).astype(np.uint32)
+    zc = np.array([oracle.normal_from_word(int(v)) for v in wn])
     np.testing.assert_array_equal(zc, -z[:5000])
-    # |t| small is the tail: on each sign the normal decreases as the signed word grows (from -0 down to -6.34 over the
-    # negative words, from +6.34 down to +0 over the positive ones), up to the table's own error at segment joins
+    assert oracle.normal_from_word(0) == 0.0 and oracle.normal_from_word(0x80000000) == 0.0
+    # |t| small is the tail: on each sign the normal decreases as the signed word grows (from -0 down to -6.23 over the
+    # negative words, from +6.23 down to +0 over the positive ones), up to the table's own error at segment joins
     k = w.view(np.int32)
-    for half in (k < 0, k >= 0):
+    for half in (k < 0, k > 0):
         order = np.argsort(k[half], kind="stable")
         assert np.all(np.diff(z[half][order]) <= 2.0 * stated)
-    assert z.max() <= 6.338 and z.min() >= -6.338 and z[k >= 0].min() > 0.0 and z[k < 0].max() < 0.0
+    assert z.max() <= 6.231 and z.min() >= -6.231 and z[k > 0].min() > 0.0 and z[(k < 0) & (k > -2 ** 31)].max() < 0.0
+    assert abs(z.max() - 6.2302) < 1e-3                       # -Phi^-1(2^-32): the words 1 and 0xFFFFFFFF are in the sample
 
 
 def test_time_grid(oracle, golden):

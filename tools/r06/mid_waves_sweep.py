@@ -19,6 +19,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 SIZES = (16384, 65536, 100000, 131072, 200000, 262144, 400000, 524288, 786432, 1048576)
+if os.environ.get("SVMC_SWEEP_SIZES"):          # e.g. the path counts either side of the few-waves / full-launch switch
+    SIZES = tuple(int(v) for v in os.environ["SVMC_SWEEP_SIZES"].split(","))
 
 
 def timed(fn, calls):
