@@ -56,6 +56,21 @@ def test_host_only_entry_points_work_without_gpu():
     assert np.isnan(prices[1])                                 # 0/0 like nanmean of an all-NaN slice
 
 
+def test_random_stream_version_is_one_number_everywhere():
+    """the stream version the library reports, the header's define, the Python constant and the table both sides were generated
+    from (version 4: the lattice point of a word is the signed integer itself, SVMC_ICDF_HALF_LATTICE 0) agree"""
+    import stochvolmodels_amd as sv
+    from stochvolmodels_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "svmc.h")).read()
+    declared = int(re.search(r"#define SVMC_RNG_STREAM_VERSION (\d+)", header).group(1))
+    assert declared == sv.RNG_STREAM_VERSION == _lib.load().svmc_rng_stream_version() == 4
+    for rel in (("stochvolmodels_amd", "csrc", "svmc_icdf_table.h"), ("oracle", "svo_icdf_table.h")):
+        table = open(os.path.join(root, *rel)).read()
+        assert "#define SVMC_ICDF_HALF_LATTICE 0" in table and "#define SVMC_ICDF_RAW 1" in table
+        assert f"version {declared}" in table.splitlines()[1]
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
 def test_no_cpu_fallback():
     import stochvolmodels_amd as sv
